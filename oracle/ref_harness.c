@@ -1,0 +1,106 @@
+/*
+ * ref_harness.c -- driver glue around the REAL reference solver (test infrastructure).
+ *
+ * Compiled only where /root/reference exists (this container) by oracle/Makefile,
+ * together with the reference's own sources where they lie:
+ *   SiftGPU/ba_libs/lib/sba-1.5/{sba_levmar,sba_levmar_wrap,sba_lapack,sba_crsm,sba_chkjac}.c
+ *   SiftGPU/ba_libs/lib/sfm-driver/sfm.c, lib/matrix/{matrix,vector}.c, lib/cminpack/lm*.c ...
+ * into oracle/_ref/libref_sfm.so (git-ignored).  LAPACK/BLAS = the image's MKL
+ * (/opt/conda/lib/libmkl_rt.so.1, LP64), as SURVEY.md section 8c verified.
+ *
+ * The reference's optimizer main (Optimizer/main_all.cpp) is missing from the tree, so
+ * there are two ways in, both kept:
+ *   1. run_sfm(...)            -- Bundler's own driver, sfm.c:598, untouched.
+ *   2. ref_sba_motstr(...)     -- calls the reference's sba_motstr_levmar (sba.h:95) with a
+ *      projection callback that forwards to the reference's exported rot_update (sfm.c:78)
+ *      and sfm_project_rd (sfm.c:303) exactly the way its static sfm_project_point3
+ *      (sfm.c:509-558) does; this exposes itmax/opts/info and the Uout/Vout/Wout/Sout hooks,
+ *      which run_sfm hard-codes or hides.
+ * Nothing here restates the solver: every number comes out of reference code.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "sba.h"
+#include "sfm.h"
+
+typedef struct {
+    camera_params_t *cams;
+    int est_focal, undistort, explicit_centers;
+} glue_t;
+
+/* same call sequence as sfm_project_point3 (static in sfm.c:509-558), minus its
+ * last-rotation cache (sfm.c:545-553), which only avoids recomputing rot_update */
+static void glue_project(int j, int i, double *aj, double *bi, double *xij, void *adata)
+{
+    glue_t *g = (glue_t *)adata;
+    double K[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, Rnew[9];
+    double *dt = aj, *w = aj + 3, *k;
+    (void)i;
+    if (!g->est_focal) K[0] = K[4] = g->cams[j].f;
+    else K[0] = K[4] = aj[6] / g->cams[j].f_scale; /* TEST_FOCAL branch, sfm.c:532 */
+    k = g->est_focal ? aj + 7 : aj + 6;
+    rot_update(g->cams[j].R, w, Rnew);
+    sfm_project_rd(g->cams + j, K, k, Rnew, dt, bi, xij, g->undistort, g->explicit_centers);
+}
+
+int ref_sba_motstr(int n, int m, int mcon, int cnp, const int *pt_ptr, const int *obs_cam,
+                   const double *x, double *p, const double *R0, const double *f_fixed,
+                   int est_focal, int undistort, int explicit_centers,
+                   int itmax, int verbose, const double *opts6, double *info10,
+                   double *Vout, double *Sout, double *Uout, double *Wout)
+{
+    int nobs = pt_ptr[n], i, j, o, ret;
+    char *vmask = (char *)calloc((size_t)n * m, 1);
+    camera_params_t *cams = (camera_params_t *)calloc(m, sizeof(camera_params_t));
+    double *xx = (double *)malloc(sizeof(double) * 2 * nobs);
+    glue_t g;
+    if (!vmask || !cams || !xx) return -2;
+    for (i = 0; i < n; ++i)
+        for (o = pt_ptr[i]; o < pt_ptr[i + 1]; ++o) vmask[(size_t)i * m + obs_cam[o]] = 1;
+    memcpy(xx, x, sizeof(double) * 2 * nobs); /* sba wants a non-const, compact (i,j)-ordered x */
+    for (j = 0; j < m; ++j) {
+        memcpy(cams[j].R, R0 + 9 * j, 9 * sizeof(double));
+        cams[j].f = f_fixed ? f_fixed[j] : 1.0;
+        cams[j].known_intrinsics = 0;
+        cams[j].f_scale = 0.001; /* values run_sfm installs under TEST_FOCAL, sfm.c:640-663 */
+        cams[j].k_scale = 5.0;
+    }
+    g.cams = cams; g.est_focal = est_focal; g.undistort = undistort; g.explicit_centers = explicit_centers;
+    ret = sba_motstr_levmar(n, m, mcon, vmask, p, cnp, 3, xx, NULL, 2, glue_project, NULL, &g,
+                            itmax, verbose, opts6, info10, 0, NULL, 0, NULL, Vout, Sout, Uout, Wout);
+    free(vmask); free(cams); free(xx);
+    return ret;
+}
+
+/* Bundler's driver as is.  cams_R m*9, cams_t m*3 (t or C), cams_f m, cams_k m*2 are read
+ * and written back; pts n*3 likewise. */
+void ref_run_sfm(int n, int m, int ncons, const int *pt_ptr, const int *obs_cam, const double *x,
+                 int est_focal, int undistort, int explicit_centers,
+                 double *cams_R, double *cams_t, double *cams_f, double *cams_k, double *pts, double eps2)
+{
+    int nobs = pt_ptr[n], i, j, o;
+    char *vmask = (char *)calloc((size_t)n * m, 1);
+    camera_params_t *cams = (camera_params_t *)calloc(m, sizeof(camera_params_t));
+    double *xx = (double *)malloc(sizeof(double) * 2 * nobs);
+    v3_t *P = (v3_t *)malloc(sizeof(v3_t) * n);
+    for (i = 0; i < n; ++i) {
+        for (o = pt_ptr[i]; o < pt_ptr[i + 1]; ++o) vmask[(size_t)i * m + obs_cam[o]] = 1;
+        Vx(P[i]) = pts[3 * i]; Vy(P[i]) = pts[3 * i + 1]; Vz(P[i]) = pts[3 * i + 2];
+    }
+    memcpy(xx, x, sizeof(double) * 2 * nobs);
+    for (j = 0; j < m; ++j) {
+        memcpy(cams[j].R, cams_R + 9 * j, 9 * sizeof(double));
+        memcpy(cams[j].t, cams_t + 3 * j, 3 * sizeof(double));
+        cams[j].f = cams_f[j]; cams[j].k[0] = cams_k[2 * j]; cams[j].k[1] = cams_k[2 * j + 1];
+    }
+    run_sfm(n, m, ncons, vmask, xx, est_focal, 0, undistort, explicit_centers, cams, P,
+            0, 0, NULL, 0.0, 0, 0, eps2, NULL, NULL, NULL, NULL);
+    for (j = 0; j < m; ++j) {
+        memcpy(cams_R + 9 * j, cams[j].R, 9 * sizeof(double));
+        memcpy(cams_t + 3 * j, cams[j].t, 3 * sizeof(double));
+        cams_f[j] = cams[j].f; cams_k[2 * j] = cams[j].k[0]; cams_k[2 * j + 1] = cams[j].k[1];
+    }
+    for (i = 0; i < n; ++i) { pts[3 * i] = Vx(P[i]); pts[3 * i + 1] = Vy(P[i]); pts[3 * i + 2] = Vz(P[i]); }
+    free(vmask); free(cams); free(xx); free(P);
+}
