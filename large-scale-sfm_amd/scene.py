@@ -120,9 +120,12 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
     X_true = rng.uniform(-1, 1, (n, 3))
     start = rng.integers(0, m, n)
     stride = rng.choice(np.asarray(strides), n)
-    cams = (start[:, None] + stride[:, None] * np.arange(d)[None, :]) % m
+    if m >= d * max(strides):
+        cams = (start[:, None] + stride[:, None] * np.arange(d)[None, :]) % m
+    else:  # tiny scenes: the stride pattern would wrap onto itself -> d distinct random cameras
+        assert d <= m
+        cams = np.argsort(rng.random((n, m)), axis=1)[:, :d]
     cams.sort(axis=1)
-    assert m >= d * max(strides), "stride pattern would wrap onto itself"
     obs_cam = cams.reshape(-1).astype(np.int32)
     pt_ptr = (np.arange(n + 1) * d).astype(np.int32)
     obs_pt = np.repeat(np.arange(n), d)

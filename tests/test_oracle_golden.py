@@ -1,0 +1,122 @@
+"""Pin the CPU restatement (oracle/ba_oracle.c) to vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import scene_from_golden
+
+NAMES = ["micro", "C1", "C1t"]
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_blocks_at_p0(oracle, name):
+    sc, z = scene_from_golden(name)
+    lin = oracle.linearize(sc, fd_jacobian=1)
+    assert abs(lin["cost"] - float(z["cost0"])) <= 1e-12 * float(z["cost0"])
+    assert rel(lin["U"], z["U0"]) < 1e-9
+    assert rel(lin["V"], z["V0"]) < 1e-9
+    # S = U - W V^-1 W^T cancels heavily; compare against the scale of U
+    assert np.abs(lin["S"] - z["S0"]).max() < 1e-9 * np.abs(z["U0"]).max()
+    if "W0" in z.files:
+        m, n, cnp = sc.m, sc.n, sc.cnp
+        Wd = np.zeros((m * cnp, n * 3))
+        pt = sc.obs_pt()
+        for o in range(sc.nobs):
+            j, i = sc.obs_cam[o], pt[o]
+            Wd[j * cnp:(j + 1) * cnp, 3 * i:3 * i + 3] = lin["W"][o]
+        assert rel(Wd, z["W0"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_analytic_jacobian_close_to_fd(oracle, name):
+    sc, z = scene_from_golden(name)
+    a = oracle.linearize(sc, fd_jacobian=0)
+    assert rel(a["U"], z["U0"]) < 1e-4
+    assert rel(a["V"], z["V0"]) < 1e-4
+    assert rel(a["ea"], oracle.linearize(sc, fd_jacobian=1)["ea"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_cost_trace(oracle, name):
+    sc, z = scene_from_golden(name)
+    want = z["cost_trace"]
+    got = np.array([oracle.run(sc, itmax=k)["info"][1] for k in range(1, len(want) + 1)])
+    assert np.allclose(got, want, rtol=1e-8, atol=0)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_full_solve(oracle, name):
+    sc, z = scene_from_golden(name)
+    r = oracle.run(sc, itmax=150)
+    info, want = r["info"], z["info_final"]
+    assert r["ret"] == int(z["ret_final"])
+    for k in (5, 6, 7, 8, 9):               # iterations, stop reason, nfev, njev, nlss
+        assert info[k] == want[k], k
+    assert abs(info[0] - want[0]) <= 1e-12 * want[0]
+    rm, rw = np.sqrt(info[1] / sc.nobs), np.sqrt(want[1] / sc.nobs)
+    assert abs(rm - rw) <= 1e-6              # SURVEY section 8c tolerance, FD switch on
+    assert np.abs(r["p"] - z["p_final"]).max() < 1e-6
+    assert abs(info[4] - want[4]) <= 1e-6 * want[4]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fixed_cameras_mcon(oracle, name):
+    sc, z = scene_from_golden(name)
+    r = oracle.run(sc, itmax=150, mcon=2)
+    assert np.array_equal(r["p"][:2 * sc.cnp], sc.p0[:2 * sc.cnp])
+    assert r["info"][5] == z["info_mcon2"][5] and r["info"][6] == z["info_mcon2"][6]
+    assert np.abs(r["p"] - z["p_mcon2"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_matches_run_sfm(oracle, name):
+    """Bundler's own driver (sfm.c:598) end to end: unpack as sfm.c:881-935 does."""
+    from oracle import Oracle
+    import ctypes as C
+    sc, z = scene_from_golden(name)
+    r = oracle.run(sc, itmax=150)
+    m, cnp = sc.m, sc.cnp
+    a = r["p"][:m * cnp].reshape(m, cnp)
+    R = np.zeros((m, 9))
+    for j in range(m):
+        oracle.lib.ora_rot_update(sc.R0[j].ctypes.data_as(C.POINTER(C.c_double)),
+                                  np.ascontiguousarray(a[j, 3:6]).ctypes.data_as(C.POINTER(C.c_double)),
+                                  R[j].ctypes.data_as(C.POINTER(C.c_double)))
+    assert np.abs(R.reshape(m, 3, 3) - z["sfm_R"]).max() < 1e-7
+    assert np.abs(a[:, :3] - z["sfm_t"]).max() < 1e-6
+    assert np.abs(a[:, 6] / 0.001 - z["sfm_f"]).max() < 1e-3
+    assert np.abs(r["p"][m * cnp:].reshape(-1, 3) - z["sfm_pts"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["C1", "C1t"])
+def test_pcg_mode_reaches_same_minimum(oracle, name):
+    """The engine's inexact solve (block-Jacobi PCG, analytic Jacobian) vs the reference's
+    exact dense Cholesky + FD Jacobian: same converged RMSE within max(1e-3 px, 0.5 %)."""
+    sc, z = scene_from_golden(name)
+    r = oracle.run(sc, itmax=150, fd_jacobian=0, solver=1, pcg_tol=1e-3, pcg_maxit=100)
+    rm, rw = np.sqrt(r["info"][1] / sc.nobs), np.sqrt(z["info_final"][1] / sc.nobs)
+    assert abs(rm - rw) <= max(1e-3, 0.005 * rw)
+    assert r["info"][5] == z["info_final"][5]
+
+
+def test_too_few_measurements_is_an_error(oracle):
+    sc, _ = scene_from_golden("micro")
+    sc.n = 2   # 2 points -> 2*nobs < unknowns (sba_levmar.c:647-650)
+    sc.pt_ptr = sc.pt_ptr[:3].copy()
+    sc.p0 = np.concatenate([sc.p0[:sc.m * sc.cnp], sc.p0[sc.m * sc.cnp:sc.m * sc.cnp + 6]])
+    assert oracle.run(sc, itmax=5)["ret"] == -1
+
+
+def test_live_reference_if_present(oracle):
+    from oracle import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref not built here")
+    from conftest import pkg
+    sc = pkg("scene").make_scene("x", m=15, n=700, d=4, seed=31337)
+    a, b = oracle.run(sc, itmax=40), Reference().run(sc, itmax=40)
+    assert a["ret"] == b["ret"] and a["info"][6] == b["info"][6]
+    assert np.abs(a["p"] - b["p"]).max() < 1e-6
