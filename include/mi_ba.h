@@ -1,0 +1,158 @@
+/*
+ * mi_ba.h -- C ABI of the MI355X-native bundle-adjustment engine (libmi_ba.so).
+ *
+ * Drop-in boundary for the Optimizer/ hot path of large-scale-sfm.  Plain C, host pointers
+ * and sizes only; the library owns every HIP allocation, stream, graph and RCCL communicator.
+ * The C++ plugin surface of the reference (class ParallelBA, Optimizer/pba/src/pba/pba.h:52-133)
+ * and its C solver entry points (sba_motstr_levmar, Optimizer/sba-1.5/sba.h:95-108; run_sfm,
+ * SiftGPU/ba_libs/lib/sfm-driver/sfm.h:68-86) are thin shims over THIS header -- see
+ * include/mi_pba.h, include/mi_sba.h and INTEGRATION.md.
+ *
+ * Parameterisation = the one Bundler's run_sfm hands to sba (sfm.c:657-709): per camera
+ *   a_j = [ C_j or t_j (3) | omega_j (3) | f_j * f_scale (if est_focal) | k1*k_scale, k2*k_scale (if undistort) ]
+ * around a fixed initial rotation R0_j (R_j = exp([omega_j]x) R0_j, sfm.c:78-117,545-553), per
+ * point b_i = [X Y Z].  Projection (sfm.c:303-374):
+ *   q = R_j (X - C_j)   or   R_j X + t_j ;   x^ = proj_sign * f * q.xy / q.z * (1 + k1 r^2 + k2 r^4)
+ * proj_sign = -1 is Bundler's camera (sfm.c:333), +1 the VisualSFM / PBA one (+z forward).
+ * All arithmetic on the device is IEEE double.
+ *
+ * Error behaviour follows the reference: entry points return >= 0 on success and MI_BA_ERROR (-1,
+ * = SBA_ERROR, sba.h:57) on failure with a message in mi_ba_last_error(); nothing throws; a
+ * missing GPU / HIP runtime failure is an error, never a silent CPU fallback.
+ */
+#ifndef MI_BA_H
+#define MI_BA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_BA_ERROR (-1)
+#define MI_BA_INFOSZ 10      /* SBA_INFOSZ, sba.h:56 */
+#define MI_BA_VERSION 100
+
+typedef struct mi_ba_engine mi_ba_engine;
+typedef struct mi_ba_plan mi_ba_plan;
+
+typedef struct {
+    /* model (sfm.c:598-617 arguments of run_sfm) */
+    int est_focal;          /* 1: focal length is a parameter (cnp 7), 0: fixed (cnp 6) */
+    int undistort;          /* 1: k1,k2 are parameters (reserved; round 1 supports 0 only) */
+    int explicit_centers;   /* 1: camera params hold the centre C, 0: the translation t */
+    int mcon;               /* first mcon cameras are held fixed (sba.h:95 'mcon') */
+    double proj_sign;       /* -1 Bundler, +1 VisualSFM/PBA */
+    double f_scale;         /* 0.001, sfm.c:640 */
+    double k_scale;         /* 5.0,   sfm.c:641 */
+    /* Levenberg-Marquardt controller (sba_levmar.c:506-511,609-612) */
+    int itmax;              /* 150 = MAX_ITERS, sfm.c:820 */
+    double opts[6];         /* tau, eps1, eps2, eps3, eps4, eps5 (sfm.c:711-719) */
+    int disable_stops;      /* bench only: keep iterating after the stop rules would fire */
+    /* reduced camera system: block-Jacobi PCG (role of sba_Axb_Chol, sba_lapack.c:374) */
+    int pcg_maxit;
+    double pcg_tol;         /* stop when sqrt(r'z / r0'z0) < pcg_tol */
+    /* placement */
+    int device;             /* HIP device ordinal */
+    int rank, world;        /* point shard of this process; world > 1 needs mi_ba_comm_init */
+    int verbose;
+    /* planner knobs (0 = default) */
+    int tile_max_batches;
+    int reserved[7];
+} mi_ba_config;
+
+/* fills the defaults above (Bundler's run_sfm settings, cnp 7, explicit centres) */
+void mi_ba_default_config(mi_ba_config *cfg);
+
+/* ---- engine life cycle ---------------------------------------------------------------- */
+mi_ba_engine *mi_ba_create(const mi_ba_config *cfg);     /* NULL when no usable HIP device */
+void mi_ba_destroy(mi_ba_engine *e);
+const char *mi_ba_last_error(const mi_ba_engine *e);      /* e == NULL: error of mi_ba_create */
+int mi_ba_cnp(const mi_ba_engine *e);
+
+/* ---- problem definition; roles of ParallelBA::SetCameraData / SetPointData / SetProjection
+ *      (pba.h:96-101).  Host arrays are copied; the caller keeps ownership. ------------------- */
+int mi_ba_set_cameras(mi_ba_engine *e, int m, const double *a0 /* m*cnp */, const double *R0 /* m*9 */,
+                      const double *f_fixed /* m, used when !est_focal; may be NULL otherwise */);
+int mi_ba_set_points(mi_ba_engine *e, int n, const double *xyz /* n*3 */);
+/* observations sorted by point (pt_idx non-decreasing, like pba's driver.cpp:158-161 requires) */
+int mi_ba_set_observations(mi_ba_engine *e, int64_t nobs, const double *xy /* nobs*2 */,
+                           const int *pt_idx, const int *cam_idx);
+/* builds the shard plan, uploads everything to HBM */
+int mi_ba_prepare(mi_ba_engine *e);
+
+/* ---- solve: the role of sba_motstr_levmar / RunBundleAdjustment ------------------------- */
+/* returns the number of LM iterations (>= 0) or MI_BA_ERROR; info[] as sba's (sba_levmar.c:512-527) */
+int mi_ba_run(mi_ba_engine *e, double info[MI_BA_INFOSZ]);
+/* step-wise driving (bench, tests): begin() evaluates the initial cost and picks mu0,
+ * step() = ONE damping trial = one reduced system built + solved + gain-ratio test.
+ * step() returns 1 accepted, 0 rejected, 2 stopped (see info[6]), MI_BA_ERROR on failure. */
+int mi_ba_begin(mi_ba_engine *e);
+int mi_ba_step(mi_ba_engine *e);
+int mi_ba_get_info(const mi_ba_engine *e, double info[MI_BA_INFOSZ]);
+/* per trial: itno, mu, cost_before, cost_trial, accepted, pcg_iterations (6 doubles each) */
+int mi_ba_get_trace(const mi_ba_engine *e, double *trace, int cap);
+/* current estimate, original point order */
+int mi_ba_get_params(mi_ba_engine *e, double *a /* m*cnp */, double *xyz /* n*3 */);
+/* reset the estimate (keeps the plan) */
+int mi_ba_set_params(mi_ba_engine *e, const double *a, const double *xyz);
+/* final rotations R_j = exp([omega_j]x) R0_j, m*9 (sfm.c:897) */
+int mi_ba_get_rotations(mi_ba_engine *e, double *R);
+
+/* ---- parity hooks: what sba exports through Uout/Vout/Sout (sba_levmar.c:1633-2026) -------
+ * One linearisation at the current estimate with damping mu (mu = 0 allowed when every V_i is
+ * invertible).  Any pointer may be NULL.
+ *   S   (m*cnp)^2 row-major reduced camera matrix  U* - W V*^-1 W^T
+ *   E   m*cnp  reduced right-hand side,  ea m*cnp = sum A^T e,  eb n*3 = sum B^T e,
+ *   V   n*9 undamped V_i (full symmetric),  diagU m*cnp, returns cost in *cost              */
+int mi_ba_debug_linearize(mi_ba_engine *e, double mu, double *S, double *E, double *ea, double *eb,
+                          double *V, double *diagU, double *cost);
+/* after debug_linearize: solve S da = E with the PCG, back-substitute; da m*cnp, db n*3,
+ * cost at p + dp; returns PCG iterations or MI_BA_ERROR */
+int mi_ba_debug_solve(mi_ba_engine *e, double mu, double *da, double *db, double *cost_new);
+
+/* ---- measurement: device-side timings from HIP events on the engine's stream ------------ */
+typedef struct {
+    double build_ms, build_launches;       /* fused linearise + Schur kernel(s) */
+    double pcg_ms, pcg_solves, pcg_iters;
+    double backsub_ms, backsub_launches;
+    double step_ms, steps;                 /* whole trial incl. host control */
+    double allreduce_ms, allreduces;
+    double build_bytes;                    /* algorithmic HBM bytes of one build launch */
+    double reserved[5];
+} mi_ba_timing;
+int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
+int mi_ba_reset_timing(mi_ba_engine *e);
+
+/* ---- multi-GPU: one process per GPU, points sharded, RCCL all-reduce of the Schur partials */
+#define MI_BA_UNIQUE_ID_BYTES 128
+int mi_ba_comm_unique_id(char id[MI_BA_UNIQUE_ID_BYTES]);                 /* rank 0 */
+int mi_ba_comm_init(mi_ba_engine *e, const char id[MI_BA_UNIQUE_ID_BYTES]); /* every rank, before prepare */
+
+/* ---- planner (host only; usable without a GPU) -------------------------------------------
+ * Same code the engine runs in mi_ba_prepare: point permutation (visibility-signature sort),
+ * shard cut, wave batches, LDS tiles, pair tables and the block-sparse pattern of S.          */
+mi_ba_plan *mi_ba_plan_build(int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
+                             int rank, int world, int tile_max_batches);
+void mi_ba_plan_free(mi_ba_plan *p);
+/* stats: see MI_BA_PLAN_* indices */
+enum {
+    MI_BA_PLAN_NPTS_LOCAL = 0, MI_BA_PLAN_NOBS_LOCAL, MI_BA_PLAN_NBATCH, MI_BA_PLAN_NTILE,
+    MI_BA_PLAN_NPAIR, MI_BA_PLAN_NB_UPPER, MI_BA_PLAN_NB_FULL, MI_BA_PLAN_NSLOT_TOTAL,
+    MI_BA_PLAN_NBATCH_DIRECT, MI_BA_PLAN_NPAIR_DIRECT, MI_BA_PLAN_NLONG, MI_BA_PLAN_PT_BEGIN,
+    MI_BA_PLAN_PT_END, MI_BA_PLAN_MAX_SLOTS, MI_BA_PLAN_NSTATS = 16
+};
+int mi_ba_plan_stats(const mi_ba_plan *p, int64_t stats[MI_BA_PLAN_NSTATS]);
+/* array access for tests: returns element count, copies min(cap, count) elements.
+ * names: "perm" (int32, internal->original point), "obs_cam", "obs_pt" (int32, internal local),
+ * "obs_src" (int64 original observation index), "batch_obs", "batch_pair", "batch_pt", "tile_batch",
+ * "tile_slot", "slot_gblk", "tile_cslot", "cslot_cam", "pair" (uint32), "pair_gblk" (uint32),
+ * "obs_cslot" (uint8), "up_row" (int32 m+1), "up_col" (int32), "bsr_row", "bsr_col", "bsr_src",
+ * "tile_mode" (uint8: 1 = LDS accumulate, 0 = direct)                                           */
+int64_t mi_ba_plan_get(const mi_ba_plan *p, const char *name, void *out, int64_t cap_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_BA_H */

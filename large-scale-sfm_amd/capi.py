@@ -1,0 +1,241 @@
+"""ctypes binding of the C ABI in include/mi_ba.h (libmi_ba.so).
+
+Plumbing only: every number comes from the HIP engine.  There is no CPU fallback -- a missing
+library or a missing GPU raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmi_ba.so")
+CSRC = os.path.join(HERE, "csrc")
+
+INFOSZ = 10
+PLAN_STATS = ["npts_local", "nobs_local", "nbatch", "ntile", "npair", "nb_upper", "nb_full", "nslot_total",
+              "nbatch_direct", "npair_direct", "nlong", "pt_begin", "pt_end", "max_slots"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class Config(C.Structure):
+    _fields_ = [("est_focal", C.c_int), ("undistort", C.c_int), ("explicit_centers", C.c_int), ("mcon", C.c_int),
+                ("proj_sign", C.c_double), ("f_scale", C.c_double), ("k_scale", C.c_double),
+                ("itmax", C.c_int), ("opts", C.c_double * 6), ("disable_stops", C.c_int),
+                ("pcg_maxit", C.c_int), ("pcg_tol", C.c_double),
+                ("device", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("verbose", C.c_int),
+                ("tile_max_batches", C.c_int), ("reserved", C.c_int * 7)]
+
+
+class Timing(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("build_ms", "build_launches", "pcg_ms", "pcg_solves", "pcg_iters", "backsub_ms", "backsub_launches",
+                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes")] + [("reserved", C.c_double * 5)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+def build(force: bool = False) -> str:
+    """compile libmi_ba.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C {CSRC}); "
+                               "the engine has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.mi_ba_create.restype = C.c_void_p
+        L.mi_ba_last_error.restype = C.c_char_p
+        L.mi_ba_last_error.argtypes = [C.c_void_p]
+        L.mi_ba_plan_build.restype = C.c_void_p
+        L.mi_ba_plan_get.restype = C.c_int64
+        for name in ("mi_ba_destroy", "mi_ba_cnp", "mi_ba_prepare", "mi_ba_begin", "mi_ba_step", "mi_ba_reset_timing"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.mi_ba_plan_free.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def default_config(**kw) -> Config:
+    c = Config()
+    lib().mi_ba_default_config(C.byref(c))
+    for k, v in kw.items():
+        if k == "opts":
+            c.opts = (C.c_double * 6)(*v)
+        else:
+            setattr(c, k, v)
+    return c
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+class Engine:
+    """One engine = one GPU = one point shard."""
+
+    def __init__(self, cfg: Config | None = None, **kw):
+        self.L = lib()
+        self.cfg = cfg if cfg is not None else default_config(**kw)
+        self.h = self.L.mi_ba_create(C.byref(self.cfg))
+        if not self.h:
+            raise RuntimeError("mi_ba_create failed: " + self.L.mi_ba_last_error(None).decode())
+        self.cnp = self.L.mi_ba_cnp(self.h)
+        self.m = self.n = self.nobs = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_ba_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, r, what):
+        if r < 0:
+            raise RuntimeError(f"{what}: " + self.L.mi_ba_last_error(self.h).decode())
+        return r
+
+    def error(self) -> str:
+        return self.L.mi_ba_last_error(self.h).decode()
+
+    def load_scene(self, sc, p0=None):
+        """sc: large-scale-sfm_amd.scene.Scene (Bundler packing)."""
+        p0 = sc.p0 if p0 is None else p0
+        m, n, cnp = sc.m, sc.n, sc.cnp
+        assert cnp == self.cnp, (cnp, self.cnp)
+        self.set_problem(np.ascontiguousarray(p0[:m * cnp]).reshape(m, cnp), sc.R0, sc.f_fixed,
+                         np.ascontiguousarray(p0[m * cnp:]).reshape(n, 3), sc.x, sc.obs_pt(), sc.obs_cam)
+
+    def set_problem(self, a0, R0, f_fixed, xyz, xy, pt_idx, cam_idx):
+        a0 = np.ascontiguousarray(a0, np.float64); R0 = np.ascontiguousarray(R0, np.float64)
+        ff = None if f_fixed is None else np.ascontiguousarray(f_fixed, np.float64)
+        xyz = np.ascontiguousarray(xyz, np.float64); xy = np.ascontiguousarray(xy, np.float64)
+        pt = np.ascontiguousarray(pt_idx, np.int32); cam = np.ascontiguousarray(cam_idx, np.int32)
+        self.m, self.n, self.nobs = a0.shape[0], xyz.shape[0], xy.shape[0]
+        self._chk(self.L.mi_ba_set_cameras(self.h, self.m, _d(a0), _d(R0), _d(ff)), "set_cameras")
+        self._chk(self.L.mi_ba_set_points(self.h, self.n, _d(xyz)), "set_points")
+        self._chk(self.L.mi_ba_set_observations(self.h, C.c_int64(self.nobs), _d(xy), pt.ctypes.data_as(_ip),
+                                                cam.ctypes.data_as(_ip)), "set_observations")
+
+    def comm_init(self, uid: bytes):
+        buf = C.create_string_buffer(uid, 128)
+        self._chk(self.L.mi_ba_comm_init(self.h, buf), "comm_init")
+
+    def prepare(self):
+        self._chk(self.L.mi_ba_prepare(self.h), "prepare")
+
+    def run(self):
+        info = np.zeros(INFOSZ)
+        ret = self.L.mi_ba_run(self.h, _d(info))
+        return ret, info
+
+    def begin(self):
+        self._chk(self.L.mi_ba_begin(self.h), "begin")
+
+    def step(self) -> int:
+        return self._chk(self.L.mi_ba_step(self.h), "step")
+
+    def info(self):
+        info = np.zeros(INFOSZ)
+        self.L.mi_ba_get_info(self.h, _d(info))
+        return info
+
+    def trace(self):
+        n = self.L.mi_ba_get_trace(self.h, None, 0)
+        t = np.zeros((max(n, 1), 6))
+        self.L.mi_ba_get_trace(self.h, _d(t), n)
+        return t[:n]
+
+    def params(self):
+        a = np.zeros((self.m, self.cnp)); xyz = np.zeros((self.n, 3))
+        self._chk(self.L.mi_ba_get_params(self.h, _d(a), _d(xyz)), "get_params")
+        return a, xyz
+
+    def packed_params(self):
+        a, xyz = self.params()
+        return np.concatenate([a.reshape(-1), xyz.reshape(-1)])
+
+    def set_params(self, a, xyz):
+        a = np.ascontiguousarray(a, np.float64); xyz = np.ascontiguousarray(xyz, np.float64)
+        self._chk(self.L.mi_ba_set_params(self.h, _d(a), _d(xyz)), "set_params")
+
+    def rotations(self):
+        R = np.zeros((self.m, 9))
+        self._chk(self.L.mi_ba_get_rotations(self.h, _d(R)), "get_rotations")
+        return R
+
+    def debug_linearize(self, mu):
+        N = self.m * self.cnp
+        S = np.zeros((N, N)); E = np.zeros((self.m, self.cnp)); ea = np.zeros((self.m, self.cnp))
+        eb = np.zeros((self.n, 3)); V = np.zeros((self.n, 3, 3)); dU = np.zeros((self.m, self.cnp)); cost = C.c_double(0)
+        self._chk(self.L.mi_ba_debug_linearize(self.h, C.c_double(mu), _d(S), _d(E), _d(ea), _d(eb), _d(V), _d(dU),
+                                               C.byref(cost)), "debug_linearize")
+        return dict(S=S, E=E, ea=ea, eb=eb, V=V, diagU=dU, cost=cost.value)
+
+    def debug_solve(self, mu):
+        da = np.zeros((self.m, self.cnp)); db = np.zeros((self.n, 3)); cost = C.c_double(0)
+        its = self._chk(self.L.mi_ba_debug_solve(self.h, C.c_double(mu), _d(da), _d(db), C.byref(cost)), "debug_solve")
+        return dict(da=da, db=db, cost_new=cost.value, pcg_iters=its)
+
+    def timing(self) -> dict:
+        t = Timing()
+        self.L.mi_ba_get_timing(self.h, C.byref(t))
+        return t.as_dict()
+
+    def reset_timing(self):
+        self.L.mi_ba_reset_timing(self.h)
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    if lib().mi_ba_comm_unique_id(buf) != 0:
+        raise RuntimeError("mi_ba_comm_unique_id failed")
+    return buf.raw
+
+
+class Plan:
+    """host-only shard plan (usable without a GPU)."""
+
+    _dtypes = dict(obs_src=np.int64, batch_pair=np.int64, pair=np.uint32, pair_gblk=np.uint32, obs_cslot=np.uint8,
+                   tile_mode=np.uint8, bsr_trans=np.uint8)
+
+    def __init__(self, n, m, pt_idx, cam_idx, rank=0, world=1, tile_max_batches=0):
+        self.L = lib()
+        pt = np.ascontiguousarray(pt_idx, np.int32); cam = np.ascontiguousarray(cam_idx, np.int32)
+        self.h = self.L.mi_ba_plan_build(n, m, C.c_int64(len(pt)), pt.ctypes.data_as(_ip), cam.ctypes.data_as(_ip),
+                                         rank, world, tile_max_batches)
+        if not self.h:
+            raise ValueError("plan: " + self.L.mi_ba_last_error(None).decode())
+
+    def stats(self) -> dict:
+        s = (C.c_int64 * 16)()
+        self.L.mi_ba_plan_stats(C.c_void_p(self.h), s)
+        return {k: int(s[i]) for i, k in enumerate(PLAN_STATS)}
+
+    def get(self, name: str) -> np.ndarray:
+        n = self.L.mi_ba_plan_get(C.c_void_p(self.h), name.encode(), None, C.c_int64(0))
+        if n < 0:
+            raise KeyError(name)
+        out = np.zeros(max(n, 1), self._dtypes.get(name, np.int32))
+        self.L.mi_ba_plan_get(C.c_void_p(self.h), name.encode(), out.ctypes.data_as(C.c_void_p), C.c_int64(n))
+        return out[:n]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.mi_ba_plan_free(C.c_void_p(self.h))
+            self.h = None

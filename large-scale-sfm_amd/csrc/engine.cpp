@@ -1,0 +1,542 @@
+// engine.cpp -- see engine.h.  Host orchestration only; every number is produced by kernels.hip.
+#include "engine.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+
+namespace miba {
+
+namespace {
+constexpr double kEpsilonSq = 1E-12 * 1E-12; // SBA_EPSILON_SQ, sba_levmar.c:37-38
+constexpr double kOneThird = 0.3333333334;   // SBA_ONE_THIRD, sba_levmar.c:40
+constexpr int kPcgChunk = 8;                 // PCG iterations launched between two host checks
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+} // namespace
+
+bool Engine::hipok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+Engine::Engine(const mi_ba_config &c) : cfg(c)
+{
+    cnp = 6 + (cfg.est_focal ? 1 : 0);
+    if (cfg.undistort) { err = "undistort (k1,k2 as parameters, cnp 8/9) is not supported yet"; return; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        err = std::string("no HIP device: ") + (e == hipSuccess ? "device count is 0" : hipGetErrorString(e)) +
+              " (the engine has no CPU fallback)";
+        return;
+    }
+    if (cfg.device < 0 || cfg.device >= ndev) { err = "bad device ordinal"; return; }
+    if (!hipok(hipSetDevice(cfg.device), "hipSetDevice")) return;
+    if (!hipok(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking), "hipStreamCreate")) return;
+    for (auto &ev : ev_) if (!hipok(hipEventCreate(&ev), "hipEventCreate")) return;
+    if (!hipok(hipHostMalloc((void **)&h_scal_, sizeof(double) * 1024, hipHostMallocDefault), "hipHostMalloc")) return;
+    created_ = true;
+}
+
+Engine::~Engine()
+{
+    if (comm_) ncclCommDestroy((ncclComm_t)comm_);
+    if (h_scal_) (void)hipHostFree(h_scal_);
+    for (auto &ev : ev_) if (ev) (void)hipEventDestroy(ev);
+    if (st_) (void)hipStreamDestroy(st_);
+}
+
+ModelCfg Engine::model() const
+{
+    ModelCfg mc;
+    mc.explicit_centers = cfg.explicit_centers; mc.est_focal = cfg.est_focal; mc.undistort = cfg.undistort;
+    mc.mcon = cfg.mcon; mc.proj_sign = cfg.proj_sign; mc.f_scale = cfg.f_scale; mc.k_scale = cfg.k_scale;
+    return mc;
+}
+
+int Engine::set_cameras(int m, const double *a0, const double *R0, const double *f_fixed)
+{
+    if (m <= 0 || !a0 || !R0) { err = "set_cameras: bad arguments"; return MI_BA_ERROR; }
+    if (!cfg.est_focal && !f_fixed) { err = "set_cameras: f_fixed is required when the focal length is not estimated"; return MI_BA_ERROR; }
+    m_ = m;
+    h_a0_.assign(a0, a0 + (size_t)m * cnp);
+    h_R0_.assign(R0, R0 + (size_t)m * 9);
+    have_ff_ = f_fixed != nullptr;
+    if (have_ff_) h_ff_.assign(f_fixed, f_fixed + m); else h_ff_.assign(m, 1.0);
+    prepared_ = begun_ = false;
+    return 0;
+}
+
+int Engine::set_points(int n, const double *xyz)
+{
+    if (n <= 0 || !xyz) { err = "set_points: bad arguments"; return MI_BA_ERROR; }
+    n_ = n;
+    h_xyz_.assign(xyz, xyz + (size_t)n * 3);
+    prepared_ = begun_ = false;
+    return 0;
+}
+
+int Engine::set_observations(int64_t nobs, const double *xy, const int *pt_idx, const int *cam_idx)
+{
+    if (nobs <= 0 || !xy || !pt_idx || !cam_idx) { err = "set_observations: bad arguments"; return MI_BA_ERROR; }
+    nobs_ = nobs;
+    h_xy_.assign(xy, xy + (size_t)nobs * 2);
+    h_pt_.assign(pt_idx, pt_idx + nobs);
+    h_cam_.assign(cam_idx, cam_idx + nobs);
+    prepared_ = begun_ = false;
+    return 0;
+}
+
+int Engine::comm_init(const char *id)
+{
+    if (cfg.world <= 1) return 0;
+    ncclUniqueId uid;
+    static_assert(sizeof(uid) <= MI_BA_UNIQUE_ID_BYTES, "unique id size");
+    std::memcpy(&uid, id, sizeof(uid));
+    ncclComm_t c;
+    ncclResult_t r = ncclCommInitRank(&c, cfg.world, uid, cfg.rank);
+    if (r != ncclSuccess) { err = std::string("ncclCommInitRank: ") + ncclGetErrorString(r); return MI_BA_ERROR; }
+    comm_ = c;
+    return 0;
+}
+
+int Engine::prepare()
+{
+    if (!created_) return MI_BA_ERROR;
+    if (!m_ || !n_ || !nobs_) { err = "prepare: cameras, points and observations must be set first"; return MI_BA_ERROR; }
+    if (cfg.mcon < 0 || cfg.mcon > m_) { err = "prepare: bad mcon"; return MI_BA_ERROR; }
+    if (cfg.world > 1 && !comm_) { err = "prepare: world > 1 needs mi_ba_comm_init first"; return MI_BA_ERROR; }
+    // sba_levmar.c:645-650: fewer measurements than unknowns is an error
+    if (2 * nobs_ < (int64_t)m_ * cnp + 3 * (int64_t)n_) {
+        err = "cannot solve a problem with fewer measurements than unknowns";
+        return MI_BA_ERROR;
+    }
+    std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches);
+    if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
+    if (!plan_.long_pts.empty()) {
+        err = "plan: a point has more than 64 observations (long-track path not implemented yet)";
+        return MI_BA_ERROR;
+    }
+    const Plan &pl = plan_;
+#define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
+    UP(d_tile_batch_, pl.tile_batch); UP(d_tile_slot_, pl.tile_slot); UP(d_tile_cslot_, pl.tile_cslot);
+    UP(d_slot_gblk_, pl.slot_gblk); UP(d_cslot_cam_, pl.cslot_cam);
+    UP(d_batch_obs_, pl.batch_obs); UP(d_batch_pt_, pl.batch_pt); UP(d_pt_obs_, pl.pt_obs);
+    UP(d_obs_cam_, pl.obs_cam); UP(d_obs_pt_, pl.obs_pt); UP(d_obs_cslot_, pl.obs_cslot);
+    UP(d_pair_, pl.pair); UP(d_pair_gblk_, pl.pair_gblk);
+    UP(d_bsr_row_, pl.bsr_row); UP(d_bsr_col_, pl.bsr_col); UP(d_bsr_src_, pl.bsr_src); UP(d_bsr_trans_, pl.bsr_trans);
+    {
+        std::vector<long long> bp(pl.batch_pair.begin(), pl.batch_pair.end());
+        UP(d_batch_pair_, bp);
+        std::vector<int> rowidx(pl.nb_full()), diag(m_, -1);
+        for (int j = 0; j < m_; ++j)
+            for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) { rowidx[q] = j; if (pl.bsr_col[q] == j) diag[j] = q; }
+        UP(d_bsr_rowidx_, rowidx); UP(d_bsr_diag_, diag);
+        const int64_t nol = pl.nobs_local();
+        std::vector<double2> xy(nol);
+        for (int64_t o = 0; o < nol; ++o) { xy[o].x = h_xy_[2 * pl.obs_src[o]]; xy[o].y = h_xy_[2 * pl.obs_src[o] + 1]; }
+        UP(d_obs_xy_, xy);
+    }
+    UP(d_R0_, h_R0_); UP(d_ff_, h_ff_);
+#undef UP
+    const size_t npl = (size_t)pl.npts_local();
+    for (int b = 0; b < 2; ++b) {
+        if (!hipok(d_cam_a_[b].alloc((size_t)m_ * kCP), "alloc cam_a")) return MI_BA_ERROR;
+        if (!hipok(d_cam_lin_[b].alloc((size_t)m_ * kCamLin), "alloc cam_lin")) return MI_BA_ERROR;
+        if (!hipok(d_pts_[b].alloc(npl * 3), "alloc pts")) return MI_BA_ERROR;
+    }
+    const size_t acc_n = (size_t)pl.nb_up() * 64 + (size_t)3 * m_ * kCP + kScalCount;
+    if (!hipok(d_ptout_.alloc(npl * kPtOut), "alloc ptout") || !hipok(d_acc_.alloc(acc_n), "alloc acc") ||
+        !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Minv_.alloc((size_t)m_ * 64), "alloc Minv") ||
+        !hipok(d_E_.alloc((size_t)m_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)m_ * kCP), "alloc dA") ||
+        !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)m_ * kCP * 7), "alloc pcg") ||
+        !hipok(d_rzpq_.alloc((size_t)2 * (cfg.pcg_maxit + 4)), "alloc rz/pq"))
+        return MI_BA_ERROR;
+    if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
+    if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
+    prepared_ = true;
+    if (set_params(h_a0_.data(), h_xyz_.data()) != 0) return MI_BA_ERROR;
+    // algorithmic HBM bytes of one k_build launch (DESIGN.md "k_build"): observation stream 25 B,
+    // pair table 4 B, point in 24 B / ptout 96 B, camera records once, every S block once
+    timing.build_bytes = 25.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 120.0 * (double)npl +
+                         192.0 * m_ + 512.0 * pl.nb_up() + 4.0 * (double)pl.pair_gblk.size();
+    if (cfg.verbose)
+        std::fprintf(stderr, "[mi_ba] rank %d/%d: %lld pts %lld obs, %d batches, %d tiles (%d LDS), %zu pairs, S: %d upper / %d full blocks\n",
+                     cfg.rank, cfg.world, (long long)npl, (long long)pl.nobs_local(), pl.nbatch(), pl.ntile(), pl.ntile_lds,
+                     pl.pair.size(), pl.nb_up(), pl.nb_full());
+    return 0;
+}
+
+int Engine::set_params(const double *a, const double *xyz)
+{
+    if (!prepared_) { err = "set_params: prepare first"; return MI_BA_ERROR; }
+    std::vector<double> ap((size_t)m_ * kCP, 0.0);
+    for (int j = 0; j < m_; ++j)
+        for (int r = 0; r < cnp; ++r) ap[(size_t)j * kCP + r] = a[(size_t)j * cnp + r];
+    const Plan &pl = plan_;
+    const size_t npl = (size_t)pl.npts_local();
+    std::vector<double> pp(npl * 3);
+    for (size_t t = 0; t < npl; ++t)
+        for (int r = 0; r < 3; ++r) pp[3 * t + r] = xyz[3 * (size_t)pl.perm[pl.pt_begin + t] + r];
+    pl2_inactive_ = 0.0;
+    for (int t = pl.n_active; t < n_; ++t)
+        for (int r = 0; r < 3; ++r) { double v = xyz[3 * (size_t)pl.perm[t] + r]; pl2_inactive_ += v * v; }
+    if (xyz != h_xyz_.data()) h_xyz_.assign(xyz, xyz + (size_t)n_ * 3);
+    cur_ = 0;
+    if (!hipok(hipMemcpy(d_cam_a_[0].p, ap.data(), ap.size() * sizeof(double), hipMemcpyHostToDevice), "upload cam_a")) return MI_BA_ERROR;
+    if (npl && !hipok(hipMemcpy(d_pts_[0].p, pp.data(), pp.size() * sizeof(double), hipMemcpyHostToDevice), "upload pts")) return MI_BA_ERROR;
+    begun_ = false;
+    return 0;
+}
+
+bool Engine::allreduce1()
+{
+    if (cfg.world <= 1) return true;
+    double t0 = now_ms();
+    const size_t nsum = (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP + 8;
+    ncclResult_t r = ncclAllReduce(d_acc_.p, d_acc_.p, nsum, ncclDouble, ncclSum, (ncclComm_t)comm_, st_);
+    if (r == ncclSuccess) r = ncclAllReduce(scal_() + 8, scal_() + 8, 8, ncclDouble, ncclMax, (ncclComm_t)comm_, st_);
+    if (r != ncclSuccess) return fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    timing.allreduce_ms += now_ms() - t0; timing.allreduces += 1;
+    return true;
+}
+
+bool Engine::allreduce2()
+{
+    if (cfg.world <= 1) return true;
+    ncclResult_t r = ncclAllReduce(scal_() + 32, scal_() + 32, 8, ncclDouble, ncclSum, (ncclComm_t)comm_, st_);
+    if (r == ncclSuccess) r = ncclAllReduce(scal_() + 40, scal_() + 40, 8, ncclDouble, ncclMax, (ncclComm_t)comm_, st_);
+    if (r != ncclSuccess) return fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return true;
+}
+
+// linearise at the current estimate with damping mu and build the reduced camera system
+bool Engine::linear_phase(double mu)
+{
+    const Plan &pl = plan_;
+    const ModelCfg mc = model();
+    if (!hipok(hipMemsetAsync(d_acc_.p, 0, d_acc_.n * sizeof(double), st_), "memset acc")) return false;
+    launch_cam_prep(st_, m_, cnp, mc, d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p);
+    BuildArgs a{};
+    a.tile_batch = d_tile_batch_.p; a.tile_slot = d_tile_slot_.p; a.tile_cslot = d_tile_cslot_.p;
+    a.slot_gblk = d_slot_gblk_.p; a.cslot_cam = d_cslot_cam_.p;
+    a.batch_obs = d_batch_obs_.p; a.batch_pt = d_batch_pt_.p; a.batch_pair = d_batch_pair_.p; a.pt_obs = d_pt_obs_.p;
+    a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p;
+    a.pair = d_pair_.p; a.pair_gblk = d_pair_gblk_.p; a.pair_gblk_base = pl.npair_lds;
+    a.m = m_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
+    a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.scal = scal_(); a.cfg = mc;
+    (void)hipEventRecord(ev_[0], st_);
+    a.tile0 = 0;
+    launch_build(st_, cnp, true, pl.ntile_lds, a);
+    a.tile0 = pl.ntile_lds;
+    launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
+    (void)hipEventRecord(ev_[1], st_);
+    if (!allreduce1()) return false;
+    launch_finalize(st_, cnp, m_, pl.nb_full(), cfg.mcon, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
+                    S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_E_.p, scal_());
+    launch_block_inv(st_, m_, d_bsr_diag_.p, d_S_full_.p, d_Minv_.p, scal_());
+    return hipok(hipGetLastError(), "launch (linear phase)");
+}
+
+// PCG on S da = E, camera update, back-substitution, cost at the trial point
+bool Engine::solve_phase(double mu, double *dB_dev)
+{
+    const Plan &pl = plan_;
+    const ModelCfg mc = model();
+    const size_t vec = (size_t)m_ * kCP;
+    PcgArgs p{};
+    p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_full_.p; p.Minv = d_Minv_.p; p.E = d_E_.p;
+    p.x = d_dA_.p; p.r = d_pcg_.p; p.r1 = d_pcg_.p + vec; p.z = d_pcg_.p + 2 * vec; p.p0 = d_pcg_.p + 3 * vec;
+    p.p1 = d_pcg_.p + 4 * vec; p.q = d_pcg_.p + 5 * vec;
+    p.rz = d_rzpq_.p; p.pq = d_rzpq_.p + (cfg.pcg_maxit + 4); p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = m_; p.it = 0;
+    if (!hipok(hipMemsetAsync(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double), st_), "memset rz/pq")) return false;
+    (void)hipEventRecord(ev_[2], st_);
+    launch_pcg_init(st_, p);
+    int it = 0;
+    const int nrz = cfg.pcg_maxit + 4;
+    while (it < cfg.pcg_maxit) {
+        const int chunk = std::min(kPcgChunk, cfg.pcg_maxit - it);
+        for (int c = 0; c < chunk; ++c) { p.it = it + c; launch_pcg_iter(st_, p); }
+        it += chunk;
+        if (!hipok(hipMemcpyAsync(h_scal_ + 64, d_rzpq_.p, sizeof(double) * nrz, hipMemcpyDeviceToHost, st_), "copy rz")) return false;
+        if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
+        if (!hipok(hipStreamSynchronize(st_), "sync (pcg)")) return false;
+        const double *rz = h_scal_ + 64;
+        if (h_scal_[SC_PCG_STATUS] != 0.0 || !(rz[0] > 0.0)) break;
+        if (it <= cfg.pcg_maxit && std::sqrt(std::fabs(rz[it]) / rz[0]) < cfg.pcg_tol) break;
+    }
+    (void)hipEventRecord(ev_[3], st_);
+    launch_cam_update(st_, m_, cnp, mc, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, d_cam_a_[cur_ ^ 1].p,
+                      d_cam_lin_[cur_ ^ 1].p, scal_());
+    BacksubArgs b{};
+    b.batch_obs = d_batch_obs_.p; b.batch_pt = d_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
+    b.obs_xy = d_obs_xy_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
+    b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.scal = scal_();
+    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = pl.nbatch(); b.cfg = mc;
+    (void)hipEventRecord(ev_[4], st_);
+    launch_backsub(st_, cnp, b);
+    (void)hipEventRecord(ev_[5], st_);
+    if (!allreduce2()) return false;
+    return hipok(hipGetLastError(), "launch (solve phase)");
+}
+
+bool Engine::read_scalars()
+{
+    if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
+    return hipok(hipStreamSynchronize(st_), "sync");
+}
+
+int Engine::begin()
+{
+    if (!prepared_) { err = "begin: prepare first"; return MI_BA_ERROR; }
+    mu_ = 0; nu_ = 2; itno_ = 0; stop_ = 0; nfev_ = 1; njev_ = 0; nlss_ = 0; dp_L2_ = DBL_MAX; new_outer_ = true;
+    trace.clear();
+    // probe pass: cost at p0 and the largest diagonal entry of U, V -> mu0 = tau * max (sba_levmar.c:1124-1128)
+    if (!linear_phase(1.0) || !read_scalars()) return MI_BA_ERROR;
+    p_eL2_ = init_p_eL2_ = h_scal_[SC_COST];
+    maxdiag_ = std::max(std::max(h_scal_[SC_MAXDIAG_U], h_scal_[SC_MAXDIAG_V]), DBL_MIN);
+    eab_inf_ = std::max(h_scal_[SC_EA_INF], h_scal_[SC_EB_INF]);
+    mu_ = std::fabs(cfg.opts[0]) * maxdiag_;
+    if (!std::isfinite(p_eL2_)) stop_ = 7;
+    begun_ = true;
+    return 0;
+}
+
+void Engine::accept_trial() { cur_ ^= 1; }
+
+// one damping trial; the control flow is sba_levmar.c:1085-1614 unrolled into a resumable step
+int Engine::step()
+{
+    if (!begun_) { err = "step: begin first"; return MI_BA_ERROR; }
+    if (stop_ || itno_ >= cfg.itmax) { if (!stop_) stop_ = 3; return 2; }
+    const double t0 = now_ms();
+    const double eps1 = std::fabs(cfg.opts[1]), eps2 = std::fabs(cfg.opts[2]), eps2_sq = cfg.opts[2] * cfg.opts[2],
+                 eps3_sq = cfg.opts[3] * cfg.opts[3], eps4_sq = cfg.opts[4] * cfg.opts[4], eps5 = cfg.opts[5];
+    const bool stops = !cfg.disable_stops;
+    if (new_outer_) { ++njev_; new_outer_ = false; }
+    const double mu = mu_;
+    if (!linear_phase(mu) || !solve_phase(mu, nullptr) || !read_scalars()) return MI_BA_ERROR;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) { timing.build_ms += ms; timing.build_launches += 1; }
+    if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) { timing.pcg_ms += ms; timing.pcg_solves += 1; }
+    if (hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) { timing.backsub_ms += ms; timing.backsub_launches += 1; }
+    const double *s = h_scal_;
+    timing.pcg_iters += s[SC_PCG_ITERS];
+    p_eL2_ = s[SC_COST];
+    p_L2_ = s[SC_PL2_CAMS] + s[SC_PL2_PTS] + pl2_inactive_;
+    eab_inf_ = std::max(s[SC_EA_INF], s[SC_EB_INF]);
+    maxdiag_ = std::max(std::max(s[SC_MAXDIAG_U], s[SC_MAXDIAG_V]), DBL_MIN);
+    int ret = 0;
+    auto end_outer = [&]() { // tail of the outer for-loop body, sba_levmar.c:1614 + the ++itno
+        if (p_eL2_ <= eps3_sq && stops) stop_ = 5;
+        ++itno_; new_outer_ = true;
+        if (itno_ >= cfg.itmax) stop_ = 3; // sba_levmar.c:1617
+    };
+    auto push_trace = [&](double cost_trial, int accepted) {
+        const double row[6] = { (double)itno_, mu, p_eL2_, cost_trial, (double)accepted, s[SC_PCG_ITERS] };
+        trace.insert(trace.end(), row, row + 6);
+    };
+    do {
+        if (eab_inf_ <= eps1 && stops) { dp_L2_ = 0.0; stop_ = 1; ret = 2; break; }          // :1117-1121
+        if (s[SC_SINGULAR] != 0.0) { push_trace(NAN, 0); goto moredamping; }                 // :1156-1158
+        ++nlss_;
+        if (s[SC_PCG_STATUS] != 0.0 || s[SC_NOT_PD] != 0.0) { push_trace(NAN, 0); goto moredamping; } // issolved == 0
+        dp_L2_ = s[SC_DP2_CAMS] + s[SC_DP2_PTS];
+        if (dp_L2_ <= eps2_sq * p_L2_ && stops) { stop_ = 2; end_outer(); ret = 2; break; }  // :1450-1454
+        if (dp_L2_ >= (p_L2_ + eps2) / kEpsilonSq) {                                          // :1456-1462
+            err = "the matrix of the augmented normal equations is almost singular";
+            return MI_BA_ERROR;
+        }
+        ++nfev_;
+        {
+            const double pdp_eL2 = s[SC_COST_NEW];
+            if (!std::isfinite(pdp_eL2)) { stop_ = 7; end_outer(); ret = 2; break; }         // :1479-1485
+            const double dL = s[SC_DL_CAMS] + s[SC_DL_PTS], dF = p_eL2_ - pdp_eL2;
+            if (dL > 0.0 && dF > 0.0) {                                                       // :1543
+                push_trace(pdp_eL2, 1);
+                double tmp = 2.0 * dF / dL - 1.0;
+                tmp = 1.0 - tmp * tmp * tmp;
+                mu_ = mu_ * ((tmp >= kOneThird) ? tmp : kOneThird);
+                nu_ = 2;
+                bool discard = false;
+                if (stops) {
+                    if (pdp_eL2 - 2.0 * std::sqrt(p_eL2_ * pdp_eL2) < (eps4_sq - 1.0) * p_eL2_) stop_ = 4; // :1567
+                    // QUIRK kept (sba_levmar.c:1569-1572): stop 8 leaves before p <- p + dp
+                    if (s[SC_MAX_PCT] < eps5 && itno_ >= 4) { stop_ = 8; discard = true; }
+                }
+                if (!discard) { accept_trial(); p_eL2_ = pdp_eL2; }
+                end_outer();
+                ret = stop_ ? 2 : 1;
+                break;
+            }
+            push_trace(pdp_eL2, 0);
+        }
+    moredamping:                                                                               // :1584-1597
+        mu_ *= nu_;
+        {
+            const int nu2 = (int)((unsigned)nu_ << 1);
+            if (nu2 <= nu_) { stop_ = 6; end_outer(); ret = 2; break; }
+            nu_ = nu2;
+        }
+        ret = 0;
+    } while (false);
+    timing.step_ms += now_ms() - t0; timing.steps += 1;
+    return ret;
+}
+
+void Engine::fill_info(double info[MI_BA_INFOSZ]) const
+{
+    info[0] = init_p_eL2_; info[1] = p_eL2_; info[2] = eab_inf_; info[3] = dp_L2_;
+    info[4] = mu_ / maxdiag_; info[5] = itno_; info[6] = stop_;
+    info[7] = (double)nfev_ * (double)nobs_; info[8] = (double)njev_ * (double)nobs_; info[9] = nlss_;
+}
+
+int Engine::run(double info[MI_BA_INFOSZ])
+{
+    if (begin() != 0) return MI_BA_ERROR;
+    while (!stop_ && itno_ < cfg.itmax) {
+        int r = step();
+        if (r == MI_BA_ERROR) return MI_BA_ERROR;
+    }
+    if (itno_ >= cfg.itmax) stop_ = 3;
+    if (info) fill_info(info);
+    return stop_ != 7 ? itno_ : MI_BA_ERROR;
+}
+
+int Engine::get_params(double *a, double *xyz)
+{
+    if (!prepared_) { err = "get_params: prepare first"; return MI_BA_ERROR; }
+    const Plan &pl = plan_;
+    if (a) {
+        std::vector<double> ap((size_t)m_ * kCP);
+        if (!hipok(hipMemcpy(ap.data(), d_cam_a_[cur_].p, ap.size() * sizeof(double), hipMemcpyDeviceToHost), "download cam_a")) return MI_BA_ERROR;
+        for (int j = 0; j < m_; ++j)
+            for (int r = 0; r < cnp; ++r) a[(size_t)j * cnp + r] = ap[(size_t)j * kCP + r];
+    }
+    if (xyz) {
+        const size_t npl = (size_t)pl.npts_local();
+        std::vector<double> pp(npl * 3);
+        if (npl && !hipok(hipMemcpy(pp.data(), d_pts_[cur_].p, pp.size() * sizeof(double), hipMemcpyDeviceToHost), "download pts")) return MI_BA_ERROR;
+        std::memcpy(xyz, h_xyz_.data(), sizeof(double) * (size_t)n_ * 3); // untouched (unobserved / other ranks')
+        if (cfg.world > 1) {
+            // every rank contributes its shard to a zero-filled full array; SUM all-reduce = all-gather
+            std::vector<double> full((size_t)n_ * 3, 0.0);
+            for (size_t t = 0; t < npl; ++t)
+                for (int r = 0; r < 3; ++r) full[3 * (size_t)pl.perm[pl.pt_begin + t] + r] = pp[3 * t + r];
+            if (!hipok(hipMemcpy(d_full_pts_.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice), "upload full pts")) return MI_BA_ERROR;
+            ncclResult_t r = ncclAllReduce(d_full_pts_.p, d_full_pts_.p, full.size(), ncclDouble, ncclSum, (ncclComm_t)comm_, st_);
+            if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return MI_BA_ERROR; }
+            if (!hipok(hipStreamSynchronize(st_), "sync")) return MI_BA_ERROR;
+            if (!hipok(hipMemcpy(full.data(), d_full_pts_.p, full.size() * sizeof(double), hipMemcpyDeviceToHost), "download full pts")) return MI_BA_ERROR;
+            for (int t = 0; t < pl.n_active; ++t)
+                for (int r = 0; r < 3; ++r) xyz[3 * (size_t)pl.perm[t] + r] = full[3 * (size_t)pl.perm[t] + r];
+        } else {
+            for (size_t t = 0; t < npl; ++t)
+                for (int r = 0; r < 3; ++r) xyz[3 * (size_t)pl.perm[pl.pt_begin + t] + r] = pp[3 * t + r];
+        }
+    }
+    return 0;
+}
+
+int Engine::get_rotations(double *R)
+{
+    if (!prepared_) { err = "get_rotations: prepare first"; return MI_BA_ERROR; }
+    launch_cam_prep(st_, m_, cnp, model(), d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p);
+    DevBuf<double> tmp;
+    if (!hipok(tmp.alloc((size_t)m_ * 9), "alloc R")) return MI_BA_ERROR;
+    launch_rotations(st_, m_, d_cam_lin_[cur_].p, tmp.p);
+    if (!hipok(hipStreamSynchronize(st_), "sync")) return MI_BA_ERROR;
+    return hipok(hipMemcpy(R, tmp.p, sizeof(double) * (size_t)m_ * 9, hipMemcpyDeviceToHost), "download R") ? 0 : MI_BA_ERROR;
+}
+
+int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double *eb, double *V, double *diagU, double *cost)
+{
+    if (!prepared_) { err = "debug_linearize: prepare first"; return MI_BA_ERROR; }
+    if (cfg.world > 1 && (eb || V)) { err = "debug_linearize: point outputs need world == 1"; return MI_BA_ERROR; }
+    if (!linear_phase(mu) || !read_scalars()) return MI_BA_ERROR;
+    const Plan &pl = plan_;
+    if (cost) *cost = h_scal_[SC_COST];
+    const size_t vec = (size_t)m_ * kCP;
+    std::vector<double> tmp;
+    auto unpad = [&](const double *src, double *dst) {
+        for (int j = 0; j < m_; ++j) for (int r = 0; r < cnp; ++r) dst[(size_t)j * cnp + r] = src[(size_t)j * kCP + r];
+    };
+    if (S) {
+        tmp.resize((size_t)pl.nb_full() * 64);
+        if (!hipok(hipMemcpy(tmp.data(), d_S_full_.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost), "download S")) return MI_BA_ERROR;
+        const size_t N = (size_t)m_ * cnp;
+        std::fill(S, S + N * N, 0.0);
+        for (int j = 0; j < m_; ++j)
+            for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) {
+                const int k = pl.bsr_col[q];
+                for (int r = 0; r < cnp; ++r)
+                    for (int c = 0; c < cnp; ++c) S[((size_t)j * cnp + r) * N + (size_t)k * cnp + c] = tmp[(size_t)q * 64 + r * 8 + c];
+            }
+    }
+    if (E) { tmp.resize(vec); if (!hipok(hipMemcpy(tmp.data(), d_E_.p, vec * sizeof(double), hipMemcpyDeviceToHost), "download E")) return MI_BA_ERROR; unpad(tmp.data(), E); }
+    if (ea || diagU) {
+        tmp.resize(3 * vec);
+        if (!hipok(hipMemcpy(tmp.data(), camvec_(), 3 * vec * sizeof(double), hipMemcpyDeviceToHost), "download camvec")) return MI_BA_ERROR;
+        if (ea) unpad(tmp.data(), ea);
+        if (diagU) unpad(tmp.data() + 2 * vec, diagU);
+    }
+    if (eb || V) {
+        const size_t npl = (size_t)pl.npts_local();
+        tmp.resize(npl * kPtOut);
+        if (npl && !hipok(hipMemcpy(tmp.data(), d_ptout_.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost), "download ptout")) return MI_BA_ERROR;
+        if (eb) std::fill(eb, eb + (size_t)n_ * 3, 0.0);
+        if (V) std::fill(V, V + (size_t)n_ * 9, 0.0);
+        for (size_t t = 0; t < npl; ++t) {
+            const double *po = tmp.data() + t * kPtOut;
+            const size_t i = (size_t)pl.perm[pl.pt_begin + t];
+            if (eb) for (int r = 0; r < 3; ++r) eb[3 * i + r] = po[9 + r];
+            if (V) { // V = (V*^-1)^-1 - mu I, inverted on the host for the parity test only
+                const double a00 = po[0], a01 = po[1], a02 = po[2], a11 = po[3], a12 = po[4], a22 = po[5];
+                const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+                const double det = a00 * c00 + a01 * c01 + a02 * c02, id = det != 0.0 ? 1.0 / det : 0.0;
+                double *v = V + 9 * i;
+                v[0] = c00 * id - mu; v[1] = v[3] = c01 * id; v[2] = v[6] = c02 * id;
+                v[4] = (a00 * a22 - a02 * a02) * id - mu; v[5] = v[7] = (a01 * a02 - a00 * a12) * id;
+                v[8] = (a00 * a11 - a01 * a01) * id - mu;
+            }
+        }
+    }
+    return 0;
+}
+
+int Engine::debug_solve(double mu, double *da, double *db, double *cost_new)
+{
+    if (!prepared_) { err = "debug_solve: prepare first"; return MI_BA_ERROR; }
+    if (cfg.world > 1 && db) { err = "debug_solve: point outputs need world == 1"; return MI_BA_ERROR; }
+    if (!solve_phase(mu, d_dB_.p) || !read_scalars()) return MI_BA_ERROR;
+    const Plan &pl = plan_;
+    if (cost_new) *cost_new = h_scal_[SC_COST_NEW];
+    if (da) {
+        std::vector<double> tmp((size_t)m_ * kCP);
+        if (!hipok(hipMemcpy(tmp.data(), d_dA_.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost), "download dA")) return MI_BA_ERROR;
+        for (int j = 0; j < m_; ++j) for (int r = 0; r < cnp; ++r) da[(size_t)j * cnp + r] = (j >= cfg.mcon) ? tmp[(size_t)j * kCP + r] : 0.0;
+    }
+    if (db) {
+        const size_t npl = (size_t)pl.npts_local();
+        std::vector<double> tmp(npl * 3);
+        if (npl && !hipok(hipMemcpy(tmp.data(), d_dB_.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost), "download dB")) return MI_BA_ERROR;
+        std::fill(db, db + (size_t)n_ * 3, 0.0);
+        for (size_t t = 0; t < npl; ++t) for (int r = 0; r < 3; ++r) db[3 * (size_t)pl.perm[pl.pt_begin + t] + r] = tmp[3 * t + r];
+    }
+    if (h_scal_[SC_PCG_STATUS] != 0.0 || h_scal_[SC_NOT_PD] != 0.0) { err = "debug_solve: reduced system not positive definite"; return MI_BA_ERROR; }
+    return (int)h_scal_[SC_PCG_ITERS];
+}
+
+} // namespace miba

@@ -1,0 +1,114 @@
+// engine.h -- host side of the MI355X bundle-adjustment engine: HBM residency, the
+// Levenberg-Marquardt controller (sba_levmar.c:848-1617 restated step-wise) and the RCCL exchange.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_ba.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace miba {
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count)
+    {
+        release();
+        n = count;
+        return hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &v)
+    {
+        hipError_t e = alloc(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+// layout of the accumulation buffer `acc` (doubles):  [ S_up nb_up*64 | camvec 3*m*8 | scal 48 ]
+// all-reduce #1: SUM over [S_up | camvec | scal[0..8)], MAX over scal[8..16)
+// all-reduce #2: SUM over scal[32..40), MAX over scal[40..48)
+constexpr int kScalCount = 48;
+
+class Engine {
+public:
+    explicit Engine(const mi_ba_config &c);
+    ~Engine();
+    bool ok() const { return created_; }
+
+    int set_cameras(int m, const double *a0, const double *R0, const double *f_fixed);
+    int set_points(int n, const double *xyz);
+    int set_observations(int64_t nobs, const double *xy, const int *pt_idx, const int *cam_idx);
+    int prepare();
+    int begin();
+    int step();
+    int run(double info[MI_BA_INFOSZ]);
+    void fill_info(double info[MI_BA_INFOSZ]) const;
+    int get_params(double *a, double *xyz);
+    int set_params(const double *a, const double *xyz);
+    int get_rotations(double *R);
+    int debug_linearize(double mu, double *S, double *E, double *ea, double *eb, double *V, double *diagU, double *cost);
+    int debug_solve(double mu, double *da, double *db, double *cost_new);
+    int comm_init(const char *id);
+
+    mi_ba_config cfg;
+    int cnp = 7;
+    std::string err;
+    std::vector<double> trace;   // 6 doubles per trial
+    mi_ba_timing timing{};
+
+private:
+    bool fail(const std::string &msg) { err = msg; return false; }
+    bool hipok(hipError_t e, const char *what);
+    bool linear_phase(double mu);                 // cam_prep .. build .. all-reduce .. finalize .. block_inv
+    bool solve_phase(double mu, double *dB_dev);  // pcg .. cam_update .. backsub .. all-reduce
+    bool read_scalars();
+    bool allreduce1();
+    bool allreduce2();
+    void accept_trial();
+    ModelCfg model() const;
+
+    bool created_ = false, prepared_ = false, begun_ = false;
+    hipStream_t st_ = nullptr;
+    hipEvent_t ev_[8] = {};
+    void *comm_ = nullptr; // ncclComm_t
+
+    // host problem
+    int m_ = 0, n_ = 0;
+    int64_t nobs_ = 0;
+    std::vector<double> h_a0_, h_R0_, h_ff_, h_xyz_, h_xy_;
+    std::vector<int> h_pt_, h_cam_;
+    bool have_ff_ = false;
+    double pl2_inactive_ = 0.0;
+    Plan plan_;
+
+    // device: plan
+    DevBuf<int> d_tile_batch_, d_tile_slot_, d_tile_cslot_, d_slot_gblk_, d_cslot_cam_, d_batch_obs_, d_batch_pt_, d_pt_obs_,
+        d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_;
+    DevBuf<long long> d_batch_pair_;
+    DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_;
+    DevBuf<unsigned> d_pair_, d_pair_gblk_;
+    DevBuf<double2> d_obs_xy_;
+    // device: state
+    DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_Minv_, d_E_, d_dA_, d_dB_,
+        d_pcg_, d_rzpq_, d_full_pts_;
+    int cur_ = 0; // index of the current estimate in the [2] buffers
+    double *h_scal_ = nullptr; // pinned, kScalCount
+    double *S_up_() { return d_acc_.p; }
+    double *camvec_() { return d_acc_.p + (size_t)plan_.nb_up() * 64; }
+    double *scal_() { return d_acc_.p + (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP; }
+
+    // LM state (names follow sba_levmar.c:596-613)
+    double mu_ = 0, p_eL2_ = 0, init_p_eL2_ = 0, eab_inf_ = 0, dp_L2_ = 0, p_L2_ = 0, maxdiag_ = 0;
+    int nu_ = 2, itno_ = 0, stop_ = 0, nfev_ = 0, njev_ = 0, nlss_ = 0;
+    bool new_outer_ = true;
+};
+
+} // namespace miba

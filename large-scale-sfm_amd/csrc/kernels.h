@@ -1,0 +1,94 @@
+// kernels.h -- device-side data layout and launch wrappers (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "plan.h"
+
+namespace miba {
+
+// ---- HBM layout ---------------------------------------------------------------------------
+// cam_a    [m][8]   camera parameters a_j, padded to 8 doubles (64 B rows)
+// cam_lin  [m][24]  per-linearisation camera record: R(9) = exp([w]x) R0, Jl(9) = left Jacobian of
+//                   SO(3) at w, c(3) = C or t, f, k1, k2   (192 B, L2-resident, gathered per obs)
+// pts      [npl][3] this rank's points, internal (signature-sorted) order
+// obs_xy   [nol]    double2 measurement; obs_cam/obs_pt int32; obs_cslot uint8
+// S_up     [nb_up][64]  upper blocks of the reduced camera matrix (8x8 padded, row-major)
+// camvec   [3][m][8]    ea_j | E_j partial (= sum A^T(e - B h)) | diag U_j
+// ptout    [npl][12]    (V_i + mu I)^-1 (6: 00 01 02 11 12 22) | h_i = V*^-1 eb_i (3) | eb_i (3)
+// S_full   [nb][64]     BSR values used by the PCG, Minv [m][64] block-Jacobi preconditioner
+constexpr int kCamLin = 24;
+constexpr int kPtOut = 12;
+
+struct ModelCfg {
+    int explicit_centers, est_focal, undistort, mcon;
+    double proj_sign, f_scale, k_scale;
+};
+
+// scalar block (doubles) shared by kernels and the host LM controller; lives at the tail of the
+// accumulation buffer (engine.h) so the SUM part of all-reduce #1 is one contiguous range
+enum Scal {
+    // [0,8)  k_build sums over this rank's observations / points      (all-reduce #1, SUM)
+    SC_COST = 0, SC_PL2_PTS = 1,
+    // [8,16) k_build maxima                                            (all-reduce #1, MAX)
+    SC_EB_INF = 8, SC_MAXDIAG_V = 9, SC_SINGULAR = 10,
+    // [16,32) camera-side values, replicated on every rank
+    SC_EA_INF = 16, SC_MAXDIAG_U, SC_PL2_CAMS, SC_DL_CAMS, SC_DP2_CAMS, SC_PCG_ITERS, SC_PCG_STATUS, SC_PCG_DONE, SC_NOT_PD,
+    // [32,40) k_backsub sums                                           (all-reduce #2, SUM)
+    SC_COST_NEW = 32, SC_DL_PTS = 33, SC_DP2_PTS = 34,
+    // [40,48) k_backsub maxima                                         (all-reduce #2, MAX)
+    SC_MAX_PCT = 40,
+    SC_COUNT = 48
+};
+
+struct BuildArgs {
+    const int *tile_batch, *tile_slot, *tile_cslot, *slot_gblk, *cslot_cam;
+    const int *batch_obs, *batch_pt;
+    const long long *batch_pair;
+    const int *pt_obs;
+    const int *obs_cam, *obs_pt;
+    const unsigned char *obs_cslot;
+    const double2 *obs_xy;
+    const unsigned *pair, *pair_gblk;
+    long long pair_gblk_base;
+    int tile0, m;
+    const double *cam_lin, *pts;
+    double mu;
+    double *S_up, *camvec, *ptout, *scal;
+    ModelCfg cfg;
+};
+
+struct BacksubArgs {
+    const int *batch_obs, *batch_pt, *pt_obs, *obs_cam, *obs_pt;
+    const double2 *obs_xy;
+    const double *cam_lin, *cam_lin_new, *pts, *ptout, *dA;
+    double *pts_new, *dB, *scal;
+    double mu, eps5;
+    int nbatch;
+    ModelCfg cfg;
+};
+
+struct PcgArgs {
+    const int *bsr_row, *bsr_col;
+    const double *S, *Minv, *E;
+    double *x, *r, *r1, *z, *p0, *p1, *q;   // r/r1 and p0/p1 alternate by iteration parity
+    double *rz, *pq, *scal;
+    double tol;
+    int m, it;
+};
+
+void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
+                     const double *f_fixed, double *cam_lin);
+void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);
+void launch_finalize(hipStream_t st, int cnp, int m, int nb, int mcon, double mu, const int *bsr_rowidx, const int *bsr_col,
+                     const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
+                     const double *camvec, const double *cam_a, double *E, double *scal);
+void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal);
+void launch_pcg_init(hipStream_t st, const PcgArgs &a);
+void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // spmv + update for iteration a.it
+void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, double mu, const double *cam_a, const double *dA,
+                       const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
+                       double *cam_lin_new, double *scal);
+void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a);
+void launch_rotations(hipStream_t st, int m, const double *cam_lin, double *R);
+
+} // namespace miba

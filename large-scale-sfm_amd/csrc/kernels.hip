@@ -1,0 +1,753 @@
+// kernels.hip -- hand-written HIP kernels of the bundle-adjustment engine, gfx950 (CDNA4) only.
+//
+// One LM damping trial (sba_levmar.c:1131-1612) is
+//   k_cam_prep -> k_build (-> RCCL all-reduce) -> k_finalize{,_vec} -> k_block_inv
+//   -> PCG (k_pcg_init, k_pcg_spmv, k_pcg_update) -> k_cam_update -> k_backsub (-> all-reduce)
+// All arithmetic is IEEE double.  Wavefront = 64 lanes; k_build and k_backsub use ONE wavefront
+// per workgroup so every LDS hand-off is wave-synchronous (the s_barrier of a one-wave workgroup
+// costs nothing) and no inter-wave protocol exists anywhere in this file; cross-workgroup
+// accumulation is by f64 atomics into zero-initialised HBM buffers only.
+#include "kernels.h"
+
+namespace miba {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// max of non-negative doubles through the monotone bit pattern; NaN compares above everything
+__device__ __forceinline__ void atomic_max_pos(double *p, double v)
+{
+    atomicMax(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void gadd(double *p, double v) { unsafeAtomicAdd(p, v); } // global_atomic_add_f64
+__device__ __forceinline__ void ladd(double *p, double v)                           // ds_add_f64
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ------------------------------------------------------------------------------------------
+// camera model: projection (sfm.c:303-374) and its analytic Jacobian (the reference uses forward
+// differences, sba_levmar_wrap.c:163-259; the analytic form agrees to ~1e-6 relative, see
+// tests/test_oracle_golden.py::test_analytic_jacobian_close_to_fd)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void project_obs(const ModelCfg &cfg, const double *__restrict__ cl, const double X[3],
+                                            double &u, double &v)
+{
+    double q[3];
+    if (cfg.explicit_centers) {
+        double d0 = X[0] - cl[18], d1 = X[1] - cl[19], d2 = X[2] - cl[20];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) q[r] = cl[3 * r] * d0 + cl[3 * r + 1] * d1 + cl[3 * r + 2] * d2;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) q[r] = cl[3 * r] * X[0] + cl[3 * r + 1] * X[1] + cl[3 * r + 2] * X[2] + cl[18 + r];
+    }
+    double f = cl[21], k1 = cl[22], k2 = cl[23];
+    double iz = 1.0 / q[2], mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
+    double g = cfg.proj_sign * f * (1.0 + k1 * r2 + k2 * r2 * r2);
+    u = g * mx; v = g * my;
+}
+
+template <int CNP>
+__device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double *__restrict__ cl, const double X[3],
+                                              double2 xy, bool fixed_cam, double e[2], double A[2][CNP], double B[2][3])
+{
+    double R[9], q[3], qr[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = cl[i];
+    const double c0 = cl[18], c1 = cl[19], c2 = cl[20], f = cl[21], k1 = cl[22], k2 = cl[23];
+    if (cfg.explicit_centers) {
+        double d0 = X[0] - c0, d1 = X[1] - c1, d2 = X[2] - c2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { qr[r] = R[3 * r] * d0 + R[3 * r + 1] * d1 + R[3 * r + 2] * d2; q[r] = qr[r]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) qr[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2];
+        q[0] = qr[0] + c0; q[1] = qr[1] + c1; q[2] = qr[2] + c2;
+    }
+    const double s = cfg.proj_sign, iz = 1.0 / q[2];
+    const double mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
+    const double D = 1.0 + k1 * r2 + k2 * r2 * r2, Dp = k1 + 2.0 * k2 * r2;
+    e[0] = xy.x - s * f * mx * D;
+    e[1] = xy.y - s * f * my * D;
+    const double dmx[3] = { iz, 0.0, -mx * iz }, dmy[3] = { 0.0, iz, -my * iz };
+    double Pq[2][3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        double dr2 = 2.0 * (mx * dmx[t] + my * dmy[t]);
+        Pq[0][t] = s * f * (D * dmx[t] + mx * Dp * dr2);
+        Pq[1][t] = s * f * (D * dmy[t] + my * Dp * dr2);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) B[r][t] = Pq[r][0] * R[t] + Pq[r][1] * R[3 + t] + Pq[r][2] * R[6 + t];
+    if (fixed_cam) { // A_ij is taken as zero for the first mcon cameras (sba_levmar.c:460-462)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int t = 0; t < CNP; ++t) A[r][t] = 0.0;
+        return;
+    }
+    // M = -[qr]x Jl
+    const double *Jl = cl + 9;
+    double M[3][3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        M[0][t] = -(-qr[2] * Jl[3 + t] + qr[1] * Jl[6 + t]);
+        M[1][t] = -(qr[2] * Jl[t] - qr[0] * Jl[6 + t]);
+        M[2][t] = -(-qr[1] * Jl[t] + qr[0] * Jl[3 + t]);
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            A[r][t] = cfg.explicit_centers ? -B[r][t] : Pq[r][t];
+            A[r][3 + t] = Pq[r][0] * M[0][t] + Pq[r][1] * M[1][t] + Pq[r][2] * M[2][t];
+        }
+        if constexpr (CNP >= 7) A[r][6] = s * (r == 0 ? mx : my) * D / cfg.f_scale;
+    }
+}
+
+// exp([w]x) R0 exactly as rot_update (sfm.c:78-117), and the left Jacobian of SO(3) at w
+__device__ __forceinline__ void cam_record(const ModelCfg &cfg, int cnp, const double *__restrict__ a,
+                                           const double *__restrict__ R0, double f_fix, double *__restrict__ cl)
+{
+    const double w0 = a[3], w1 = a[4], w2 = a[5];
+    const double t2 = w0 * w0 + w1 * w1 + w2 * w2, theta = sqrt(t2);
+    double R[9];
+    if (theta == 0.0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = R0[i];
+    } else {
+        const double n0 = w0 / theta, n1 = w1 / theta, n2 = w2 / theta;
+        const double nx[9] = { 0.0, -n2, n1, n2, 0.0, -n0, -n1, n0, 0.0 };
+        const double sn = sin(theta), omc = 1.0 - cos(theta);
+        double dR[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double sq = nx[3 * r] * nx[c] + nx[3 * r + 1] * nx[3 + c] + nx[3 * r + 2] * nx[6 + c];
+                dR[3 * r + c] = (r == c ? 1.0 : 0.0) + sn * nx[3 * r + c] + omc * sq;
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                R[3 * r + c] = dR[3 * r] * R0[c] + dR[3 * r + 1] * R0[3 + c] + dR[3 * r + 2] * R0[6 + c];
+    }
+    double ca, cb;
+    if (t2 < 1e-8) { ca = 0.5 - t2 / 24.0; cb = 1.0 / 6.0 - t2 / 120.0; }
+    else { ca = (1.0 - cos(theta)) / t2; cb = (theta - sin(theta)) / (t2 * theta); }
+    const double wx[9] = { 0.0, -w2, w1, w2, 0.0, -w0, -w1, w0, 0.0 };
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cl[i] = R[i];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double sq = wx[3 * r] * wx[c] + wx[3 * r + 1] * wx[3 + c] + wx[3 * r + 2] * wx[6 + c];
+            cl[9 + 3 * r + c] = (r == c ? 1.0 : 0.0) + ca * wx[3 * r + c] + cb * sq;
+        }
+    cl[18] = a[0]; cl[19] = a[1]; cl[20] = a[2];
+    cl[21] = cfg.est_focal ? a[6] / cfg.f_scale : f_fix;
+    cl[22] = 0.0; cl[23] = 0.0; // k1, k2: undistort reserved
+    (void)cnp;
+}
+
+__global__ void k_cam_prep(int m, int cnp, ModelCfg cfg, const double *__restrict__ cam_a, const double *__restrict__ R0,
+                           const double *__restrict__ f_fixed, double *__restrict__ cam_lin)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    cam_record(cfg, cnp, cam_a + (size_t)j * kCP, R0 + (size_t)j * 9, f_fixed ? f_fixed[j] : 1.0, cam_lin + (size_t)j * kCamLin);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_build: fused linearise + Schur complement, one damping trial.
+//
+//   workgroup = one 64-lane wavefront = one TILE (a run of batches; plan.h)
+//   phase 1  lane = observation: gather camera record + point, residual e, A (2 x CNP), B (2 x 3)
+//            -> LDS                                     [sba_levmar.c:856, 919-1030]
+//   phase 2  lane = (point, component): V_i (6 upper), eb_i (3) summed from LDS
+//   phase 3  lane = point: V*_i = V_i + mu I, closed-form inverse, h_i = V*^-1 eb_i  [:1138-1162]
+//   phase 4  lane = observation: G = B V*^-1; ea_j, E_j = A^T (e - B h_i), diag U_j  [:1322-1338]
+//   phase 5  lane = observation PAIR (a <= b) of one point:
+//               block(j_a, j_b) += A_a^T (delta_ab I - G_a B_b^T) A_b
+//            which is delta_ab U - Y_ij W_ik^T of sba_levmar.c:1182-1301 written through the
+//            2 x 2 matrix G_a B_b^T (measurements are 2-vectors, so every block has rank <= 2
+//            and W_ij = A^T B never has to be formed or stored).
+//   LDS mode:  blocks accumulate into a per-tile LDS table (ds_add_f64), flushed once per tile
+//              as 49-lane contiguous f64 atomics (one S block = one wave instruction).
+//   direct mode (points with > kMaxViewsLds views): every pair adds straight into HBM.
+// ------------------------------------------------------------------------------------------
+template <int CNP, bool LDS>
+__global__ __launch_bounds__(64) void k_build(const BuildArgs g)
+{
+    constexpr int SA = 2 * CNP + 1;           // odd strides (in doubles) keep ds_read_b64 conflict-free
+    constexpr int SB = 7, SE = 3, SV = 9;
+    constexpr int BLK = CNP * CNP, SS = BLK | 1, SC = (3 * CNP) | 1;
+    __shared__ double sA[kWave * SA], sB[kWave * SB], sG[kWave * SB], sE[kWave * SE], sV[kWave * SV];
+    __shared__ double sS[LDS ? kNSlot * SS : 1], sC[LDS ? kNCSlot * SC : 1];
+
+    const int lane = threadIdx.x;
+    const int tile = g.tile0 + blockIdx.x;
+    const ModelCfg cfg = g.cfg;
+    int nslots = 0, ncs = 0;
+    if constexpr (LDS) {
+        nslots = g.tile_slot[tile + 1] - g.tile_slot[tile];
+        ncs = g.tile_cslot[tile + 1] - g.tile_cslot[tile];
+        for (int i = lane; i < nslots * SS; i += kWave) sS[i] = 0.0;
+        for (int i = lane; i < ncs * SC; i += kWave) sC[i] = 0.0;
+    }
+    double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0;
+
+    for (int b = g.tile_batch[tile]; b < g.tile_batch[tile + 1]; ++b) {
+        const int o0 = g.batch_obs[b], nob = g.batch_obs[b + 1] - o0;
+        const int p0 = g.batch_pt[b], npt = g.batch_pt[b + 1] - p0;
+        const bool active = lane < nob;
+        double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
+        int j = 0, lp = 0, cs = 0;
+        // ---- phase 1
+        if (active) {
+            const int o = o0 + lane;
+            j = g.obs_cam[o];
+            const int ip = g.obs_pt[o];
+            lp = ip - p0;
+            if constexpr (LDS) cs = g.obs_cslot[o];
+            const double2 xy = g.obs_xy[o];
+            const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
+            linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, j < cfg.mcon, e, A, B);
+            cost += e[0] * e[0] + e[1] * e[1];
+#pragma unroll
+            for (int t = 0; t < CNP; ++t) { sA[lane * SA + t] = A[0][t]; sA[lane * SA + CNP + t] = A[1][t]; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { sB[lane * SB + t] = B[0][t]; sB[lane * SB + 3 + t] = B[1][t]; }
+            sE[lane * SE] = e[0]; sE[lane * SE + 1] = e[1];
+        }
+        __syncthreads();
+        // ---- phase 2: V_i upper triangle (00 01 02 11 12 22) and eb_i, 7 points per sweep
+        for (int base = 0; base < npt; base += 7) {
+            const int qd = lane / 9, comp = lane - 9 * qd, lpp = base + qd;
+            if (lane < 63 && lpp < npt) {
+                const int os = g.pt_obs[p0 + lpp] - o0, oe = g.pt_obs[p0 + lpp + 1] - o0;
+                double sum = 0.0;
+                if (comp < 6) {
+                    const int r = comp < 3 ? 0 : (comp < 5 ? 1 : 2);
+                    const int c = comp < 3 ? comp : (comp < 5 ? comp - 2 : 2);
+                    for (int o = os; o < oe; ++o)
+                        sum += sB[o * SB + r] * sB[o * SB + c] + sB[o * SB + 3 + r] * sB[o * SB + 3 + c];
+                } else {
+                    const int r = comp - 6;
+                    for (int o = os; o < oe; ++o) sum += sB[o * SB + r] * sE[o * SE] + sB[o * SB + 3 + r] * sE[o * SE + 1];
+                }
+                sV[lpp * SV + comp] = sum;
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: damped inverse per point (role of sba_symat_invert_BK on a 3x3)
+        if (lane < npt) {
+            const int ip = p0 + lane;
+            double v00 = sV[lane * SV], v01 = sV[lane * SV + 1], v02 = sV[lane * SV + 2];
+            double v11 = sV[lane * SV + 3], v12 = sV[lane * SV + 4], v22 = sV[lane * SV + 5];
+            const double eb0 = sV[lane * SV + 6], eb1 = sV[lane * SV + 7], eb2 = sV[lane * SV + 8];
+            maxdv = fmax(maxdv, fmax(v00, fmax(v11, v22)));
+            ebinf = fmax(ebinf, fmax(fabs(eb0), fmax(fabs(eb1), fabs(eb2))));
+            const double X0 = g.pts[3 * (size_t)ip], X1 = g.pts[3 * (size_t)ip + 1], X2 = g.pts[3 * (size_t)ip + 2];
+            pl2 += X0 * X0 + X1 * X1 + X2 * X2;
+            v00 += g.mu; v11 += g.mu; v22 += g.mu;
+            const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
+            const double det = v00 * c00 + v01 * c01 + v02 * c02;
+            double i00 = 0, i01 = 0, i02 = 0, i11 = 0, i12 = 0, i22 = 0;
+            if (det == 0.0 || !isfinite(det)) sing = 1.0; // "singular matrix V*_i, increasing damping", :1156-1158
+            else {
+                const double id = 1.0 / det;
+                i00 = c00 * id; i01 = c01 * id; i02 = c02 * id;
+                i11 = (v00 * v22 - v02 * v02) * id; i12 = (v01 * v02 - v00 * v12) * id; i22 = (v00 * v11 - v01 * v01) * id;
+            }
+            const double h0 = i00 * eb0 + i01 * eb1 + i02 * eb2, h1 = i01 * eb0 + i11 * eb1 + i12 * eb2,
+                         h2 = i02 * eb0 + i12 * eb1 + i22 * eb2;
+            double *sv = sV + lane * SV;
+            sv[0] = i00; sv[1] = i01; sv[2] = i02; sv[3] = i11; sv[4] = i12; sv[5] = i22; sv[6] = h0; sv[7] = h1; sv[8] = h2;
+            double *po = g.ptout + (size_t)ip * kPtOut;
+            po[0] = i00; po[1] = i01; po[2] = i02; po[3] = i11; po[4] = i12; po[5] = i22;
+            po[6] = h0; po[7] = h1; po[8] = h2; po[9] = eb0; po[10] = eb1; po[11] = eb2;
+        }
+        __syncthreads();
+        // ---- phase 4: G = B V*^-1 and the camera-side vectors
+        if (active) {
+            const double *sv = sV + lp * SV;
+            const double i00 = sv[0], i01 = sv[1], i02 = sv[2], i11 = sv[3], i12 = sv[4], i22 = sv[5];
+            double er[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                sG[lane * SB + 3 * r] = B[r][0] * i00 + B[r][1] * i01 + B[r][2] * i02;
+                sG[lane * SB + 3 * r + 1] = B[r][0] * i01 + B[r][1] * i11 + B[r][2] * i12;
+                sG[lane * SB + 3 * r + 2] = B[r][0] * i02 + B[r][1] * i12 + B[r][2] * i22;
+                er[r] = e[r] - (B[r][0] * sv[6] + B[r][1] * sv[7] + B[r][2] * sv[8]);
+            }
+            if (j >= cfg.mcon) {
+#pragma unroll
+                for (int t = 0; t < CNP; ++t) {
+                    const double vea = A[0][t] * e[0] + A[1][t] * e[1];
+                    const double vE = A[0][t] * er[0] + A[1][t] * er[1];
+                    const double vdu = A[0][t] * A[0][t] + A[1][t] * A[1][t];
+                    if constexpr (LDS) {
+                        ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE); ladd(&sC[cs * SC + 2 * CNP + t], vdu);
+                    } else {
+                        gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], vea);
+                        gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], vE);
+                        gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], vdu);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 5: pair products
+        for (long long q = g.batch_pair[b] + lane; q < g.batch_pair[b + 1]; q += kWave) {
+            const unsigned ent = g.pair[q];
+            const int la = ent & 63, lb = (ent >> 6) & 63;
+            const double *Ga = sG + la * SB, *Bb = sB + lb * SB;
+            double M00 = Ga[0] * Bb[0] + Ga[1] * Bb[1] + Ga[2] * Bb[2];
+            double M01 = Ga[0] * Bb[3] + Ga[1] * Bb[4] + Ga[2] * Bb[5];
+            double M10 = Ga[3] * Bb[0] + Ga[4] * Bb[1] + Ga[5] * Bb[2];
+            double M11 = Ga[3] * Bb[3] + Ga[4] * Bb[4] + Ga[5] * Bb[5];
+            const double dg = (la == lb) ? 1.0 : 0.0;
+            M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
+            double T0[CNP], T1[CNP];
+            const double *Ab = sA + lb * SA, *Aa = sA + la * SA;
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) {
+                const double a0 = Ab[c], a1 = Ab[CNP + c];
+                T0[c] = M00 * a0 + M01 * a1;
+                T1[c] = M10 * a0 + M11 * a1;
+            }
+            if constexpr (LDS) {
+                double *dst = sS + (ent >> 12) * SS;
+#pragma unroll
+                for (int r = 0; r < CNP; ++r) {
+                    const double a0 = Aa[r], a1 = Aa[CNP + r];
+#pragma unroll
+                    for (int c = 0; c < CNP; ++c) ladd(&dst[r * CNP + c], a0 * T0[c] + a1 * T1[c]);
+                }
+            } else {
+                double *dst = g.S_up + (size_t)g.pair_gblk[q - g.pair_gblk_base] * (kCP * kCP);
+#pragma unroll
+                for (int r = 0; r < CNP; ++r) {
+                    const double a0 = Aa[r], a1 = Aa[CNP + r];
+#pragma unroll
+                    for (int c = 0; c < CNP; ++c) gadd(&dst[r * kCP + c], a0 * T0[c] + a1 * T1[c]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- flush the tile's accumulators: one S block = one contiguous f64 atomic wave instruction
+    if constexpr (LDS) {
+        const int s0 = g.tile_slot[tile], c0 = g.tile_cslot[tile];
+        if (lane < BLK) {
+            const int r = lane / CNP, c = lane - r * CNP;
+            for (int s = 0; s < nslots; ++s)
+                gadd(&g.S_up[(size_t)g.slot_gblk[s0 + s] * (kCP * kCP) + r * kCP + c], sS[s * SS + lane]);
+        }
+        if (lane < 3 * CNP) {
+            const int which = lane / CNP, t = lane - which * CNP;
+            for (int c = 0; c < ncs; ++c)
+                gadd(&g.camvec[((size_t)which * g.m + g.cslot_cam[c0 + c]) * kCP + t], sC[c * SC + lane]);
+        }
+    }
+    cost = wave_sum(cost); pl2 = wave_sum(pl2);
+    ebinf = wave_max(ebinf); maxdv = wave_max(maxdv); sing = wave_max(sing);
+    if (lane == 0) {
+        gadd(&g.scal[SC_COST], cost);
+        gadd(&g.scal[SC_PL2_PTS], pl2);
+        atomic_max_pos(&g.scal[SC_EB_INF], ebinf);
+        atomic_max_pos(&g.scal[SC_MAXDIAG_V], maxdv);
+        if (sing != 0.0) atomic_max_pos(&g.scal[SC_SINGULAR], 1.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize: upper blocks -> full BSR values of S = U* - W V*^-1 W^T  (sba_levmar.c:1270-1316:
+// "copy the LOWER TRIANGULAR PART of S from the upper one"), damping on the diagonal (:1138-1142),
+// identity on the padding row/column and on the rows of the mcon fixed cameras.
+// one thread per matrix element, 64 threads = one block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, int mcon, double mu, const int *__restrict__ rowidx,
+                                                 const int *__restrict__ col, const int *__restrict__ src,
+                                                 const unsigned char *__restrict__ trans, const double *__restrict__ S_up,
+                                                 double *__restrict__ S_full)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int blk = (int)(gid >> 6), el = (int)(gid & 63);
+    if (blk >= nb) return;
+    const int r = el >> 3, c = el & 7, j = rowidx[blk], k = col[blk];
+    const double *sb = S_up + (size_t)src[blk] * 64;
+    double v;
+    if (j == k) {
+        v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
+        if (r == c) v = (r < cnp) ? v + mu : 1.0;
+        if (j < mcon) v = (r == c) ? 1.0 : 0.0;
+    } else {
+        v = trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
+        if (j < mcon || k < mcon) v = 0.0;
+    }
+    if (r >= cnp || c >= cnp) v = (j == k && r == c) ? 1.0 : 0.0;
+    S_full[(size_t)blk * 64 + el] = v;
+}
+
+// right-hand side E_j = ea_j - sum_i Y_ij eb_i (already folded: E = sum A^T (e - B h)), ||ea||_inf,
+// max diag U, ||a||^2   (sba_levmar.c:1085-1088, 1124-1128)
+__global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, int mcon, const double *__restrict__ camvec,
+                                                     const double *__restrict__ cam_a, double *__restrict__ E,
+                                                     double *__restrict__ scal)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    double eainf = 0.0, maxdu = 0.0, pl2 = 0.0;
+    if (gid < m * kCP) {
+        const int j = gid >> 3, r = gid & 7;
+        const bool live = (r < cnp) && (j >= mcon);
+        const double ea = camvec[gid], Ev = camvec[(size_t)m * kCP + gid], du = camvec[2 * (size_t)m * kCP + gid];
+        E[gid] = live ? Ev : 0.0;
+        if (live) { eainf = fabs(ea); maxdu = du; }
+        if (r < cnp) { const double a = cam_a[gid]; pl2 = a * a; }
+    }
+    eainf = wave_max(eainf); maxdu = wave_max(maxdu); pl2 = wave_sum(pl2);
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_pos(&scal[SC_EA_INF], eainf);
+        atomic_max_pos(&scal[SC_MAXDIAG_U], maxdu);
+        gadd(&scal[SC_PL2_CAMS], pl2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// block-Jacobi preconditioner: Minv_j = S_jj^-1 by an unrolled 8x8 Cholesky, one thread per camera
+// (PBA: ComputeDiagonalBlockC + InvertSymmetricMatrix, SparseBundleCPU.cpp:1604-1734)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_block_inv(int m, const int *__restrict__ bsr_diag, const double *__restrict__ S_full,
+                                                 double *__restrict__ Minv, double *__restrict__ scal)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const double *sb = S_full + (size_t)bsr_diag[j] * 64;
+    double L[8][8];
+    bool ok = true;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+            double s = sb[r * 8 + c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) s -= L[r][k] * L[c][k];
+            if (r == c) { if (!(s > 0.0)) { ok = false; s = 1.0; } L[r][r] = sqrt(s); }
+            else L[r][c] = s / L[c][c];
+        }
+    if (!ok) atomic_max_pos(&scal[SC_NOT_PD], 1.0);
+    // Linv (lower), then Minv = Linv^T Linv
+    double Li[8][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < c) { Li[r][c] = 0.0; continue; }
+            double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) if (k >= c) s -= L[r][k] * Li[k][c];
+            Li[r][c] = s / L[r][r];
+        }
+    double *out = Minv + (size_t)j * 64;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k >= r && k >= c) s += Li[k][r] * Li[k][c];
+            out[r * 8 + c] = s;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// PCG on the block-sparse reduced camera system (the role of sba_Axb_Chol; algorithm of PBA's
+// SolveNormalEquationPCGX, SparseBundleCPU.cpp:3347-3474, with S explicit).
+//   rz[it] = r_it . z_it, pq[it] = p_it . S p_it live in HBM, one slot per iteration, so no kernel
+//   ever waits on the host; every workgroup takes the same converged/breakdown decision from them.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool pcg_done(const PcgArgs &a, int it)
+{
+    if (a.scal[SC_PCG_STATUS] != 0.0) return true;
+    const double rz0 = a.rz[0];
+    if (!(rz0 > 0.0)) return true;
+    return sqrt(fabs(a.rz[it]) / rz0) < a.tol;
+}
+
+// 8 cameras per 64-lane group: lane = (camera, row)
+__global__ __launch_bounds__(64) void k_pcg_init(const PcgArgs a)
+{
+    const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+    double part = 0.0;
+    if (j < a.m) {
+        const double *Mi = a.Minv + (size_t)j * 64 + r * 8, *Ej = a.E + (size_t)j * 8;
+        double zz = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) zz += Mi[c] * Ej[c];
+        const int idx = j * 8 + r;
+        a.x[idx] = 0.0; a.r[idx] = Ej[r]; a.z[idx] = zz; a.p0[idx] = zz;
+        part = Ej[r] * zz;
+    }
+    part = wave_sum(part);
+    if (threadIdx.x == 0) gadd(&a.rz[0], part);
+}
+
+// one wavefront per block row: lane (r,c) multiplies element (r,c) of each 8x8 block (a 512-B
+// contiguous wave load), reduction over c by three xor-shuffles
+__global__ __launch_bounds__(64) void k_pcg_spmv(const PcgArgs a)
+{
+    if (pcg_done(a, a.it)) return;
+    const int j = blockIdx.x, lane = threadIdx.x, r = lane >> 3, c = lane & 7;
+    const double *pprev = (a.it & 1) ? a.p0 : a.p1;   // p_{it-1}
+    double *pcur = (a.it & 1) ? a.p1 : a.p0;          // p_it (it = 0: p0 = z, written by k_pcg_init)
+    const double beta = a.it ? a.rz[a.it] / a.rz[a.it - 1] : 0.0;
+    double acc = 0.0;
+    for (int q = a.bsr_row[j]; q < a.bsr_row[j + 1]; ++q) {
+        const int k = a.bsr_col[q];
+        const double pk = a.it ? a.z[k * 8 + c] + beta * pprev[k * 8 + c] : a.z[k * 8 + c];
+        acc += a.S[(size_t)q * 64 + lane] * pk;
+    }
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+    double part = 0.0;
+    if (c == 0) {
+        const int idx = j * 8 + r;
+        const double pj = a.it ? a.z[idx] + beta * pprev[idx] : a.z[idx];
+        a.q[idx] = acc;
+        pcur[idx] = pj;
+        part = acc * pj;
+    }
+    part = wave_sum(part);
+    if (lane == 0) gadd(&a.pq[a.it], part);
+}
+
+__global__ __launch_bounds__(64) void k_pcg_update(const PcgArgs a)
+{
+    if (pcg_done(a, a.it)) return;
+    const double pq = a.pq[a.it];
+    if (!(pq > 0.0) || !isfinite(pq)) { // S not positive definite along p: "not solved" (dpotrf info > 0)
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[SC_PCG_STATUS] = 2.0;
+        return;
+    }
+    const double alpha = a.rz[a.it] / pq;
+    const double *pcur = (a.it & 1) ? a.p1 : a.p0;
+    const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+    double part = 0.0;
+    // all 8 row-lanes of a camera need that camera's 8 new residuals: each lane recomputes them from
+    // r_it (read-only here; r_{it+1} goes to the other buffer, so there is no read/write overlap)
+    const double *rin = (a.it & 1) ? a.r1 : a.r;
+    double *rout = (a.it & 1) ? a.r : a.r1;
+    if (j < a.m) {
+        const double *Mi = a.Minv + (size_t)j * 64 + r * 8;
+        double zz = 0.0, rr = 0.0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const double rc = rin[j * 8 + c] - alpha * a.q[j * 8 + c];
+            zz += Mi[c] * rc;
+            if (c == r) rr = rc;
+        }
+        const int idx = j * 8 + r;
+        a.x[idx] += alpha * pcur[idx];
+        a.z[idx] = zz;
+        rout[idx] = rr;
+        part = rr * zz;
+    }
+    part = wave_sum(part);
+    if (threadIdx.x == 0) {
+        gadd(&a.rz[a.it + 1], part);
+        if (blockIdx.x == 0) a.scal[SC_PCG_ITERS] = (double)(a.it + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// camera update: a_new = a + da, new camera record, dL and ||dp||^2 camera parts
+// (sba_levmar.c:1444-1447, 1524-1525)
+// ------------------------------------------------------------------------------------------
+__global__ void k_cam_update(int m, int cnp, ModelCfg cfg, double mu, const double *__restrict__ cam_a,
+                             const double *__restrict__ dA, const double *__restrict__ camvec,
+                             const double *__restrict__ R0, const double *__restrict__ f_fixed,
+                             double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ scal)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    double dl = 0.0, dp2 = 0.0;
+    if (j < m) {
+        double an[kCP];
+#pragma unroll
+        for (int r = 0; r < kCP; ++r) {
+            const double d = (r < cnp && j >= cfg.mcon) ? dA[j * kCP + r] : 0.0;
+            an[r] = cam_a[j * kCP + r] + d;
+            cam_a_new[j * kCP + r] = an[r];
+            dl += d * (mu * d + camvec[j * kCP + r]);
+            dp2 += d * d;
+        }
+        cam_record(cfg, cnp, an, R0 + (size_t)j * 9, f_fixed ? f_fixed[j] : 1.0, cam_lin_new + (size_t)j * kCamLin);
+    }
+    dl = wave_sum(dl); dp2 = wave_sum(dp2);
+    if ((threadIdx.x & 63) == 0) { gadd(&scal[SC_DL_CAMS], dl); gadd(&scal[SC_DP2_CAMS], dp2); }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_backsub: db_i = V*^-1 (eb_i - sum_j W_ij^T da_j) = h_i - V*^-1 sum_j B^T (A da_j)
+// (sba_levmar.c:1393-1433), trial point, cost at p + dp (:1468-1476), dL and ||dp||^2 point parts,
+// and Bundler's max relative residual change (:1552-1561).  One wavefront per batch.
+// ------------------------------------------------------------------------------------------
+template <int CNP>
+__global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
+{
+    __shared__ double sT[kWave * 3], sX[kWave * 3];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const ModelCfg cfg = g.cfg;
+    const int o0 = g.batch_obs[b], nob = g.batch_obs[b + 1] - o0;
+    const int p0 = g.batch_pt[b], npt = g.batch_pt[b + 1] - p0;
+    const bool active = lane < nob;
+    double e[2] = { 0.0, 0.0 };
+    int j = 0, lp = 0;
+    double2 xy = make_double2(0.0, 0.0);
+    if (active) {
+        const int o = o0 + lane;
+        j = g.obs_cam[o];
+        const int ip = g.obs_pt[o];
+        lp = ip - p0;
+        xy = g.obs_xy[o];
+        const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
+        double A[2][CNP], B[2][3];
+        linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, j < cfg.mcon, e, A, B);
+        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < CNP; ++t) { const double d = g.dA[j * kCP + t]; w0 += A[0][t] * d; w1 += A[1][t] * d; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) sT[lane * 3 + t] = B[0][t] * w0 + B[1][t] * w1;
+    }
+    __syncthreads();
+    double dl = 0.0, dp2 = 0.0;
+    if (lane < npt) {
+        const int ip = p0 + lane;
+        const int os = g.pt_obs[ip] - o0, oe = g.pt_obs[ip + 1] - o0;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+        for (int o = os; o < oe; ++o) { t0 += sT[o * 3]; t1 += sT[o * 3 + 1]; t2 += sT[o * 3 + 2]; }
+        const double *po = g.ptout + (size_t)ip * kPtOut;
+        const double d0 = po[6] - (po[0] * t0 + po[1] * t1 + po[2] * t2);
+        const double d1 = po[7] - (po[1] * t0 + po[3] * t1 + po[4] * t2);
+        const double d2 = po[8] - (po[2] * t0 + po[4] * t1 + po[5] * t2);
+        const double X0 = g.pts[3 * (size_t)ip] + d0, X1 = g.pts[3 * (size_t)ip + 1] + d1, X2 = g.pts[3 * (size_t)ip + 2] + d2;
+        g.pts_new[3 * (size_t)ip] = X0; g.pts_new[3 * (size_t)ip + 1] = X1; g.pts_new[3 * (size_t)ip + 2] = X2;
+        if (g.dB) { g.dB[3 * (size_t)ip] = d0; g.dB[3 * (size_t)ip + 1] = d1; g.dB[3 * (size_t)ip + 2] = d2; }
+        sX[lane * 3] = X0; sX[lane * 3 + 1] = X1; sX[lane * 3 + 2] = X2;
+        dl = d0 * (g.mu * d0 + po[9]) + d1 * (g.mu * d1 + po[10]) + d2 * (g.mu * d2 + po[11]);
+        dp2 = d0 * d0 + d1 * d1 + d2 * d2;
+    }
+    __syncthreads();
+    double cn = 0.0, pct = 0.0;
+    if (active) {
+        const double Xn[3] = { sX[lp * 3], sX[lp * 3 + 1], sX[lp * 3 + 2] };
+        double u, v;
+        project_obs(cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, u, v);
+        const double en0 = xy.x - u, en1 = xy.y - v;
+        cn = en0 * en0 + en1 * en1;
+        // QUIRK kept from sba_levmar.c:1554: signed comparison against eps5
+        if (!(e[0] < g.eps5 && en0 < g.eps5)) pct = fmax(pct, fabs((e[0] - en0) / e[0]));
+        if (!(e[1] < g.eps5 && en1 < g.eps5)) pct = fmax(pct, fabs((e[1] - en1) / e[1]));
+        if (!(pct == pct)) pct = 0.0; // 0/0 when both residuals vanish
+    }
+    cn = wave_sum(cn); dl = wave_sum(dl); dp2 = wave_sum(dp2); pct = wave_max(pct);
+    if (lane == 0) {
+        gadd(&g.scal[SC_COST_NEW], cn);
+        gadd(&g.scal[SC_DL_PTS], dl);
+        gadd(&g.scal[SC_DP2_PTS], dp2);
+        atomic_max_pos(&g.scal[SC_MAX_PCT], pct);
+    }
+}
+
+__global__ void k_rotations(int m, const double *__restrict__ cam_lin, double *__restrict__ R)
+{
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < m * 9) R[gid] = cam_lin[(size_t)(gid / 9) * kCamLin + gid % 9];
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
+                     const double *f_fixed, double *cam_lin)
+{
+    hipLaunchKernelGGL(k_cam_prep, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, cam_a, R0, f_fixed, cam_lin);
+}
+
+void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a)
+{
+    if (ntiles <= 0) return;
+    if (cnp == 7) {
+        if (lds_mode) hipLaunchKernelGGL((k_build<7, true>), dim3(ntiles), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_build<7, false>), dim3(ntiles), dim3(64), 0, st, a);
+    } else {
+        if (lds_mode) hipLaunchKernelGGL((k_build<6, true>), dim3(ntiles), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_build<6, false>), dim3(ntiles), dim3(64), 0, st, a);
+    }
+}
+
+void launch_finalize(hipStream_t st, int cnp, int m, int nb, int mcon, double mu, const int *bsr_rowidx, const int *bsr_col,
+                     const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
+                     const double *camvec, const double *cam_a, double *E, double *scal)
+{
+    const long long total = (long long)nb * 64;
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cnp, nb, mcon, mu, bsr_rowidx,
+                       bsr_col, bsr_src, bsr_trans, S_up, S_full);
+    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, mcon, camvec, cam_a, E, scal);
+}
+
+void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal)
+{
+    hipLaunchKernelGGL(k_block_inv, dim3((m + 63) / 64), dim3(64), 0, st, m, bsr_diag, S_full, Minv, scal);
+}
+
+void launch_pcg_init(hipStream_t st, const PcgArgs &a)
+{
+    hipLaunchKernelGGL(k_pcg_init, dim3((a.m + 7) / 8), dim3(64), 0, st, a);
+}
+
+void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
+{
+    hipLaunchKernelGGL(k_pcg_spmv, dim3(a.m), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_pcg_update, dim3((a.m + 7) / 8), dim3(64), 0, st, a);
+}
+
+void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, double mu, const double *cam_a, const double *dA,
+                       const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
+                       double *cam_lin_new, double *scal)
+{
+    hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, mu, cam_a, dA, camvec, R0, f_fixed,
+                       cam_a_new, cam_lin_new, scal);
+}
+
+void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
+{
+    if (a.nbatch <= 0) return;
+    if (cnp == 7) hipLaunchKernelGGL((k_backsub<7>), dim3(a.nbatch), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_backsub<6>), dim3(a.nbatch), dim3(64), 0, st, a);
+}
+
+void launch_rotations(hipStream_t st, int m, const double *cam_lin, double *R)
+{
+    hipLaunchKernelGGL(k_rotations, dim3((m * 9 + 255) / 256), dim3(256), 0, st, m, cam_lin, R);
+}
+
+} // namespace miba

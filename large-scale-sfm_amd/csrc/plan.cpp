@@ -1,0 +1,303 @@
+// plan.cpp -- see plan.h.  Pure host code (no HIP); exported through mi_ba_plan_* for CPU tests.
+#include "plan.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <unordered_map>
+
+namespace miba {
+
+int Plan::upper_block(int j, int k) const
+{
+    if (j > k) std::swap(j, k);
+    const int *b = up_col.data() + up_row[j], *e = up_col.data() + up_row[j + 1];
+    const int *it = std::lower_bound(b, e, k);
+    return (it != e && *it == k) ? (int)(it - up_col.data()) : -1;
+}
+
+namespace {
+
+inline int point_class(int d)
+{
+    if (d == 0) return 3;
+    if (d <= kMaxViewsLds) return 0;
+    if (d <= kWave) return 1;
+    return 2;
+}
+
+inline double point_weight(int d) { return (double)d + 0.5 * (double)d * (d + 1); }
+
+} // namespace
+
+std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
+                       int rank, int world, int tile_max_batches)
+{
+    if (n <= 0 || m <= 0 || nobs < 0) return "empty problem";
+    if (world < 1 || rank < 0 || rank >= world) return "bad rank/world";
+    if ((int64_t)m * m / 8 > (int64_t)1 << 30) return "more than ~92k cameras is not supported yet";
+    if (nobs >= ((int64_t)1 << 31)) return "more than 2^31 observations is not supported yet";
+    const bool auto_tile = tile_max_batches <= 0;
+    if (auto_tile) tile_max_batches = 32;
+    pl = Plan();
+    pl.n = n; pl.m = m; pl.nobs = nobs; pl.rank = rank; pl.world = world;
+
+    // ---- CSR by point, cameras ascending inside a point
+    std::vector<int> pt_ptr(n + 1, 0);
+    for (int64_t o = 0; o < nobs; ++o) {
+        int i = pt_idx[o], j = cam_idx[o];
+        if (i < 0 || i >= n) return "point index out of range";
+        if (j < 0 || j >= m) return "camera index out of range";
+        if (o && pt_idx[o - 1] > i) return "observations must be sorted by point (pt_idx non-decreasing)";
+        pt_ptr[i + 1]++;
+    }
+    for (int i = 0; i < n; ++i) pt_ptr[i + 1] += pt_ptr[i];
+    std::vector<int> cam(nobs);
+    std::vector<int64_t> src(nobs);
+    {
+        std::vector<std::pair<int, int64_t>> tmp;
+        for (int i = 0; i < n; ++i) {
+            int b = pt_ptr[i], e = pt_ptr[i + 1];
+            bool sorted = true;
+            for (int o = b + 1; o < e; ++o) if (cam_idx[o - 1] >= cam_idx[o]) { sorted = false; break; }
+            if (sorted) {
+                for (int o = b; o < e; ++o) { cam[o] = cam_idx[o]; src[o] = o; }
+            } else {
+                tmp.clear();
+                for (int o = b; o < e; ++o) tmp.emplace_back(cam_idx[o], (int64_t)o);
+                std::sort(tmp.begin(), tmp.end());
+                for (int o = b; o < e; ++o) { cam[o] = tmp[o - b].first; src[o] = tmp[o - b].second; }
+                for (int o = b + 1; o < e; ++o)
+                    if (cam[o] == cam[o - 1]) return "a point is observed twice by the same camera";
+            }
+        }
+    }
+
+    // ---- permutation: class, then visibility signature (lexicographic camera list)
+    pl.perm.resize(n);
+    std::iota(pl.perm.begin(), pl.perm.end(), 0);
+    auto deg = [&](int i) { return pt_ptr[i + 1] - pt_ptr[i]; };
+    std::sort(pl.perm.begin(), pl.perm.end(), [&](int a, int b) {
+        int ca = point_class(deg(a)), cb = point_class(deg(b));
+        if (ca != cb) return ca < cb;
+        if (ca == 0 || ca == 1) {
+            const int *pa = cam.data() + pt_ptr[a], *pb = cam.data() + pt_ptr[b];
+            int da = deg(a), db = deg(b), dm = std::min(da, db);
+            for (int t = 0; t < dm; ++t) if (pa[t] != pb[t]) return pa[t] < pb[t];
+            if (da != db) return da < db;
+        }
+        return a < b;
+    });
+    pl.n_active = 0;
+    for (int i = 0; i < n; ++i) if (deg(i) > 0) pl.n_active++;
+
+    // ---- shard cut (contiguous internal ranges, balanced by observations + pairs)
+    {
+        double total = 0;
+        for (int t = 0; t < pl.n_active; ++t) total += point_weight(deg(pl.perm[t]));
+        double lo = total * rank / world, hi = total * (rank + 1) / world, acc = 0;
+        int b = pl.n_active, e = pl.n_active;
+        bool have_b = false;
+        for (int t = 0; t < pl.n_active; ++t) {
+            if (!have_b && acc >= lo) { b = t; have_b = true; }
+            acc += point_weight(deg(pl.perm[t]));
+            if (acc >= hi && rank != world - 1) { e = t + 1; break; }
+        }
+        if (!have_b) b = pl.n_active;
+        if (rank == 0) b = 0;
+        if (rank == world - 1) e = pl.n_active;
+        if (e < b) e = b;
+        pl.pt_begin = b; pl.pt_end = e;
+    }
+
+    // ---- block pattern of S from ALL points (every rank must agree on it)
+    {
+        const size_t words = ((size_t)m + 63) / 64;
+        std::vector<uint64_t> bits(words * (size_t)m, 0);
+        for (int j = 0; j < m; ++j) bits[(size_t)j * words + (j >> 6)] |= 1ull << (j & 63);
+        const int *prev = nullptr; int prevd = -1;
+        for (int t = 0; t < pl.n_active; ++t) {
+            int i = pl.perm[t], d = deg(i);
+            const int *c = cam.data() + pt_ptr[i];
+            if (d == prevd && prev && std::memcmp(prev, c, sizeof(int) * d) == 0) continue; // same signature
+            prev = c; prevd = d;
+            for (int a = 0; a < d; ++a) {
+                uint64_t *row = bits.data() + (size_t)c[a] * words;
+                for (int b = a + 1; b < d; ++b) row[c[b] >> 6] |= 1ull << (c[b] & 63);
+            }
+        }
+        pl.up_row.assign(m + 1, 0);
+        for (int j = 0; j < m; ++j) {
+            int cnt = 0;
+            const uint64_t *row = bits.data() + (size_t)j * words;
+            for (size_t w = 0; w < words; ++w) cnt += __builtin_popcountll(row[w]);
+            pl.up_row[j + 1] = pl.up_row[j] + cnt;
+        }
+        pl.up_col.resize(pl.up_row[m]);
+        for (int j = 0; j < m; ++j) {
+            int *out = pl.up_col.data() + pl.up_row[j];
+            const uint64_t *row = bits.data() + (size_t)j * words;
+            for (size_t w = 0; w < words; ++w) {
+                uint64_t v = row[w];
+                while (v) { int b = __builtin_ctzll(v); *out++ = (int)(w * 64 + b); v &= v - 1; }
+            }
+        }
+        // full pattern: row j = {k < j : (k,j) upper} U {k >= j : (j,k) upper}, columns ascending
+        std::vector<int> lowcnt(m, 0);
+        for (int j = 0; j < m; ++j)
+            for (int q = pl.up_row[j]; q < pl.up_row[j + 1]; ++q) if (pl.up_col[q] != j) lowcnt[pl.up_col[q]]++;
+        pl.bsr_row.assign(m + 1, 0);
+        for (int j = 0; j < m; ++j) pl.bsr_row[j + 1] = pl.bsr_row[j] + lowcnt[j] + (pl.up_row[j + 1] - pl.up_row[j]);
+        int nbf = pl.bsr_row[m];
+        pl.bsr_col.resize(nbf); pl.bsr_src.resize(nbf); pl.bsr_trans.resize(nbf);
+        std::vector<int> fill(m);
+        for (int j = 0; j < m; ++j) fill[j] = pl.bsr_row[j];
+        for (int j = 0; j < m; ++j)            // lower parts first (rows visited ascending => sorted)
+            for (int q = pl.up_row[j]; q < pl.up_row[j + 1]; ++q) {
+                int k = pl.up_col[q];
+                if (k == j) continue;
+                int pos = fill[k]++;
+                pl.bsr_col[pos] = j; pl.bsr_src[pos] = q; pl.bsr_trans[pos] = 1;
+            }
+        for (int j = 0; j < m; ++j)
+            for (int q = pl.up_row[j]; q < pl.up_row[j + 1]; ++q) {
+                int pos = fill[j]++;
+                pl.bsr_col[pos] = pl.up_col[q]; pl.bsr_src[pos] = q; pl.bsr_trans[pos] = 0;
+            }
+    }
+
+    // ---- local shard arrays
+    const int npl = pl.pt_end - pl.pt_begin;
+    pl.pt_obs.assign(npl + 1, 0);
+    for (int t = 0; t < npl; ++t) pl.pt_obs[t + 1] = pl.pt_obs[t] + deg(pl.perm[pl.pt_begin + t]);
+    const int nol = pl.pt_obs[npl];
+    pl.obs_cam.resize(nol); pl.obs_pt.resize(nol); pl.obs_src.resize(nol); pl.obs_cslot.assign(nol, 0);
+    for (int t = 0; t < npl; ++t) {
+        int i = pl.perm[pl.pt_begin + t], d = deg(i);
+        for (int a = 0; a < d; ++a) {
+            int o = pl.pt_obs[t] + a;
+            pl.obs_cam[o] = cam[pt_ptr[i] + a];
+            pl.obs_src[o] = src[pt_ptr[i] + a];
+            pl.obs_pt[o] = t;
+        }
+    }
+
+    // ---- batches and tiles
+    // tile length: long enough that the per-tile flush of the LDS accumulators is amortised, short
+    // enough that the grid still has ~8 workgroups per CU (256 CUs) to balance
+    if (auto_tile) {
+        const int est_batches = nol / kWave + 1;
+        tile_max_batches = std::min(32, std::max(2, (est_batches + 2047) / 2048));
+    }
+    pl.batch_obs.assign(1, 0); pl.batch_pt.assign(1, 0); pl.batch_pair.assign(1, 0);
+    pl.tile_batch.assign(1, 0); pl.tile_slot.assign(1, 0); pl.tile_cslot.assign(1, 0);
+    std::unordered_map<uint64_t, int> smap;
+    std::unordered_map<int, int> cmap;
+    std::vector<int> sig_slots;       // slots of the previous point's pairs (signature cache)
+    const int *sig_cams = nullptr; int sig_d = -1;
+    int cur_obs = 0, batches_in_tile = 0;
+    int t = 0;
+
+    auto close_batch = [&](int t_end) {
+        if (cur_obs == 0) return;
+        pl.batch_obs.push_back(pl.pt_obs[t_end]);
+        pl.batch_pt.push_back(t_end);
+        pl.batch_pair.push_back((int64_t)pl.pair.size());
+        cur_obs = 0;
+        batches_in_tile++;
+    };
+    auto close_tile = [&](uint8_t mode) {
+        if (batches_in_tile == 0) return;
+        pl.tile_batch.push_back((int)pl.batch_obs.size() - 1);
+        pl.tile_slot.push_back((int)pl.slot_gblk.size());
+        pl.tile_cslot.push_back((int)pl.cslot_cam.size());
+        pl.tile_mode.push_back(mode);
+        pl.max_slots = std::max(pl.max_slots, (int)smap.size());
+        smap.clear(); cmap.clear(); sig_cams = nullptr; sig_d = -1;
+        batches_in_tile = 0;
+    };
+
+    // class 0: LDS-accumulated tiles
+    for (; t < npl; ++t) {
+        int d = pl.pt_obs[t + 1] - pl.pt_obs[t];
+        if (point_class(d) != 0) break;
+        const int *c = pl.obs_cam.data() + pl.pt_obs[t];
+        bool same_sig = (d == sig_d && sig_cams && std::memcmp(sig_cams, c, sizeof(int) * d) == 0);
+        if (cur_obs + d > kWave) {
+            close_batch(t);
+            if (batches_in_tile >= tile_max_batches) { close_tile(1); same_sig = false; }
+        }
+        if (!same_sig) {
+            int newb = 0, newc = 0;
+            for (int a = 0; a < d; ++a) {
+                if (!cmap.count(c[a])) newc++;
+                for (int b = a; b < d; ++b) if (!smap.count(((uint64_t)c[a] << 32) | (uint32_t)c[b])) newb++;
+            }
+            if ((int)smap.size() + newb > kNSlot || (int)cmap.size() + newc > kNCSlot) {
+                close_batch(t);
+                close_tile(1);
+            }
+            sig_slots.clear();
+            for (int a = 0; a < d; ++a) {
+                if (!cmap.count(c[a])) {
+                    int cs = (int)cmap.size();
+                    cmap[c[a]] = cs;
+                    pl.cslot_cam.push_back(c[a]);
+                }
+                for (int b = a; b < d; ++b) {
+                    uint64_t key = ((uint64_t)c[a] << 32) | (uint32_t)c[b];
+                    auto it = smap.find(key);
+                    int s;
+                    if (it == smap.end()) {
+                        s = (int)smap.size();
+                        smap.emplace(key, s);
+                        int g = pl.upper_block(c[a], c[b]);
+                        if (g < 0) return "internal: block missing from pattern";
+                        pl.slot_gblk.push_back(g);
+                    } else s = it->second;
+                    sig_slots.push_back(s);
+                }
+            }
+            sig_cams = c; sig_d = d;
+        }
+        int q = 0;
+        for (int a = 0; a < d; ++a) {
+            pl.obs_cslot[pl.pt_obs[t] + a] = (uint8_t)cmap[c[a]];
+            for (int b = a; b < d; ++b)
+                pl.pair.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6) | ((uint32_t)sig_slots[q++] << 12));
+        }
+        cur_obs += d;
+    }
+    close_batch(t);
+    close_tile(1);
+    pl.npair_lds = (int64_t)pl.pair.size();
+    pl.ntile_lds = pl.ntile();
+    pl.nbatch_lds = pl.nbatch();
+
+    // class 1: direct tiles (pairs add straight into S with global atomics)
+    for (; t < npl; ++t) {
+        int d = pl.pt_obs[t + 1] - pl.pt_obs[t];
+        if (point_class(d) != 1) break;
+        const int *c = pl.obs_cam.data() + pl.pt_obs[t];
+        if (cur_obs + d > kWave) {
+            close_batch(t);
+            if (batches_in_tile >= tile_max_batches) close_tile(0);
+        }
+        for (int a = 0; a < d; ++a)
+            for (int b = a; b < d; ++b) {
+                int g = pl.upper_block(c[a], c[b]);
+                if (g < 0) return "internal: block missing from pattern";
+                pl.pair.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6));
+                pl.pair_gblk.push_back((uint32_t)g);
+            }
+        cur_obs += d;
+    }
+    close_batch(t);
+    close_tile(0);
+
+    // class 2: long points
+    for (; t < npl; ++t) pl.long_pts.push_back(t);
+    return "";
+}
+
+} // namespace miba

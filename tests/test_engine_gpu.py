@@ -1,0 +1,240 @@
+"""Parity of the HIP engine (through the C ABI, include/mi_ba.h) against the CPU oracle and the
+golden vectors of the real reference.  Needs an MI355X: run with  pytest -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import pkg, scene_from_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def reduced_system(lin, sc, mu, mcon=0):
+    """S(mu), E(mu), Vinv from the oracle's undamped blocks (numpy, dense)."""
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    Vinv = np.linalg.inv(lin["V"] + mu * np.eye(3))
+    N = m * cnp
+    S = np.zeros((N, N)); E = lin["ea"].copy().reshape(-1)
+    pt = sc.obs_pt()
+    Y = np.einsum("oab,obc->oac", lin["W"], Vinv[pt])
+    for i in range(n):
+        obs = range(sc.pt_ptr[i], sc.pt_ptr[i + 1])
+        for a in obs:
+            ja = sc.obs_cam[a]
+            E[ja * cnp:(ja + 1) * cnp] -= Y[a] @ lin["eb"][i]
+            for b in obs:
+                jb = sc.obs_cam[b]
+                S[ja * cnp:(ja + 1) * cnp, jb * cnp:(jb + 1) * cnp] -= Y[a] @ lin["W"][b].T
+    for j in range(m):
+        S[j * cnp:(j + 1) * cnp, j * cnp:(j + 1) * cnp] += lin["U"][j] + mu * np.eye(cnp)
+    return S, E, Vinv
+
+
+def make_engine(sc, **kw):
+    capi = pkg("capi")
+    eng = capi.Engine(capi.default_config(est_focal=sc.est_focal, explicit_centers=sc.explicit_centers,
+                                          proj_sign=sc.proj_sign, **kw))
+    eng.load_scene(sc)
+    eng.prepare()
+    return eng
+
+
+@pytest.mark.parametrize("name", ["micro", "C1", "C1t"])
+def test_linearization_blocks(oracle, name):
+    sc, z = scene_from_golden(name)
+    eng = make_engine(sc)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    g = eng.debug_linearize(mu)
+    assert abs(g["cost"] - lin["cost"]) <= 1e-11 * lin["cost"]
+    assert rel(g["ea"], lin["ea"]) < 1e-10
+    assert rel(g["eb"], lin["eb"]) < 1e-10
+    assert rel(g["V"], lin["V"]) < 1e-8          # recovered from (V + mu I)^-1 on the host
+    assert rel(g["diagU"], np.einsum("jrr->jr", lin["U"])) < 1e-10
+    S, E, _ = reduced_system(lin, sc, mu)
+    scale = np.abs(lin["U"]).max()
+    assert np.abs(g["S"] - S).max() < 1e-10 * scale
+    assert np.abs(g["S"] - g["S"].T).max() == 0.0 or np.abs(g["S"] - g["S"].T).max() < 1e-12 * scale
+    assert rel(g["E"].reshape(-1), E) < 1e-9
+    # against the REAL reference's finite-difference blocks (golden): same quantities, looser
+    assert rel(g["diagU"], np.einsum("jrr->jr", z["U0"])) < 1e-4
+    assert rel(g["V"], z["V0"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["micro", "C1", "C1t"])
+def test_solve_and_backsubstitution(oracle, name):
+    sc, z = scene_from_golden(name)
+    eng = make_engine(sc, pcg_tol=1e-13, pcg_maxit=400)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    eng.debug_linearize(mu)
+    g = eng.debug_solve(mu)
+    S, E, Vinv = reduced_system(lin, sc, mu)
+    da = np.linalg.solve(S, E).reshape(sc.m, sc.cnp)
+    assert rel(g["da"], da) < 1e-7
+    pt = sc.obs_pt()
+    t = np.zeros((sc.n, 3))
+    np.add.at(t, pt, np.einsum("oab,oa->ob", lin["W"], da[sc.obs_cam]))
+    db = np.einsum("iab,ib->ia", Vinv, lin["eb"] - t)
+    assert rel(g["db"], db) < 1e-7
+    p_new = sc.p0 + np.concatenate([da.reshape(-1), db.reshape(-1)])
+    want = oracle.cost(sc, p_new)
+    assert abs(g["cost_new"] - want) < 1e-7 * want
+
+
+@pytest.mark.parametrize("name", ["micro", "C1", "C1t"])
+def test_full_solve_matches_reference(oracle, name):
+    """north_star parity bar: final reprojection RMSE within max(1e-3 px, 0.5 %) of the
+    reference sba-1.5 solve (golden), same LM trajectory."""
+    sc, z = scene_from_golden(name)
+    eng = make_engine(sc)
+    ret, info = eng.run()
+    want = z["info_final"]
+    rm, rw = np.sqrt(info[1] / sc.nobs), np.sqrt(want[1] / sc.nobs)
+    assert abs(rm - rw) <= max(1e-3, 0.005 * rw)
+    assert ret == int(z["ret_final"]) and info[6] == want[6] and info[9] == want[9]
+    assert abs(info[0] - want[0]) <= 1e-9 * want[0]
+    # cost after every accepted step within 5 % of the reference trace, in fact much closer
+    tr = eng.trace()
+    acc = tr[tr[:, 4] == 1][:, 3]
+    k = min(len(acc), len(z["cost_trace"]))
+    assert np.allclose(acc[:k], z["cost_trace"][:k], rtol=1e-4)
+    assert np.all(np.diff(acc) < 0)
+    # parameters: same minimum
+    p = eng.packed_params()
+    assert np.abs(p - z["p_final"]).max() < 1e-4
+
+
+def test_tight_pcg_reproduces_oracle_trajectory(oracle):
+    sc, z = scene_from_golden("C1")
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert ret == o["ret"] and info[6] == o["info"][6]
+    assert np.abs(eng.packed_params() - o["p"]).max() < 1e-7
+    assert abs(info[1] - o["info"][1]) < 1e-9 * o["info"][1]
+    assert abs(info[4] - o["info"][4]) < 1e-6 * o["info"][4]
+
+
+def test_fixed_cameras(oracle):
+    sc, z = scene_from_golden("C1")
+    eng = make_engine(sc, mcon=2)
+    ret, info = eng.run()
+    p = eng.packed_params()
+    assert np.array_equal(p[:2 * sc.cnp], sc.p0[:2 * sc.cnp])
+    assert info[5] == z["info_mcon2"][5] and info[6] == z["info_mcon2"][6]
+    assert np.abs(p - z["p_mcon2"]).max() < 1e-4
+
+
+def test_rotations_unpack_like_run_sfm():
+    sc, z = scene_from_golden("C1")
+    eng = make_engine(sc)
+    eng.run()
+    a, xyz = eng.params()
+    assert np.abs(eng.rotations().reshape(-1, 3, 3) - z["sfm_R"]).max() < 1e-6
+    assert np.abs(a[:, :3] - z["sfm_t"]).max() < 1e-4
+    assert np.abs(a[:, 6] / 0.001 - z["sfm_f"]).max() < 1e-1
+    assert np.abs(xyz - z["sfm_pts"]).max() < 1e-4
+
+
+def test_fixed_focal_cnp6(oracle):
+    sc = pkg("scene").make_scene("x", m=12, n=800, d=5, seed=99, est_focal=0)
+    eng = make_engine(sc)
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert ret == o["ret"] and info[6] == o["info"][6]
+    assert abs(np.sqrt(info[1] / sc.nobs) - np.sqrt(o["info"][1] / sc.nobs)) < 1e-6
+
+
+def test_long_tracks_use_direct_tiles(oracle):
+    """points with > 10 views bypass the LDS tile and add straight into S"""
+    sc = pkg("scene").make_scene("x", m=40, n=600, d=13, seed=5, strides=(1, 2, 3))
+    capi = pkg("capi")
+    st = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).stats()
+    assert st["nbatch_direct"] == st["nbatch"] and st["npair_direct"] == sc.n * 13 * 14 // 2
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    g = eng.debug_linearize(mu)
+    S, E, _ = reduced_system(lin, sc, mu)
+    assert np.abs(g["S"] - S).max() < 1e-10 * np.abs(lin["U"]).max()
+    assert rel(g["E"].reshape(-1), E) < 1e-9
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert ret == o["ret"]
+    assert abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
+
+
+def test_mixed_track_lengths_and_unsorted_cameras(oracle):
+    """ragged input: track lengths 2..14, cameras NOT sorted inside a point, some points unobserved"""
+    scene = pkg("scene")
+    rng = np.random.default_rng(3)
+    base = scene.make_scene("x", m=30, n=900, d=14, seed=8, strides=(1, 2))
+    keep = []
+    for i in range(base.n):
+        d = int(rng.integers(2, 15)) if i % 50 else 0          # every 50th point has no observation
+        idx = np.arange(base.pt_ptr[i], base.pt_ptr[i + 1])
+        keep.append(rng.permutation(idx)[:d])                  # random subset, random order
+    sel = np.concatenate(keep)
+    pt = np.repeat(np.arange(base.n), [len(k) for k in keep]).astype(np.int32)
+    cam, xy = base.obs_cam[sel], base.x[sel]
+    # oracle wants cameras ascending inside a point
+    order = np.lexsort((cam, pt))
+    sc = scene.Scene(n=base.n, m=base.m, cnp=base.cnp, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0,
+                     pt_ptr=np.concatenate([[0], np.cumsum(np.bincount(pt, minlength=base.n))]).astype(np.int32),
+                     obs_cam=cam[order], x=xy[order], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true)
+    capi = pkg("capi")
+    eng = capi.Engine(capi.default_config(pcg_tol=1e-12, pcg_maxit=400))
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    eng.set_problem(sc.p0[:m * cnp].reshape(m, cnp), sc.R0, sc.f_fixed, sc.p0[m * cnp:].reshape(n, 3), xy, pt, cam)
+    eng.prepare()
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert ret == o["ret"] and info[6] == o["info"][6]
+    assert abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
+    p = eng.packed_params()
+    assert np.abs(p - o["p"]).max() < 1e-6
+    unobserved = np.arange(0, n, 50)
+    assert np.array_equal(p[m * cnp:].reshape(n, 3)[unobserved], sc.p0[m * cnp:].reshape(n, 3)[unobserved])
+
+
+def test_error_paths():
+    capi = pkg("capi")
+    sc, _ = scene_from_golden("micro")
+    eng = capi.Engine(capi.default_config())
+    with pytest.raises(RuntimeError, match="prepare"):
+        eng.prepare()                                   # nothing set
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    a0, xyz = sc.p0[:m * cnp].reshape(m, cnp), sc.p0[m * cnp:].reshape(n, 3)
+    eng.set_problem(a0, sc.R0, sc.f_fixed, xyz[:2], sc.x[:8], sc.obs_pt()[:8], sc.obs_cam[:8])
+    with pytest.raises(RuntimeError, match="fewer measurements"):   # sba_levmar.c:647-650
+        eng.prepare()
+    pt = sc.obs_pt().copy(); pt[[0, 5]] = pt[[5, 0]]
+    eng.set_problem(a0, sc.R0, sc.f_fixed, xyz, sc.x, pt, sc.obs_cam)
+    with pytest.raises(RuntimeError, match="sorted by point"):
+        eng.prepare()
+    with pytest.raises(RuntimeError, match="not supported"):
+        capi.Engine(capi.default_config(undistort=1))
+
+
+def test_c2_size_properties(oracle):
+    """BASELINE config C2 (200 cams / 100k pts / 1M obs): size-independent properties --
+    monotone cost, converged RMSE at the noise level, agreement with the oracle's cost function
+    at the returned parameters, idempotence of a second solve."""
+    sc = pkg("scene").make_scene("C2")
+    eng = make_engine(sc)
+    ret, info = eng.run()
+    tr = eng.trace()
+    acc = tr[tr[:, 4] == 1][:, 3]
+    assert ret > 3 and np.all(np.diff(acc) < 0)
+    rmse = np.sqrt(info[1] / sc.nobs)
+    assert 0.12 < rmse < 0.16                                  # U(-0.25,0.25) noise: sigma 0.144, minus fitted dof
+    p = eng.packed_params()
+    assert abs(oracle.cost(sc, p) - info[1]) < 1e-9 * info[1]  # CPU cost function at the GPU's answer
+    a, xyz = eng.params()
+    eng.set_params(a, xyz)
+    ret2, info2 = eng.run()
+    assert info2[1] <= info[1] * (1 + 1e-12) and info2[0] == pytest.approx(info[1], rel=1e-12)
