@@ -1,0 +1,162 @@
+#!/usr/bin/env python
+"""bench.py -- LM iterations/sec (+ reprojection RMSE) of the MI355X bundle-adjustment engine.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE Levenberg-Marquardt damping trial (sba's nlss unit: one reduced camera system
+built, solved and gain-ratio tested) over the whole synthetic scene, inputs resident in HBM.
+Workload = BASELINE.json's metric config, C3: 1k cameras / 1M points / 10M observations
+(seeded, large-scale-sfm_amd/scene.py).  With N > 1 the SAME scene is point-sharded over the
+ranks (RCCL all-reduce of the Schur partials inside libmi_ba.so), so scaling is "strong".
+Rank 0 prints one JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(scene_mod):
+    """The reference's CPU solve timed on this box's host cores, on a bounded sample (config C2:
+    C3 needs a 392 MB dense S and ~1e11 flop of Cholesky per iteration -> minutes per iteration)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle, Reference
+    sc = scene_mod.make_scene("C2")
+    sample = "config C2 (200 cams / 100k pts / 1M obs, same generator)"
+    try:
+        if Reference.available():
+            ref = Reference()
+            t0 = time.time()
+            r = ref.run(sc, itmax=2)
+            dt = time.time() - t0
+            return {"value": float(r["info"][9] / dt), "unit": "LM iterations/s", "cores": 1, "kind": "reference",
+                    "sample": sample + ", 2 LM iterations of the real sba-1.5 (FD Jacobian, dense Cholesky via MKL, "
+                    "MKL_NUM_THREADS unset: sba itself is single-threaded), %.1f s" % dt,
+                    "rmse_after": float(np.sqrt(r["info"][1] / sc.nobs))}
+    except Exception as ex:  # the prebuilt reference may not load on another box
+        sys.stderr.write("cpu_baseline: reference unavailable (%s), timing the port\n" % ex)
+    o = Oracle()
+    t0 = time.time()
+    r = o.run(sc, itmax=6, fd_jacobian=1)
+    dt = time.time() - t0
+    return {"value": float(r["info"][9] / dt), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": sample + ", 6 LM iterations of oracle/ba_oracle.c (FD Jacobian, dense Cholesky), %.1f s" % dt,
+            "rmse_after": float(np.sqrt(r["info"][1] / sc.nobs))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcg-tol", type=float, default=1e-3)
+    ap.add_argument("--pcg-maxit", type=int, default=100)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    capi = importlib.import_module("large-scale-sfm_amd.capi")
+    scene_mod = importlib.import_module("large-scale-sfm_amd.scene")
+
+    t0 = time.time()
+    sc = scene_mod.make_scene(args.config)
+    t_gen = time.time() - t0
+    cfg = capi.default_config(device=local_rank, rank=rank, world=world, itmax=1 << 30, disable_stops=1,
+                              pcg_tol=args.pcg_tol, pcg_maxit=args.pcg_maxit)
+    eng = capi.Engine(cfg)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        eng.comm_init(bytes(uid.cpu().numpy().tobytes()))
+    eng.load_scene(sc)
+    t0 = time.time()
+    eng.prepare()
+    t_plan = time.time() - t0
+    eng.begin()
+    rmse0 = float(np.sqrt(eng.info()[0] / sc.nobs))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step()
+    eng.reset_timing()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    tm = eng.timing()
+    info = eng.info()
+    tr = eng.trace()
+    rmse_after = float(np.sqrt(info[1] / sc.nobs))
+
+    if rank == 0:
+        build_ms = tm["build_ms"] / max(tm["build_launches"], 1)
+        achieved = tm["build_bytes"] / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
+        out = {
+            "metric": "LM iterations/sec (+ final reprojection RMSE), 1k cams / 1M pts",
+            "value": args.steps / dt, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {sc.m} cams / {sc.n} pts / {sc.nobs} obs, cnp 7 (pose + focal), "
+                       "point-sharded Schur + block-Jacobi PCG", "parallelism": f"points/{world}",
+                       "pcg_tol": args.pcg_tol, "pcg_maxit": args.pcg_maxit},
+            "rmse_px": {"initial": rmse0, "after_timed_steps": rmse_after},
+            "accepted_steps": int((tr[:, 4] == 1).sum()), "trials": int(len(tr)),
+            "pcg_iters_per_step": tm["pcg_iters"] / max(tm["pcg_solves"], 1),
+            "kernel_ms_per_step": {"build": build_ms, "pcg": tm["pcg_ms"] / max(tm["pcg_solves"], 1),
+                                   "backsub": tm["backsub_ms"] / max(tm["backsub_launches"], 1),
+                                   "allreduce_host": tm["allreduce_ms"] / max(tm["allreduces"], 1) if world > 1 else 0.0},
+            "setup_s": {"scene": t_gen, "plan_upload": t_plan},
+            "roofline": {"bound": "hbm", "kernel": "k_build<7,LDS> (fused linearise + Schur complement)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_launch": tm["build_bytes"], "avg_launch_ms": build_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_mod)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,9 +64,21 @@ def lib() -> C.CDLL:
         L.mi_ba_last_error.argtypes = [C.c_void_p]
         L.mi_ba_plan_build.restype = C.c_void_p
         L.mi_ba_plan_get.restype = C.c_int64
-        for name in ("mi_ba_destroy", "mi_ba_cnp", "mi_ba_prepare", "mi_ba_begin", "mi_ba_step", "mi_ba_reset_timing"):
-            getattr(L, name).argtypes = [C.c_void_p]
-        L.mi_ba_plan_free.argtypes = [C.c_void_p]
+        vp, dp, ip, dbl, i32, i64 = C.c_void_p, _dp, _ip, C.c_double, C.c_int, C.c_int64
+        sig = {
+            "mi_ba_destroy": [vp], "mi_ba_cnp": [vp], "mi_ba_prepare": [vp], "mi_ba_begin": [vp], "mi_ba_step": [vp],
+            "mi_ba_reset_timing": [vp], "mi_ba_set_cameras": [vp, i32, dp, dp, dp], "mi_ba_set_points": [vp, i32, dp],
+            "mi_ba_set_observations": [vp, i64, dp, ip, ip], "mi_ba_run": [vp, dp], "mi_ba_get_info": [vp, dp],
+            "mi_ba_get_trace": [vp, dp, i32], "mi_ba_get_params": [vp, dp, dp], "mi_ba_set_params": [vp, dp, dp],
+            "mi_ba_get_rotations": [vp, dp], "mi_ba_debug_linearize": [vp, dbl, dp, dp, dp, dp, dp, dp, dp],
+            "mi_ba_debug_solve": [vp, dbl, dp, dp, dp], "mi_ba_get_timing": [vp, C.POINTER(Timing)],
+            "mi_ba_comm_init": [vp, C.c_char_p], "mi_ba_comm_unique_id": [C.c_char_p],
+            "mi_ba_plan_build": [i32, i32, i64, ip, ip, i32, i32, i32], "mi_ba_plan_free": [vp],
+            "mi_ba_plan_stats": [vp, C.POINTER(i64)], "mi_ba_plan_get": [vp, C.c_char_p, vp, i64],
+            "mi_ba_create": [C.POINTER(Config)], "mi_ba_default_config": [C.POINTER(Config)],
+        }
+        for name, args in sig.items():
+            getattr(L, name).argtypes = args
         _lib = L
     return _lib
 
@@ -129,7 +141,7 @@ class Engine:
         self.m, self.n, self.nobs = a0.shape[0], xyz.shape[0], xy.shape[0]
         self._chk(self.L.mi_ba_set_cameras(self.h, self.m, _d(a0), _d(R0), _d(ff)), "set_cameras")
         self._chk(self.L.mi_ba_set_points(self.h, self.n, _d(xyz)), "set_points")
-        self._chk(self.L.mi_ba_set_observations(self.h, C.c_int64(self.nobs), _d(xy), pt.ctypes.data_as(_ip),
+        self._chk(self.L.mi_ba_set_observations(self.h, self.nobs, _d(xy), pt.ctypes.data_as(_ip),
                                                 cam.ctypes.data_as(_ip)), "set_observations")
 
     def comm_init(self, uid: bytes):
@@ -183,13 +195,13 @@ class Engine:
         N = self.m * self.cnp
         S = np.zeros((N, N)); E = np.zeros((self.m, self.cnp)); ea = np.zeros((self.m, self.cnp))
         eb = np.zeros((self.n, 3)); V = np.zeros((self.n, 3, 3)); dU = np.zeros((self.m, self.cnp)); cost = C.c_double(0)
-        self._chk(self.L.mi_ba_debug_linearize(self.h, C.c_double(mu), _d(S), _d(E), _d(ea), _d(eb), _d(V), _d(dU),
-                                               C.byref(cost)), "debug_linearize")
+        self._chk(self.L.mi_ba_debug_linearize(self.h, mu, _d(S), _d(E), _d(ea), _d(eb), _d(V), _d(dU),
+                                               C.cast(C.byref(cost), _dp)), "debug_linearize")
         return dict(S=S, E=E, ea=ea, eb=eb, V=V, diagU=dU, cost=cost.value)
 
     def debug_solve(self, mu):
         da = np.zeros((self.m, self.cnp)); db = np.zeros((self.n, 3)); cost = C.c_double(0)
-        its = self._chk(self.L.mi_ba_debug_solve(self.h, C.c_double(mu), _d(da), _d(db), C.byref(cost)), "debug_solve")
+        its = self._chk(self.L.mi_ba_debug_solve(self.h, mu, _d(da), _d(db), C.cast(C.byref(cost), _dp)), "debug_solve")
         return dict(da=da, db=db, cost_new=cost.value, pcg_iters=its)
 
     def timing(self) -> dict:
@@ -217,25 +229,25 @@ class Plan:
     def __init__(self, n, m, pt_idx, cam_idx, rank=0, world=1, tile_max_batches=0):
         self.L = lib()
         pt = np.ascontiguousarray(pt_idx, np.int32); cam = np.ascontiguousarray(cam_idx, np.int32)
-        self.h = self.L.mi_ba_plan_build(n, m, C.c_int64(len(pt)), pt.ctypes.data_as(_ip), cam.ctypes.data_as(_ip),
+        self.h = self.L.mi_ba_plan_build(n, m, len(pt), pt.ctypes.data_as(_ip), cam.ctypes.data_as(_ip),
                                          rank, world, tile_max_batches)
         if not self.h:
             raise ValueError("plan: " + self.L.mi_ba_last_error(None).decode())
 
     def stats(self) -> dict:
         s = (C.c_int64 * 16)()
-        self.L.mi_ba_plan_stats(C.c_void_p(self.h), s)
+        self.L.mi_ba_plan_stats(self.h, s)
         return {k: int(s[i]) for i, k in enumerate(PLAN_STATS)}
 
     def get(self, name: str) -> np.ndarray:
-        n = self.L.mi_ba_plan_get(C.c_void_p(self.h), name.encode(), None, C.c_int64(0))
+        n = self.L.mi_ba_plan_get(self.h, name.encode(), None, 0)
         if n < 0:
             raise KeyError(name)
         out = np.zeros(max(n, 1), self._dtypes.get(name, np.int32))
-        self.L.mi_ba_plan_get(C.c_void_p(self.h), name.encode(), out.ctypes.data_as(C.c_void_p), C.c_int64(n))
+        self.L.mi_ba_plan_get(self.h, name.encode(), out.ctypes.data_as(C.c_void_p), n)
         return out[:n]
 
     def __del__(self):
         if getattr(self, "h", None):
-            self.L.mi_ba_plan_free(C.c_void_p(self.h))
+            self.L.mi_ba_plan_free(self.h)
             self.h = None

@@ -103,9 +103,12 @@ def test_full_solve_matches_reference(oracle, name):
     k = min(len(acc), len(z["cost_trace"]))
     assert np.allclose(acc[:k], z["cost_trace"][:k], rtol=1e-4)
     assert np.all(np.diff(acc) < 0)
-    # parameters: same minimum
+    # same minimum: with no camera held fixed the minimiser is only defined up to the 7-dof gauge,
+    # along which an inexact PCG step may drift, so compare through the CPU cost function instead
+    # of parameter by parameter (test_tight_pcg_reproduces_oracle_trajectory does the latter)
     p = eng.packed_params()
-    assert np.abs(p - z["p_final"]).max() < 1e-4
+    assert abs(oracle.cost(sc, p) - info[1]) < 1e-9 * info[1]
+    assert np.abs(p - z["p_final"]).max() < 5e-3
 
 
 def test_tight_pcg_reproduces_oracle_trajectory(oracle):
@@ -134,7 +137,7 @@ def test_rotations_unpack_like_run_sfm():
     eng = make_engine(sc)
     eng.run()
     a, xyz = eng.params()
-    assert np.abs(eng.rotations().reshape(-1, 3, 3) - z["sfm_R"]).max() < 1e-6
+    assert np.abs(eng.rotations().reshape(-1, 3, 3) - z["sfm_R"]).max() < 1e-4   # gauge drift, see above
     assert np.abs(a[:, :3] - z["sfm_t"]).max() < 1e-4
     assert np.abs(a[:, 6] / 0.001 - z["sfm_f"]).max() < 1e-1
     assert np.abs(xyz - z["sfm_pts"]).max() < 1e-4
@@ -231,7 +234,7 @@ def test_c2_size_properties(oracle):
     acc = tr[tr[:, 4] == 1][:, 3]
     assert ret > 3 and np.all(np.diff(acc) < 0)
     rmse = np.sqrt(info[1] / sc.nobs)
-    assert 0.12 < rmse < 0.16                                  # U(-0.25,0.25) noise: sigma 0.144, minus fitted dof
+    assert 0.17 < rmse < 0.205                                 # U(-0.25,0.25) px per axis -> 0.204 px per point, minus fitted dof
     p = eng.packed_params()
     assert abs(oracle.cost(sc, p) - info[1]) < 1e-9 * info[1]  # CPU cost function at the GPU's answer
     a, xyz = eng.params()
