@@ -162,7 +162,8 @@ int Engine::prepare()
         !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Minv_.alloc((size_t)m_ * 64), "alloc Minv") ||
         !hipok(d_E_.alloc((size_t)m_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)m_ * kCP), "alloc dA") ||
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)m_ * kCP * 7), "alloc pcg") ||
-        !hipok(d_rzpq_.alloc((size_t)2 * (cfg.pcg_maxit + 4)), "alloc rz/pq"))
+        !hipok(d_rzpq_.alloc((size_t)(cfg.pcg_maxit + 4) + 2 * (size_t)((m_ + 7) / 8) + (size_t)m_), "alloc rz/pq") ||
+        !hipok(d_part_.alloc((size_t)std::max(pl.ntile(), kBacksubGrid) * kPartW), "alloc partials"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
@@ -236,13 +237,14 @@ bool Engine::linear_phase(double mu)
     a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p;
     a.pair = d_pair_.p; a.pair_gblk = d_pair_gblk_.p; a.pair_gblk_base = pl.npair_lds;
     a.m = m_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
-    a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.scal = scal_(); a.cfg = mc;
+    a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc;
     (void)hipEventRecord(ev_[0], st_);
     a.tile0 = 0;
     launch_build(st_, cnp, true, pl.ntile_lds, a);
     a.tile0 = pl.ntile_lds;
     launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
     (void)hipEventRecord(ev_[1], st_);
+    launch_reduce_partials(st_, pl.ntile(), d_part_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), cfg.mcon, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
                     S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_E_.p, scal_());
@@ -260,7 +262,9 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_full_.p; p.Minv = d_Minv_.p; p.E = d_E_.p;
     p.x = d_dA_.p; p.r = d_pcg_.p; p.r1 = d_pcg_.p + vec; p.z = d_pcg_.p + 2 * vec; p.p0 = d_pcg_.p + 3 * vec;
     p.p1 = d_pcg_.p + 4 * vec; p.q = d_pcg_.p + 5 * vec;
-    p.rz = d_rzpq_.p; p.pq = d_rzpq_.p + (cfg.pcg_maxit + 4); p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = m_; p.it = 0;
+    p.ng = (m_ + 7) / 8;
+    p.rz_hist = d_rzpq_.p; p.rzp = d_rzpq_.p + (cfg.pcg_maxit + 4); p.pqp = p.rzp + 2 * (size_t)p.ng;
+    p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = m_; p.it = 0;
     if (!hipok(hipMemsetAsync(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double), st_), "memset rz/pq")) return false;
     (void)hipEventRecord(ev_[2], st_);
     launch_pcg_init(st_, p);
@@ -270,12 +274,13 @@ bool Engine::solve_phase(double mu, double *dB_dev)
         const int chunk = std::min(kPcgChunk, cfg.pcg_maxit - it);
         for (int c = 0; c < chunk; ++c) { p.it = it + c; launch_pcg_iter(st_, p); }
         it += chunk;
+        p.it = it; launch_pcg_tail(st_, p); // rz_hist[it] for the host's convergence check
         if (!hipok(hipMemcpyAsync(h_scal_ + 64, d_rzpq_.p, sizeof(double) * nrz, hipMemcpyDeviceToHost, st_), "copy rz")) return false;
         if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
         if (!hipok(hipStreamSynchronize(st_), "sync (pcg)")) return false;
         const double *rz = h_scal_ + 64;
-        if (h_scal_[SC_PCG_STATUS] != 0.0 || !(rz[0] > 0.0)) break;
-        if (it <= cfg.pcg_maxit && std::sqrt(std::fabs(rz[it]) / rz[0]) < cfg.pcg_tol) break;
+        (void)rz;
+        if (h_scal_[SC_PCG_STATUS] != 0.0 || h_scal_[SC_PCG_DONE] != 0.0) break;
     }
     (void)hipEventRecord(ev_[3], st_);
     launch_cam_update(st_, m_, cnp, mc, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, d_cam_a_[cur_ ^ 1].p,
@@ -283,11 +288,12 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     BacksubArgs b{};
     b.batch_obs = d_batch_obs_.p; b.batch_pt = d_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
-    b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.scal = scal_();
-    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = pl.nbatch(); b.cfg = mc;
+    b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
+    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = pl.nbatch(); b.ngrid = std::min(pl.nbatch(), kBacksubGrid); b.cfg = mc;
     (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
     (void)hipEventRecord(ev_[5], st_);
+    launch_reduce_partials(st_, b.ngrid, d_part_.p, scal_() + SC_COST_NEW, scal_() + SC_MAX_PCT);
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }

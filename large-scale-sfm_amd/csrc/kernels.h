@@ -18,6 +18,8 @@ namespace miba {
 // S_full   [nb][64]     BSR values used by the PCG, Minv [m][64] block-Jacobi preconditioner
 constexpr int kCamLin = 24;
 constexpr int kPtOut = 12;
+constexpr int kPartW = 8;      // per-workgroup partial row: [0,4) sums, [4,8) maxima
+constexpr int kBacksubGrid = 8192;
 
 struct ModelCfg {
     int explicit_centers, est_focal, undistort, mcon;
@@ -53,7 +55,7 @@ struct BuildArgs {
     int tile0, m;
     const double *cam_lin, *pts;
     double mu;
-    double *S_up, *camvec, *ptout, *scal;
+    double *S_up, *camvec, *ptout, *part;   // part: [ntile][kPartW] cost, |X|^2, -, -, |eb|inf, max diag V, singular
     ModelCfg cfg;
 };
 
@@ -61,9 +63,9 @@ struct BacksubArgs {
     const int *batch_obs, *batch_pt, *pt_obs, *obs_cam, *obs_pt;
     const double2 *obs_xy;
     const double *cam_lin, *cam_lin_new, *pts, *ptout, *dA;
-    double *pts_new, *dB, *scal;
+    double *pts_new, *dB, *part;            // part: [ngrid][kPartW] cost_new, dL, |db|^2, -, max pct change
     double mu, eps5;
-    int nbatch;
+    int nbatch, ngrid;
     ModelCfg cfg;
 };
 
@@ -71,9 +73,9 @@ struct PcgArgs {
     const int *bsr_row, *bsr_col;
     const double *S, *Minv, *E;
     double *x, *r, *r1, *z, *p0, *p1, *q;   // r/r1 and p0/p1 alternate by iteration parity
-    double *rz, *pq, *scal;
+    double *rzp, *pqp, *rz_hist, *scal;     // rzp [2][ng] r.z partials, pqp [m] p.Sp partials, rz_hist [maxit+2]
     double tol;
-    int m, it;
+    int m, ng, it;                          // ng = ceil(m / 8) workgroups of k_pcg_init / k_pcg_update
 };
 
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
@@ -85,6 +87,8 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, int mcon, double mu
 void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal);
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // spmv + update for iteration a.it
+void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . z_it
+void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *out_sum, double *out_max);
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, double mu, const double *cam_a, const double *dA,
                        const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
                        double *cam_lin_new, double *scal);

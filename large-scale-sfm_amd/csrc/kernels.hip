@@ -371,12 +371,41 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
     }
     cost = wave_sum(cost); pl2 = wave_sum(pl2);
     ebinf = wave_max(ebinf); maxdv = wave_max(maxdv); sing = wave_max(sing);
-    if (lane == 0) {
-        gadd(&g.scal[SC_COST], cost);
-        gadd(&g.scal[SC_PL2_PTS], pl2);
-        atomic_max_pos(&g.scal[SC_EB_INF], ebinf);
-        atomic_max_pos(&g.scal[SC_MAXDIAG_V], maxdv);
-        if (sing != 0.0) atomic_max_pos(&g.scal[SC_SINGULAR], 1.0);
+    if (lane == 0) { // one partial row per tile; k_reduce_partials folds them (no same-address atomics)
+        double *pr = g.part + (size_t)tile * kPartW;
+        pr[0] = cost; pr[1] = pl2; pr[2] = 0.0; pr[3] = 0.0; pr[4] = ebinf; pr[5] = maxdv; pr[6] = sing; pr[7] = 0.0;
+    }
+}
+
+// folds per-workgroup partial rows: columns [0,4) are sums, [4,8) maxima.  One workgroup.
+__global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const double *__restrict__ part, double *__restrict__ out_sum,
+                                                        double *__restrict__ out_max)
+{
+    __shared__ double sh[16][kPartW];
+    double acc[kPartW];
+#pragma unroll
+    for (int c = 0; c < kPartW; ++c) acc[c] = 0.0;
+    for (int r = threadIdx.x; r < nrows; r += blockDim.x) {
+        const double *pr = part + (size_t)r * kPartW;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += pr[c];
+#pragma unroll
+        for (int c = 4; c < kPartW; ++c) acc[c] = fmax(acc[c], pr[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = wave_sum(acc[c]);
+#pragma unroll
+    for (int c = 4; c < kPartW; ++c) acc[c] = wave_max(acc[c]);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int c = 0; c < kPartW; ++c) sh[w][c] = acc[c];
+    __syncthreads();
+    if (threadIdx.x < kPartW) {
+        const int c = threadIdx.x, nw = blockDim.x >> 6;
+        double v = 0.0;
+        for (int k = 0; k < nw; ++k) v = (c < 4) ? v + sh[k][c] : fmax(v, sh[k][c]);
+        if (c < 4) out_sum[c] = v; else out_max[c - 4] = v;
     }
 }
 
@@ -486,15 +515,22 @@ __global__ __launch_bounds__(64) void k_block_inv(int m, const int *__restrict__
 //   rz[it] = r_it . z_it, pq[it] = p_it . S p_it live in HBM, one slot per iteration, so no kernel
 //   ever waits on the host; every workgroup takes the same converged/breakdown decision from them.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool pcg_done(const PcgArgs &a, int it)
+// sum of n partials, every lane of the wavefront gets the total
+__device__ __forceinline__ double wave_total(const double *__restrict__ v, int n, int lane)
 {
-    if (a.scal[SC_PCG_STATUS] != 0.0) return true;
-    const double rz0 = a.rz[0];
-    if (!(rz0 > 0.0)) return true;
-    return sqrt(fabs(a.rz[it]) / rz0) < a.tol;
+    double s = 0.0;
+    for (int i = lane; i < n; i += 64) s += v[i];
+    return wave_sum(s);
 }
 
-// 8 cameras per 64-lane group: lane = (camera, row)
+__device__ __forceinline__ bool pcg_converged(const PcgArgs &a, double rz_it)
+{
+    const double rz0 = a.rz_hist[0];
+    if (!(rz0 > 0.0)) return true;
+    return sqrt(fabs(rz_it) / rz0) < a.tol;
+}
+
+// 8 cameras per 64-lane group: lane = (camera, row).  Partial r.z per workgroup -> rzp[0][g].
 __global__ __launch_bounds__(64) void k_pcg_init(const PcgArgs a)
 {
     const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
@@ -509,18 +545,40 @@ __global__ __launch_bounds__(64) void k_pcg_init(const PcgArgs a)
         part = Ej[r] * zz;
     }
     part = wave_sum(part);
-    if (threadIdx.x == 0) gadd(&a.rz[0], part);
+    if (threadIdx.x == 0) a.rzp[blockIdx.x] = part;
+}
+
+// rz_hist[it] = sum of the r.z partials of iteration it, and the sticky converged flag; one wavefront.
+// Launched at the end of every chunk so the host sees the state AFTER the chunk's last update.
+__global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a)
+{
+    if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return;
+    const double rz = wave_total(a.rzp + (size_t)(a.it & 1) * a.ng, a.ng, threadIdx.x);
+    if (threadIdx.x == 0) {
+        a.rz_hist[a.it] = rz;
+        if (a.it == 0 ? !(rz > 0.0) : pcg_converged(a, rz)) a.scal[SC_PCG_DONE] = 1.0;
+    }
 }
 
 // one wavefront per block row: lane (r,c) multiplies element (r,c) of each 8x8 block (a 512-B
-// contiguous wave load), reduction over c by three xor-shuffles
+// contiguous wave load), reduction over c by three xor-shuffles.  No atomics: p.Sp goes out as one
+// partial per row, r.z comes in as one partial per k_pcg_update workgroup and is re-summed by every
+// wavefront in the same order (a few hundred L2-resident doubles), so every workgroup takes the
+// same converged / not converged decision; the decision is made sticky through SC_PCG_DONE.
 __global__ __launch_bounds__(64) void k_pcg_spmv(const PcgArgs a)
 {
-    if (pcg_done(a, a.it)) return;
     const int j = blockIdx.x, lane = threadIdx.x, r = lane >> 3, c = lane & 7;
+    if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return;
+    const double rz = wave_total(a.rzp + (size_t)(a.it & 1) * a.ng, a.ng, lane);
+    if (j == 0 && lane == 0) a.rz_hist[a.it] = rz;
+    // rz_hist[0] is written by this very launch when it == 0; use the local value then
+    if (a.it == 0 ? !(rz > 0.0) : pcg_converged(a, rz)) {
+        if (j == 0 && lane == 0) a.scal[SC_PCG_DONE] = 1.0;
+        return;
+    }
     const double *pprev = (a.it & 1) ? a.p0 : a.p1;   // p_{it-1}
     double *pcur = (a.it & 1) ? a.p1 : a.p0;          // p_it (it = 0: p0 = z, written by k_pcg_init)
-    const double beta = a.it ? a.rz[a.it] / a.rz[a.it - 1] : 0.0;
+    const double beta = a.it ? rz / a.rz_hist[a.it - 1] : 0.0;
     double acc = 0.0;
     for (int q = a.bsr_row[j]; q < a.bsr_row[j + 1]; ++q) {
         const int k = a.bsr_col[q];
@@ -537,18 +595,21 @@ __global__ __launch_bounds__(64) void k_pcg_spmv(const PcgArgs a)
         part = acc * pj;
     }
     part = wave_sum(part);
-    if (lane == 0) gadd(&a.pq[a.it], part);
+    if (lane == 0) a.pqp[j] = part;
 }
 
 __global__ __launch_bounds__(64) void k_pcg_update(const PcgArgs a)
 {
-    if (pcg_done(a, a.it)) return;
-    const double pq = a.pq[a.it];
+    if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return; // DONE: set by k_pcg_spmv(it), a launch ago
+    const double rz = a.rz_hist[a.it];
+    const double pq = wave_total(a.pqp, a.m, threadIdx.x);
     if (!(pq > 0.0) || !isfinite(pq)) { // S not positive definite along p: "not solved" (dpotrf info > 0)
         if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[SC_PCG_STATUS] = 2.0;
+        // the partial of the next iteration must still be defined
+        if (threadIdx.x == 0) a.rzp[(size_t)((a.it + 1) & 1) * a.ng + blockIdx.x] = 0.0;
         return;
     }
-    const double alpha = a.rz[a.it] / pq;
+    const double alpha = rz / pq;
     const double *pcur = (a.it & 1) ? a.p1 : a.p0;
     const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
     double part = 0.0;
@@ -573,7 +634,7 @@ __global__ __launch_bounds__(64) void k_pcg_update(const PcgArgs a)
     }
     part = wave_sum(part);
     if (threadIdx.x == 0) {
-        gadd(&a.rz[a.it + 1], part);
+        a.rzp[(size_t)((a.it + 1) & 1) * a.ng + blockIdx.x] = part;
         if (blockIdx.x == 0) a.scal[SC_PCG_ITERS] = (double)(a.it + 1);
     }
 }
@@ -614,66 +675,67 @@ template <int CNP>
 __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
 {
     __shared__ double sT[kWave * 3], sX[kWave * 3];
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const ModelCfg cfg = g.cfg;
-    const int o0 = g.batch_obs[b], nob = g.batch_obs[b + 1] - o0;
-    const int p0 = g.batch_pt[b], npt = g.batch_pt[b + 1] - p0;
-    const bool active = lane < nob;
-    double e[2] = { 0.0, 0.0 };
-    int j = 0, lp = 0;
-    double2 xy = make_double2(0.0, 0.0);
-    if (active) {
-        const int o = o0 + lane;
-        j = g.obs_cam[o];
-        const int ip = g.obs_pt[o];
-        lp = ip - p0;
-        xy = g.obs_xy[o];
-        const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
-        double A[2][CNP], B[2][3];
-        linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, j < cfg.mcon, e, A, B);
-        double w0 = 0.0, w1 = 0.0;
+    double cn = 0.0, pct = 0.0, dl = 0.0, dp2 = 0.0;
+    for (int b = blockIdx.x; b < g.nbatch; b += gridDim.x) {
+        const int o0 = g.batch_obs[b], nob = g.batch_obs[b + 1] - o0;
+        const int p0 = g.batch_pt[b], npt = g.batch_pt[b + 1] - p0;
+        const bool active = lane < nob;
+        double e[2] = { 0.0, 0.0 };
+        int j = 0, lp = 0;
+        double2 xy = make_double2(0.0, 0.0);
+        if (active) {
+            const int o = o0 + lane;
+            j = g.obs_cam[o];
+            const int ip = g.obs_pt[o];
+            lp = ip - p0;
+            xy = g.obs_xy[o];
+            const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
+            double A[2][CNP], B[2][3];
+            linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, j < cfg.mcon, e, A, B);
+            double w0 = 0.0, w1 = 0.0;
 #pragma unroll
-        for (int t = 0; t < CNP; ++t) { const double d = g.dA[j * kCP + t]; w0 += A[0][t] * d; w1 += A[1][t] * d; }
+            for (int t = 0; t < CNP; ++t) { const double d = g.dA[j * kCP + t]; w0 += A[0][t] * d; w1 += A[1][t] * d; }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) sT[lane * 3 + t] = B[0][t] * w0 + B[1][t] * w1;
-    }
-    __syncthreads();
-    double dl = 0.0, dp2 = 0.0;
-    if (lane < npt) {
-        const int ip = p0 + lane;
-        const int os = g.pt_obs[ip] - o0, oe = g.pt_obs[ip + 1] - o0;
-        double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-        for (int o = os; o < oe; ++o) { t0 += sT[o * 3]; t1 += sT[o * 3 + 1]; t2 += sT[o * 3 + 2]; }
-        const double *po = g.ptout + (size_t)ip * kPtOut;
-        const double d0 = po[6] - (po[0] * t0 + po[1] * t1 + po[2] * t2);
-        const double d1 = po[7] - (po[1] * t0 + po[3] * t1 + po[4] * t2);
-        const double d2 = po[8] - (po[2] * t0 + po[4] * t1 + po[5] * t2);
-        const double X0 = g.pts[3 * (size_t)ip] + d0, X1 = g.pts[3 * (size_t)ip + 1] + d1, X2 = g.pts[3 * (size_t)ip + 2] + d2;
-        g.pts_new[3 * (size_t)ip] = X0; g.pts_new[3 * (size_t)ip + 1] = X1; g.pts_new[3 * (size_t)ip + 2] = X2;
-        if (g.dB) { g.dB[3 * (size_t)ip] = d0; g.dB[3 * (size_t)ip + 1] = d1; g.dB[3 * (size_t)ip + 2] = d2; }
-        sX[lane * 3] = X0; sX[lane * 3 + 1] = X1; sX[lane * 3 + 2] = X2;
-        dl = d0 * (g.mu * d0 + po[9]) + d1 * (g.mu * d1 + po[10]) + d2 * (g.mu * d2 + po[11]);
-        dp2 = d0 * d0 + d1 * d1 + d2 * d2;
-    }
-    __syncthreads();
-    double cn = 0.0, pct = 0.0;
-    if (active) {
-        const double Xn[3] = { sX[lp * 3], sX[lp * 3 + 1], sX[lp * 3 + 2] };
-        double u, v;
-        project_obs(cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, u, v);
-        const double en0 = xy.x - u, en1 = xy.y - v;
-        cn = en0 * en0 + en1 * en1;
-        // QUIRK kept from sba_levmar.c:1554: signed comparison against eps5
-        if (!(e[0] < g.eps5 && en0 < g.eps5)) pct = fmax(pct, fabs((e[0] - en0) / e[0]));
-        if (!(e[1] < g.eps5 && en1 < g.eps5)) pct = fmax(pct, fabs((e[1] - en1) / e[1]));
-        if (!(pct == pct)) pct = 0.0; // 0/0 when both residuals vanish
+            for (int t = 0; t < 3; ++t) sT[lane * 3 + t] = B[0][t] * w0 + B[1][t] * w1;
+        }
+        __syncthreads();
+        if (lane < npt) {
+            const int ip = p0 + lane;
+            const int os = g.pt_obs[ip] - o0, oe = g.pt_obs[ip + 1] - o0;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+            for (int o = os; o < oe; ++o) { t0 += sT[o * 3]; t1 += sT[o * 3 + 1]; t2 += sT[o * 3 + 2]; }
+            const double *po = g.ptout + (size_t)ip * kPtOut;
+            const double d0 = po[6] - (po[0] * t0 + po[1] * t1 + po[2] * t2);
+            const double d1 = po[7] - (po[1] * t0 + po[3] * t1 + po[4] * t2);
+            const double d2 = po[8] - (po[2] * t0 + po[4] * t1 + po[5] * t2);
+            const double X0 = g.pts[3 * (size_t)ip] + d0, X1 = g.pts[3 * (size_t)ip + 1] + d1, X2 = g.pts[3 * (size_t)ip + 2] + d2;
+            g.pts_new[3 * (size_t)ip] = X0; g.pts_new[3 * (size_t)ip + 1] = X1; g.pts_new[3 * (size_t)ip + 2] = X2;
+            if (g.dB) { g.dB[3 * (size_t)ip] = d0; g.dB[3 * (size_t)ip + 1] = d1; g.dB[3 * (size_t)ip + 2] = d2; }
+            sX[lane * 3] = X0; sX[lane * 3 + 1] = X1; sX[lane * 3 + 2] = X2;
+            dl += d0 * (g.mu * d0 + po[9]) + d1 * (g.mu * d1 + po[10]) + d2 * (g.mu * d2 + po[11]);
+            dp2 += d0 * d0 + d1 * d1 + d2 * d2;
+        }
+        __syncthreads();
+        if (active) {
+            const double Xn[3] = { sX[lp * 3], sX[lp * 3 + 1], sX[lp * 3 + 2] };
+            double u, v;
+            project_obs(cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, u, v);
+            const double en0 = xy.x - u, en1 = xy.y - v;
+            cn += en0 * en0 + en1 * en1;
+            // QUIRK kept from sba_levmar.c:1554: signed comparison against eps5
+            double pc = 0.0;
+            if (!(e[0] < g.eps5 && en0 < g.eps5)) pc = fmax(pc, fabs((e[0] - en0) / e[0]));
+            if (!(e[1] < g.eps5 && en1 < g.eps5)) pc = fmax(pc, fabs((e[1] - en1) / e[1]));
+            if (pc == pc) pct = fmax(pct, pc); // skip 0/0 when both residuals vanish
+        }
+        __syncthreads();
     }
     cn = wave_sum(cn); dl = wave_sum(dl); dp2 = wave_sum(dp2); pct = wave_max(pct);
     if (lane == 0) {
-        gadd(&g.scal[SC_COST_NEW], cn);
-        gadd(&g.scal[SC_DL_PTS], dl);
-        gadd(&g.scal[SC_DP2_PTS], dp2);
-        atomic_max_pos(&g.scal[SC_MAX_PCT], pct);
+        double *pr = g.part + (size_t)blockIdx.x * kPartW;
+        pr[0] = cn; pr[1] = dl; pr[2] = dp2; pr[3] = 0.0; pr[4] = pct; pr[5] = 0.0; pr[6] = 0.0; pr[7] = 0.0;
     }
 }
 
@@ -721,13 +783,20 @@ void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *
 
 void launch_pcg_init(hipStream_t st, const PcgArgs &a)
 {
-    hipLaunchKernelGGL(k_pcg_init, dim3((a.m + 7) / 8), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_pcg_init, dim3(a.ng), dim3(64), 0, st, a);
 }
 
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
 {
     hipLaunchKernelGGL(k_pcg_spmv, dim3(a.m), dim3(64), 0, st, a);
-    hipLaunchKernelGGL(k_pcg_update, dim3((a.m + 7) / 8), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_pcg_update, dim3(a.ng), dim3(64), 0, st, a);
+}
+
+void launch_pcg_tail(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_tail, dim3(1), dim3(64), 0, st, a); }
+
+void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *out_sum, double *out_max)
+{
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, st, nrows, part, out_sum, out_max);
 }
 
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, double mu, const double *cam_a, const double *dA,
@@ -741,8 +810,8 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, doub
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
 {
     if (a.nbatch <= 0) return;
-    if (cnp == 7) hipLaunchKernelGGL((k_backsub<7>), dim3(a.nbatch), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_backsub<6>), dim3(a.nbatch), dim3(64), 0, st, a);
+    if (cnp == 7) hipLaunchKernelGGL((k_backsub<7>), dim3(a.ngrid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_backsub<6>), dim3(a.ngrid), dim3(64), 0, st, a);
 }
 
 void launch_rotations(hipStream_t st, int m, const double *cam_lin, double *R)
