@@ -184,23 +184,25 @@ __global__ void k_cam_prep(int m, int cnp, ModelCfg cfg, const double *__restric
 //            -> LDS                                     [sba_levmar.c:856, 919-1030]
 //   phase 2  lane = (point, component): V_i (6 upper), eb_i (3) summed from LDS
 //   phase 3  lane = point: V*_i = V_i + mu I, closed-form inverse, h_i = V*^-1 eb_i  [:1138-1162]
-//   phase 4  lane = observation: G = B V*^-1; ea_j, E_j = A^T (e - B h_i), diag U_j  [:1322-1338]
+//   phase 4  lane = observation: ea_j, E_j = A^T (e - B h_i), diag U_j               [:1322-1338]
 //   phase 5  lane = observation PAIR (a <= b) of one point:
-//               block(j_a, j_b) += A_a^T (delta_ab I - G_a B_b^T) A_b
+//               block(j_a, j_b) += A_a^T (delta_ab I - G_a B_b^T) A_b,   G_a = B_a V*^-1
 //            which is delta_ab U - Y_ij W_ik^T of sba_levmar.c:1182-1301 written through the
 //            2 x 2 matrix G_a B_b^T (measurements are 2-vectors, so every block has rank <= 2
 //            and W_ij = A^T B never has to be formed or stored).
-//   LDS mode:  blocks accumulate into a per-tile LDS table (ds_add_f64), flushed once per tile
-//              as 49-lane contiguous f64 atomics (one S block = one wave instruction).
+//   LDS mode:  pair entries come in rounds of 64 (plan.h); a lane keeps "its" CNP x CNP block in
+//              registers for as long as consecutive rounds give it the same block and spills it
+//              into the tile's LDS table (ds_add_f64) only when the block changes; the table is
+//              flushed once per tile as contiguous f64 atomics (one S block = one wave instruction).
 //   direct mode (points with > kMaxViewsLds views): every pair adds straight into HBM.
 // ------------------------------------------------------------------------------------------
 template <int CNP, bool LDS>
 __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
 {
     constexpr int SA = 2 * CNP + 1;           // odd strides (in doubles) keep ds_read_b64 conflict-free
-    constexpr int SB = 7, SE = 3, SV = 9;
+    constexpr int SB = 9, SV = 9;             // sB row: B (6), e (2), local point index (1)
     constexpr int BLK = CNP * CNP, SS = BLK | 1, SC = (3 * CNP) | 1;
-    __shared__ double sA[kWave * SA], sB[kWave * SB], sG[kWave * SB], sE[kWave * SE], sV[kWave * SV];
+    __shared__ double sA[kWave * SA], sB[kWave * SB], sV[kMaxPtsBatch * SV];
     __shared__ double sS[LDS ? kNSlot * SS : 1], sC[LDS ? kNCSlot * SC : 1];
 
     const int lane = threadIdx.x;
@@ -214,6 +216,12 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         for (int i = lane; i < ncs * SC; i += kWave) sC[i] = 0.0;
     }
     double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0;
+    double acc[LDS ? BLK : 1];                // this lane's register-resident block (LDS mode)
+    int cur_slot = -1;
+    if constexpr (LDS) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
+    }
 
     for (int b = g.tile_batch[tile]; b < g.tile_batch[tile + 1]; ++b) {
         const int o0 = g.batch_obs[b], nob = g.batch_obs[b + 1] - o0;
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
             for (int t = 0; t < CNP; ++t) { sA[lane * SA + t] = A[0][t]; sA[lane * SA + CNP + t] = A[1][t]; }
 #pragma unroll
             for (int t = 0; t < 3; ++t) { sB[lane * SB + t] = B[0][t]; sB[lane * SB + 3 + t] = B[1][t]; }
-            sE[lane * SE] = e[0]; sE[lane * SE + 1] = e[1];
+            sB[lane * SB + 6] = e[0]; sB[lane * SB + 7] = e[1]; sB[lane * SB + 8] = (double)lp;
         }
         __syncthreads();
         // ---- phase 2: V_i upper triangle (00 01 02 11 12 22) and eb_i, 7 points per sweep
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
                         sum += sB[o * SB + r] * sB[o * SB + c] + sB[o * SB + 3 + r] * sB[o * SB + 3 + c];
                 } else {
                     const int r = comp - 6;
-                    for (int o = os; o < oe; ++o) sum += sB[o * SB + r] * sE[o * SE] + sB[o * SB + 3 + r] * sE[o * SE + 1];
+                    for (int o = os; o < oe; ++o) sum += sB[o * SB + r] * sB[o * SB + 6] + sB[o * SB + 3 + r] * sB[o * SB + 7];
                 }
                 sV[lpp * SV + comp] = sum;
             }
@@ -287,44 +295,45 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
             po[6] = h0; po[7] = h1; po[8] = h2; po[9] = eb0; po[10] = eb1; po[11] = eb2;
         }
         __syncthreads();
-        // ---- phase 4: G = B V*^-1 and the camera-side vectors
-        if (active) {
+        // ---- phase 4: camera-side vectors
+        if (active && j >= cfg.mcon) {
             const double *sv = sV + lp * SV;
-            const double i00 = sv[0], i01 = sv[1], i02 = sv[2], i11 = sv[3], i12 = sv[4], i22 = sv[5];
             double er[2];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                sG[lane * SB + 3 * r] = B[r][0] * i00 + B[r][1] * i01 + B[r][2] * i02;
-                sG[lane * SB + 3 * r + 1] = B[r][0] * i01 + B[r][1] * i11 + B[r][2] * i12;
-                sG[lane * SB + 3 * r + 2] = B[r][0] * i02 + B[r][1] * i12 + B[r][2] * i22;
-                er[r] = e[r] - (B[r][0] * sv[6] + B[r][1] * sv[7] + B[r][2] * sv[8]);
-            }
-            if (j >= cfg.mcon) {
+            for (int r = 0; r < 2; ++r) er[r] = e[r] - (B[r][0] * sv[6] + B[r][1] * sv[7] + B[r][2] * sv[8]);
 #pragma unroll
-                for (int t = 0; t < CNP; ++t) {
-                    const double vea = A[0][t] * e[0] + A[1][t] * e[1];
-                    const double vE = A[0][t] * er[0] + A[1][t] * er[1];
-                    const double vdu = A[0][t] * A[0][t] + A[1][t] * A[1][t];
-                    if constexpr (LDS) {
-                        ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE); ladd(&sC[cs * SC + 2 * CNP + t], vdu);
-                    } else {
-                        gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], vea);
-                        gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], vE);
-                        gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], vdu);
-                    }
+            for (int t = 0; t < CNP; ++t) {
+                const double vea = A[0][t] * e[0] + A[1][t] * e[1];
+                const double vE = A[0][t] * er[0] + A[1][t] * er[1];
+                const double vdu = A[0][t] * A[0][t] + A[1][t] * A[1][t];
+                if constexpr (LDS) {
+                    ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE); ladd(&sC[cs * SC + 2 * CNP + t], vdu);
+                } else {
+                    gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], vea);
+                    gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], vE);
+                    gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], vdu);
                 }
             }
         }
-        __syncthreads();
-        // ---- phase 5: pair products
+        // ---- phase 5: pair products (reads sA, sB, sV only: no barrier needed after phase 4)
         for (long long q = g.batch_pair[b] + lane; q < g.batch_pair[b + 1]; q += kWave) {
             const unsigned ent = g.pair[q];
+            if (LDS && ent == kPairInvalid) continue;
             const int la = ent & 63, lb = (ent >> 6) & 63;
-            const double *Ga = sG + la * SB, *Bb = sB + lb * SB;
-            double M00 = Ga[0] * Bb[0] + Ga[1] * Bb[1] + Ga[2] * Bb[2];
-            double M01 = Ga[0] * Bb[3] + Ga[1] * Bb[4] + Ga[2] * Bb[5];
-            double M10 = Ga[3] * Bb[0] + Ga[4] * Bb[1] + Ga[5] * Bb[2];
-            double M11 = Ga[3] * Bb[3] + Ga[4] * Bb[4] + Ga[5] * Bb[5];
+            const double *Ba = sB + la * SB, *Bb = sB + lb * SB;
+            const double *sv = sV + (int)Ba[8] * SV;
+            const double i00 = sv[0], i01 = sv[1], i02 = sv[2], i11 = sv[3], i12 = sv[4], i22 = sv[5];
+            double G[2][3];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                G[r][0] = Ba[3 * r] * i00 + Ba[3 * r + 1] * i01 + Ba[3 * r + 2] * i02;
+                G[r][1] = Ba[3 * r] * i01 + Ba[3 * r + 1] * i11 + Ba[3 * r + 2] * i12;
+                G[r][2] = Ba[3 * r] * i02 + Ba[3 * r + 1] * i12 + Ba[3 * r + 2] * i22;
+            }
+            double M00 = G[0][0] * Bb[0] + G[0][1] * Bb[1] + G[0][2] * Bb[2];
+            double M01 = G[0][0] * Bb[3] + G[0][1] * Bb[4] + G[0][2] * Bb[5];
+            double M10 = G[1][0] * Bb[0] + G[1][1] * Bb[1] + G[1][2] * Bb[2];
+            double M11 = G[1][0] * Bb[3] + G[1][1] * Bb[4] + G[1][2] * Bb[5];
             const double dg = (la == lb) ? 1.0 : 0.0;
             M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
             double T0[CNP], T1[CNP];
@@ -336,12 +345,20 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
                 T1[c] = M10 * a0 + M11 * a1;
             }
             if constexpr (LDS) {
-                double *dst = sS + (ent >> 12) * SS;
+                const int slot = (int)(ent >> 12);
+                if (slot != cur_slot) { // this lane's block changed: spill the finished one
+                    if (cur_slot >= 0) {
+                        double *dst = sS + cur_slot * SS;
+#pragma unroll
+                        for (int i = 0; i < BLK; ++i) { ladd(&dst[i], acc[i]); acc[i] = 0.0; }
+                    }
+                    cur_slot = slot;
+                }
 #pragma unroll
                 for (int r = 0; r < CNP; ++r) {
                     const double a0 = Aa[r], a1 = Aa[CNP + r];
 #pragma unroll
-                    for (int c = 0; c < CNP; ++c) ladd(&dst[r * CNP + c], a0 * T0[c] + a1 * T1[c]);
+                    for (int c = 0; c < CNP; ++c) acc[r * CNP + c] += a0 * T0[c] + a1 * T1[c];
                 }
             } else {
                 double *dst = g.S_up + (size_t)g.pair_gblk[q - g.pair_gblk_base] * (kCP * kCP);
@@ -355,8 +372,14 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         }
         __syncthreads();
     }
-    // ---- flush the tile's accumulators: one S block = one contiguous f64 atomic wave instruction
+    // ---- flush: registers -> LDS table -> HBM (one S block = one contiguous f64 atomic wave instruction)
     if constexpr (LDS) {
+        if (cur_slot >= 0) {
+            double *dst = sS + cur_slot * SS;
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) ladd(&dst[i], acc[i]);
+        }
+        __syncthreads();
         const int s0 = g.tile_slot[tile], c0 = g.tile_cslot[tile];
         if (lane < BLK) {
             const int r = lane / CNP, c = lane - r * CNP;

@@ -198,12 +198,22 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     int cur_obs = 0, batches_in_tile = 0;
     int t = 0;
 
+    std::vector<uint32_t> round_buf;  // pair entries of the round being filled (LDS tiles)
+    bool rounds_mode = true;
+    int pts_in_batch = 0;
+    auto flush_round = [&]() {
+        if (round_buf.empty()) return;
+        round_buf.resize(kWave, kPairInvalid);
+        pl.pair.insert(pl.pair.end(), round_buf.begin(), round_buf.end());
+        round_buf.clear();
+    };
     auto close_batch = [&](int t_end) {
         if (cur_obs == 0) return;
+        if (rounds_mode) flush_round();
         pl.batch_obs.push_back(pl.pt_obs[t_end]);
         pl.batch_pt.push_back(t_end);
         pl.batch_pair.push_back((int64_t)pl.pair.size());
-        cur_obs = 0;
+        cur_obs = 0; pts_in_batch = 0;
         batches_in_tile++;
     };
     auto close_tile = [&](uint8_t mode) {
@@ -223,7 +233,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         if (point_class(d) != 0) break;
         const int *c = pl.obs_cam.data() + pl.pt_obs[t];
         bool same_sig = (d == sig_d && sig_cams && std::memcmp(sig_cams, c, sizeof(int) * d) == 0);
-        if (cur_obs + d > kWave) {
+        if (cur_obs + d > kWave || pts_in_batch >= kMaxPtsBatch) {
             close_batch(t);
             if (batches_in_tile >= tile_max_batches) { close_tile(1); same_sig = false; }
         }
@@ -260,13 +270,14 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             }
             sig_cams = c; sig_d = d;
         }
+        if ((int)round_buf.size() + d * (d + 1) / 2 > kWave) flush_round();
         int q = 0;
         for (int a = 0; a < d; ++a) {
             pl.obs_cslot[pl.pt_obs[t] + a] = (uint8_t)cmap[c[a]];
             for (int b = a; b < d; ++b)
-                pl.pair.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6) | ((uint32_t)sig_slots[q++] << 12));
+                round_buf.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6) | ((uint32_t)sig_slots[q++] << 12));
         }
-        cur_obs += d;
+        cur_obs += d; pts_in_batch++;
     }
     close_batch(t);
     close_tile(1);
@@ -274,12 +285,13 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     pl.ntile_lds = pl.ntile();
     pl.nbatch_lds = pl.nbatch();
 
-    // class 1: direct tiles (pairs add straight into S with global atomics)
+    // class 1: direct tiles (pairs add straight into S with global atomics); dense pair list
+    rounds_mode = false;
     for (; t < npl; ++t) {
         int d = pl.pt_obs[t + 1] - pl.pt_obs[t];
         if (point_class(d) != 1) break;
         const int *c = pl.obs_cam.data() + pl.pt_obs[t];
-        if (cur_obs + d > kWave) {
+        if (cur_obs + d > kWave || pts_in_batch >= kMaxPtsBatch) {
             close_batch(t);
             if (batches_in_tile >= tile_max_batches) close_tile(0);
         }
@@ -290,7 +302,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                 pl.pair.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6));
                 pl.pair_gblk.push_back((uint32_t)g);
             }
-        cur_obs += d;
+        cur_obs += d; pts_in_batch++;
     }
     close_batch(t);
     close_tile(0);

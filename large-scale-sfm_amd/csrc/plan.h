@@ -9,7 +9,11 @@
 //   * a BATCH is <= 64 observations of whole points: one wavefront, one lane per observation;
 //   * a TILE is a run of batches whose distinct S blocks fit an LDS accumulator table
 //     (NSLOT blocks) and whose distinct cameras fit NCSLOT vectors; the tile is one workgroup;
-//   * every (a <= b) observation pair of a point is a PAIR entry (lane-local indices + slot);
+//   * every (a <= b) observation pair of a point is a PAIR entry (lane-local indices + slot).
+//     In LDS tiles the entries come in ROUNDS of exactly 64 (one per lane, padded with
+//     kPairInvalid): a round holds whole points, and points with the same camera set put the
+//     same block on the same lane round after round, so k_build keeps that block in registers
+//     and touches the LDS accumulator only when the lane's block changes;
 //   * S = U* - W V*^-1 W^T is block sparse by co-visibility: upper pattern + full BSR pattern.
 #pragma once
 #include <cstdint>
@@ -19,8 +23,10 @@
 namespace miba {
 
 constexpr int kWave = 64;        // observations per batch
-constexpr int kNSlot = 56;       // S-block accumulators per LDS tile (>= 55 = pairs of a 10-view point)
-constexpr int kNCSlot = 32;      // camera accumulators per LDS tile
+constexpr int kNSlot = 55;       // S-block accumulators per LDS tile (55 = pairs of a 10-view point)
+constexpr int kNCSlot = 24;      // camera accumulators per LDS tile
+constexpr int kMaxPtsBatch = 32; // points per batch (bounds the per-point LDS staging)
+constexpr uint32_t kPairInvalid = 0xFFFFFFFFu; // padding entry of a pair round
 constexpr int kMaxViewsLds = 10; // d(d+1)/2 <= kNSlot
 constexpr int kCP = 8;           // padded camera block dimension (cnp <= 8)
 
