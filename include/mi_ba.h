@@ -75,6 +75,9 @@ int mi_ba_cnp(const mi_ba_engine *e);
  *      (pba.h:96-101).  Host arrays are copied; the caller keeps ownership. ------------------- */
 int mi_ba_set_cameras(mi_ba_engine *e, int m, const double *a0 /* m*cnp */, const double *R0 /* m*9 */,
                       const double *f_fixed /* m, used when !est_focal; may be NULL otherwise */);
+/* optional: cameras held constant beyond the leading mcon (CameraT::constant_camera, DataInterface.h:72);
+ * mask[j] != 0 fixes camera j; NULL clears.  Call after mi_ba_set_cameras. */
+int mi_ba_set_fixed_cameras(mi_ba_engine *e, const unsigned char *mask /* m */);
 int mi_ba_set_points(mi_ba_engine *e, int n, const double *xyz /* n*3 */);
 /* observations sorted by point (pt_idx non-decreasing, like pba's driver.cpp:158-161 requires) */
 int mi_ba_set_observations(mi_ba_engine *e, int64_t nobs, const double *xy /* nobs*2 */,

@@ -1,0 +1,52 @@
+/*
+ * mi_model.h -- reconstruction files of the optimizer's process boundary, and the end-to-end
+ * "load -> bundle adjust on the MI355X -> save" call the optimizer_all executable makes.
+ *
+ * Formats (reference Optimizer/util_VSFM.h):
+ *   NVM   "NVM_V3_R9T": per camera  name f R[9 row-major] t[3] d0 d1 ; per point
+ *         X Y Z r g b nview {camIdx featId x y}*       LoadNVM :139-215, SaveNVM :218-258, written by
+ *         the pipeline's stage programs (SiftGPU/MergeClusters.cpp:520-551).  "NVM_V3" (quaternion +
+ *         camera centre) is read as LoadNVM does (:170-175).
+ *   BAL   "bundler model" text: ncam npt nobs / cam pt x y / 9 numbers per camera (w3 t3 f k1 k2) /
+ *         X Y Z                                           LoadBundlerModel :448-501, SaveBundlerModel :503-529
+ *         (-z camera -> +z: y negated on load, rows 2,3 of R and t2,t3 negated = SetInvertedRT)
+ * Camera convention in memory (DataInterface.h:50-52): x^ = f (R X + t).xy / (R X + t).z.
+ */
+#ifndef MI_MODEL_H
+#define MI_MODEL_H
+#include <stdint.h>
+#include "mi_ba.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_model mi_model;
+
+mi_model *mi_model_load_nvm(const char *path);     /* NULL on failure, reason in mi_model_last_error() */
+mi_model *mi_model_load_bal(const char *path);
+int mi_model_save_nvm(const mi_model *mdl, const char *path);
+int mi_model_save_bal(const mi_model *mdl, const char *path);
+void mi_model_free(mi_model *mdl);
+const char *mi_model_last_error(void);
+
+/* counts[0..2] = cameras, points, projections */
+int mi_model_counts(const mi_model *mdl, int64_t counts[3]);
+/* copies out; any pointer may be NULL.  f ncam, R ncam*9, t ncam*3, d ncam*2, xyz npt*3, rgb npt*3,
+ * xy nproj*2, pt_idx / cam_idx nproj, feat_id nproj */
+int mi_model_get(const mi_model *mdl, double *f, double *R, double *t, double *d, double *xyz, int *rgb,
+                 double *xy, int *pt_idx, int *cam_idx, int64_t *feat_id);
+
+/* bundle adjust in place.  cfg: only itmax, opts, pcg_*, est_focal, mcon, device, verbose are read (the
+ * camera convention of the file fixes the rest).  Returns LM iterations or MI_BA_ERROR. */
+int mi_model_optimize(mi_model *mdl, const mi_ba_config *cfg, double info[MI_BA_INFOSZ]);
+/* sqrt(sum ||x - x^||^2 / nproj) in pixels with the cameras/points currently in the model (host) */
+double mi_model_rmse(const mi_model *mdl);
+
+/* the process ABI:  optimizer_all <dir>/ A B C D E F   (SiftGPU/MergeClusters.cpp:1099-1110).
+ * Reads <dir>/outputVSFM_GB.nvm, refines, overwrites it.  Returns the process exit status. */
+int mi_optimizer_all_main(int argc, char **argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,86 @@
+/*
+ * mi_pba.h -- the reference's C++ plugin interface over the MI355X engine.
+ *
+ * Same class name, method names, argument meaning and order of virtuals as the reference's
+ * Optimizer/pba/src/pba/pba.h:52-133 (class ParallelBA, NewParallelBA, ParallelBA_GetVersion), so a
+ * caller of that interface recompiles against this header and links libmi_ba.so instead of libpba
+ * (INTEGRATION.md).  What runs underneath is NOT PBA's algorithm but the engine of mi_ba.h: the
+ * reference sba-1.5 Levenberg-Marquardt (additive damping, gain-ratio update) with the reduced
+ * camera system solved by block-Jacobi PCG on the GPU.
+ *
+ * Ownership and error behaviour follow the reference (SparseBundleCPU.cpp:2541-2590, 2660-2674):
+ * the caller owns every array, SetCameraData / SetPointData keep the raw pointers and
+ * RunBundleAdjustment() writes the result back into them in place; measurement and index arrays
+ * are const; no exceptions; invalid input -> RunBundleAdjustment() returns 0 and
+ * GetInternalConfig()->GetBundleReturnCode() tells why.
+ */
+#ifndef MI_PBA_H
+#define MI_PBA_H
+#include <cstddef>
+#include "mi_data_interface.h"
+
+/* the slice of the reference's ConfigBA (ConfigBA.h:27-202) that callers of the plugin touch */
+class ConfigBA {
+public:
+    int __lm_max_iteration;         /* ConfigBA.h "-lmi": LM iteration cap (engine itmax)              */
+    int __cg_max_iteration;         /* "-cgi": PCG iteration cap                                        */
+    float __cg_norm_threshold;      /* "-cgn": PCG stop, sqrt(r'z/r0'z0)                                */
+    bool __fixed_intrinsics;        /* SetFixedIntrinsics                                               */
+    int __use_radial_distortion;    /* EnableRadialDistortion: only 0 is supported this round           */
+    int __verbose_level;
+    int __selected_device;
+    char __bundle_return_code;      /* 'E' numeric error, 'S' small step, 'G' small gradient, 'M' itmax, 0 */
+    int __num_lm_success, __num_lm_iteration;
+    float __initial_mse, __final_mse;
+    ConfigBA();
+    char GetBundleReturnCode() const { return __bundle_return_code; }
+    const char *GetOutputParam() const { return __output_param; }
+    void ParseParam(int argc, char **argv);
+private:
+    char __output_param[1024];
+};
+
+class ParallelBA {
+public:
+    enum StatusT { STATUS_SUCCESS = 0, STATUS_CAMERA_MISSING = 1, STATUS_POINT_MISSING, STATUS_PROJECTION_MISSING,
+                   STATUS_MEASURMENT_MISSING, STATUS_ALLOCATION_FAIL };
+    /* pba.h:65-72; every value >= PBA_CUDA_DEVICE_DEFAULT selects an MI355X (there is no CPU back end) */
+    enum DeviceT { PBA_INVALID_DEVICE = -4, PBA_CPU_DOUBLE = -3, PBA_CPU_FLOAT = -2, PBA_CUDA_DEVICE_DEFAULT = -1,
+                   PBA_CUDA_DEVICE0 = 0 };
+    enum DistortionT { PBA_MEASUREMENT_DISTORTION = -1, PBA_NO_DISTORTION = 0, PBA_PROJECTION_DISTORTION = 1 };
+    enum BundleModeT { BUNDLE_FULL = 0, BUNDLE_ONLY_MOTION = 1, BUNDLE_ONLY_STRUCTURE = 2 };
+
+private:
+    struct Impl;
+    Impl *_optimizer;   /* same single data member as the reference (pba.h:86), so sizeof agrees */
+
+public:
+    /* order of virtuals = pba.h:90-124 */
+    virtual void ParseParam(int narg, char **argv);
+    virtual ConfigBA *GetInternalConfig();
+    virtual void SetFixedIntrinsics(bool fixed);
+    virtual void EnableRadialDistortion(DistortionT type);
+    virtual void SetNextTimeBudget(int seconds);
+    virtual void ReserveStorage(size_t ncam, size_t npt, size_t nproj);
+    inline void SetFocalLengthFixed(bool fixed) { SetFixedIntrinsics(fixed); }
+    inline void ResetBundleStorage() { ReserveStorage(0, 0, 0); }
+    virtual void SetCameraData(size_t ncam, CameraT *cams);
+    virtual void SetPointData(size_t npoint, Point3D *pts);
+    virtual void SetProjection(size_t nproj, const Point2D *imgpts, const int *point_idx, const int *cam_idx);
+    virtual void SetNextBundleMode(BundleModeT mode = BUNDLE_FULL);
+    virtual int RunBundleAdjustment();          /* number of successful LM iterations */
+    virtual float GetMeanSquaredError();
+    virtual void AbortBundleAdjustment();
+    virtual int GetCurrentIteration();
+    ParallelBA(DeviceT device = PBA_CUDA_DEVICE_DEFAULT);
+    void *operator new(size_t size);           /* malloc, so delete is safe across the DSO (pba.cpp:134-144) */
+    void operator delete(void *p);
+    virtual ~ParallelBA();
+    virtual void SetFocalMask(const int *fmask, float weight = 1.0f);
+};
+
+extern "C" ParallelBA *NewParallelBA(ParallelBA::DeviceT device = ParallelBA::PBA_CUDA_DEVICE_DEFAULT);
+typedef ParallelBA *(*NEWPARALLELBAPROC)(ParallelBA::DeviceT);
+extern "C" int ParallelBA_GetVersion();
+
+#endif

@@ -79,6 +79,14 @@ int Engine::set_cameras(int m, const double *a0, const double *R0, const double 
     return 0;
 }
 
+int Engine::set_fixed_cameras(const unsigned char *mask)
+{
+    if (!m_) { err = "set_fixed_cameras: set_cameras first"; return MI_BA_ERROR; }
+    if (mask) h_fixed_.assign(mask, mask + m_); else h_fixed_.assign(m_, 0);
+    prepared_ = begun_ = false;
+    return 0;
+}
+
 int Engine::set_points(int n, const double *xyz)
 {
     if (n <= 0 || !xyz) { err = "set_points: bad arguments"; return MI_BA_ERROR; }
@@ -150,6 +158,13 @@ int Engine::prepare()
         UP(d_obs_xy_, xy);
     }
     UP(d_R0_, h_R0_); UP(d_ff_, h_ff_);
+    {
+        if ((int)h_fixed_.size() != m_) h_fixed_.assign(m_, 0);
+        std::vector<unsigned char> fx(h_fixed_);
+        for (int j = 0; j < cfg.mcon && j < m_; ++j) fx[j] = 1; // sba's leading mcon cameras
+        UP(d_fixed_, fx);
+        h_fixed_eff_ = fx;
+    }
 #undef UP
     const size_t npl = (size_t)pl.npts_local();
     for (int b = 0; b < 2; ++b) {
@@ -234,7 +249,7 @@ bool Engine::linear_phase(double mu)
     a.tile_batch = d_tile_batch_.p; a.tile_slot = d_tile_slot_.p; a.tile_cslot = d_tile_cslot_.p;
     a.slot_gblk = d_slot_gblk_.p; a.cslot_cam = d_cslot_cam_.p;
     a.batch_obs = d_batch_obs_.p; a.batch_pt = d_batch_pt_.p; a.batch_pair = d_batch_pair_.p; a.pt_obs = d_pt_obs_.p;
-    a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p;
+    a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p; a.cam_fixed = d_fixed_.p;
     a.pair = d_pair_.p; a.pair_gblk = d_pair_gblk_.p; a.pair_gblk_base = pl.npair_lds;
     a.m = m_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
     a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc;
@@ -246,7 +261,7 @@ bool Engine::linear_phase(double mu)
     (void)hipEventRecord(ev_[1], st_);
     launch_reduce_partials(st_, pl.ntile(), d_part_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
-    launch_finalize(st_, cnp, m_, pl.nb_full(), cfg.mcon, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
+    launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
                     S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_E_.p, scal_());
     launch_block_inv(st_, m_, d_bsr_diag_.p, d_S_full_.p, d_Minv_.p, scal_());
     return hipok(hipGetLastError(), "launch (linear phase)");
@@ -283,11 +298,11 @@ bool Engine::solve_phase(double mu, double *dB_dev)
         if (h_scal_[SC_PCG_STATUS] != 0.0 || h_scal_[SC_PCG_DONE] != 0.0) break;
     }
     (void)hipEventRecord(ev_[3], st_);
-    launch_cam_update(st_, m_, cnp, mc, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, d_cam_a_[cur_ ^ 1].p,
+    launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, d_cam_a_[cur_ ^ 1].p,
                       d_cam_lin_[cur_ ^ 1].p, scal_());
     BacksubArgs b{};
     b.batch_obs = d_batch_obs_.p; b.batch_pt = d_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
-    b.obs_xy = d_obs_xy_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
+    b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
     b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = pl.nbatch(); b.ngrid = std::min(pl.nbatch(), kBacksubGrid); b.cfg = mc;
     (void)hipEventRecord(ev_[4], st_);
@@ -532,7 +547,7 @@ int Engine::debug_solve(double mu, double *da, double *db, double *cost_new)
     if (da) {
         std::vector<double> tmp((size_t)m_ * kCP);
         if (!hipok(hipMemcpy(tmp.data(), d_dA_.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost), "download dA")) return MI_BA_ERROR;
-        for (int j = 0; j < m_; ++j) for (int r = 0; r < cnp; ++r) da[(size_t)j * cnp + r] = (j >= cfg.mcon) ? tmp[(size_t)j * kCP + r] : 0.0;
+        for (int j = 0; j < m_; ++j) for (int r = 0; r < cnp; ++r) da[(size_t)j * cnp + r] = h_fixed_eff_[j] ? 0.0 : tmp[(size_t)j * kCP + r];
     }
     if (db) {
         const size_t npl = (size_t)pl.npts_local();

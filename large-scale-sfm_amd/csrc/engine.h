@@ -44,6 +44,7 @@ public:
     bool ok() const { return created_; }
 
     int set_cameras(int m, const double *a0, const double *R0, const double *f_fixed);
+    int set_fixed_cameras(const unsigned char *mask);
     int set_points(int n, const double *xyz);
     int set_observations(int64_t nobs, const double *xy, const int *pt_idx, const int *cam_idx);
     int prepare();
@@ -85,6 +86,7 @@ private:
     int64_t nobs_ = 0;
     std::vector<double> h_a0_, h_R0_, h_ff_, h_xyz_, h_xy_;
     std::vector<int> h_pt_, h_cam_;
+    std::vector<unsigned char> h_fixed_, h_fixed_eff_;
     bool have_ff_ = false;
     double pl2_inactive_ = 0.0;
     Plan plan_;
@@ -93,7 +95,7 @@ private:
     DevBuf<int> d_tile_batch_, d_tile_slot_, d_tile_cslot_, d_slot_gblk_, d_cslot_cam_, d_batch_obs_, d_batch_pt_, d_pt_obs_,
         d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_;
     DevBuf<long long> d_batch_pair_;
-    DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_;
+    DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_;
     DevBuf<unsigned> d_pair_, d_pair_gblk_;
     DevBuf<double2> d_obs_xy_;
     // device: state

@@ -48,7 +48,7 @@ struct BuildArgs {
     const long long *batch_pair;
     const int *pt_obs;
     const int *obs_cam, *obs_pt;
-    const unsigned char *obs_cslot;
+    const unsigned char *obs_cslot, *cam_fixed;   // cam_fixed [m]: 1 = camera held constant (A_ij := 0)
     const double2 *obs_xy;
     const unsigned *pair, *pair_gblk;
     long long pair_gblk_base;
@@ -61,6 +61,7 @@ struct BuildArgs {
 
 struct BacksubArgs {
     const int *batch_obs, *batch_pt, *pt_obs, *obs_cam, *obs_pt;
+    const unsigned char *cam_fixed;
     const double2 *obs_xy;
     const double *cam_lin, *cam_lin_new, *pts, *ptout, *dA;
     double *pts_new, *dB, *part;            // part: [ngrid][kPartW] cost_new, dL, |db|^2, -, max pct change
@@ -81,7 +82,7 @@ struct PcgArgs {
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
                      const double *f_fixed, double *cam_lin);
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);
-void launch_finalize(hipStream_t st, int cnp, int m, int nb, int mcon, double mu, const int *bsr_rowidx, const int *bsr_col,
+void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
                      const double *camvec, const double *cam_a, double *E, double *scal);
 void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal);
@@ -89,7 +90,7 @@ void launch_pcg_init(hipStream_t st, const PcgArgs &a);
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // spmv + update for iteration a.it
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . z_it
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *out_sum, double *out_max);
-void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, double mu, const double *cam_a, const double *dA,
+void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
                        const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
                        double *cam_lin_new, double *scal);
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a);

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
             if constexpr (LDS) cs = g.obs_cslot[o];
             const double2 xy = g.obs_xy[o];
             const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
-            linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, j < cfg.mcon, e, A, B);
+            linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, g.cam_fixed[j] != 0, e, A, B);
             cost += e[0] * e[0] + e[1] * e[1];
 #pragma unroll
             for (int t = 0; t < CNP; ++t) { sA[lane * SA + t] = A[0][t]; sA[lane * SA + CNP + t] = A[1][t]; }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         }
         __syncthreads();
         // ---- phase 4: camera-side vectors
-        if (active && j >= cfg.mcon) {
+        if (active && !g.cam_fixed[j]) {
             const double *sv = sV + lp * SV;
             double er[2];
 #pragma unroll
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const doubl
 // identity on the padding row/column and on the rows of the mcon fixed cameras.
 // one thread per matrix element, 64 threads = one block.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, int mcon, double mu, const int *__restrict__ rowidx,
+__global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, const unsigned char *__restrict__ fixed, double mu, const int *__restrict__ rowidx,
                                                  const int *__restrict__ col, const int *__restrict__ src,
                                                  const unsigned char *__restrict__ trans, const double *__restrict__ S_up,
                                                  double *__restrict__ S_full)
@@ -452,10 +452,10 @@ __global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, int mcon, dou
     if (j == k) {
         v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
         if (r == c) v = (r < cnp) ? v + mu : 1.0;
-        if (j < mcon) v = (r == c) ? 1.0 : 0.0;
+        if (fixed[j]) v = (r == c) ? 1.0 : 0.0;
     } else {
         v = trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
-        if (j < mcon || k < mcon) v = 0.0;
+        if (fixed[j] || fixed[k]) v = 0.0;
     }
     if (r >= cnp || c >= cnp) v = (j == k && r == c) ? 1.0 : 0.0;
     S_full[(size_t)blk * 64 + el] = v;
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, int mcon, dou
 
 // right-hand side E_j = ea_j - sum_i Y_ij eb_i (already folded: E = sum A^T (e - B h)), ||ea||_inf,
 // max diag U, ||a||^2   (sba_levmar.c:1085-1088, 1124-1128)
-__global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, int mcon, const double *__restrict__ camvec,
+__global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsigned char *__restrict__ fixed, const double *__restrict__ camvec,
                                                      const double *__restrict__ cam_a, double *__restrict__ E,
                                                      double *__restrict__ scal)
 {
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, int mcon, 
     double eainf = 0.0, maxdu = 0.0, pl2 = 0.0;
     if (gid < m * kCP) {
         const int j = gid >> 3, r = gid & 7;
-        const bool live = (r < cnp) && (j >= mcon);
+        const bool live = (r < cnp) && !fixed[j];
         const double ea = camvec[gid], Ev = camvec[(size_t)m * kCP + gid], du = camvec[2 * (size_t)m * kCP + gid];
         E[gid] = live ? Ev : 0.0;
         if (live) { eainf = fabs(ea); maxdu = du; }
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64) void k_pcg_update(const PcgArgs a)
 // camera update: a_new = a + da, new camera record, dL and ||dp||^2 camera parts
 // (sba_levmar.c:1444-1447, 1524-1525)
 // ------------------------------------------------------------------------------------------
-__global__ void k_cam_update(int m, int cnp, ModelCfg cfg, double mu, const double *__restrict__ cam_a,
+__global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *__restrict__ fixed, double mu, const double *__restrict__ cam_a,
                              const double *__restrict__ dA, const double *__restrict__ camvec,
                              const double *__restrict__ R0, const double *__restrict__ f_fixed,
                              double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ scal)
@@ -677,7 +677,7 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, double mu, const doub
         double an[kCP];
 #pragma unroll
         for (int r = 0; r < kCP; ++r) {
-            const double d = (r < cnp && j >= cfg.mcon) ? dA[j * kCP + r] : 0.0;
+            const double d = (r < cnp && !fixed[j]) ? dA[j * kCP + r] : 0.0;
             an[r] = cam_a[j * kCP + r] + d;
             cam_a_new[j * kCP + r] = an[r];
             dl += d * (mu * d + camvec[j * kCP + r]);
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
             xy = g.obs_xy[o];
             const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
             double A[2][CNP], B[2][3];
-            linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, j < cfg.mcon, e, A, B);
+            linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, g.cam_fixed[j] != 0, e, A, B);
             double w0 = 0.0, w1 = 0.0;
 #pragma unroll
             for (int t = 0; t < CNP; ++t) { const double d = g.dA[j * kCP + t]; w0 += A[0][t] * d; w1 += A[1][t] * d; }
@@ -789,14 +789,14 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
     }
 }
 
-void launch_finalize(hipStream_t st, int cnp, int m, int nb, int mcon, double mu, const int *bsr_rowidx, const int *bsr_col,
+void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
                      const double *camvec, const double *cam_a, double *E, double *scal)
 {
     const long long total = (long long)nb * 64;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cnp, nb, mcon, mu, bsr_rowidx,
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cnp, nb, fixed, mu, bsr_rowidx,
                        bsr_col, bsr_src, bsr_trans, S_up, S_full);
-    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, mcon, camvec, cam_a, E, scal);
+    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, camvec, cam_a, E, scal);
 }
 
 void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal)
@@ -822,11 +822,11 @@ void launch_reduce_partials(hipStream_t st, int nrows, const double *part, doubl
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, st, nrows, part, out_sum, out_max);
 }
 
-void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, double mu, const double *cam_a, const double *dA,
+void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
                        const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
                        double *cam_lin_new, double *scal)
 {
-    hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, mu, cam_a, dA, camvec, R0, f_fixed,
+    hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, dA, camvec, R0, f_fixed,
                        cam_a_new, cam_lin_new, scal);
 }
 

@@ -1,0 +1,299 @@
+// model_io.cpp -- NVM / BAL text I/O and the optimizer_all process contract (include/mi_model.h).
+// Host code; the numeric work is mi_ba.h's engine.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_model.h"
+
+struct mi_model {
+    std::vector<std::string> names;
+    std::vector<double> f, R, t, d;      // per camera: 1, 9, 3, 2
+    std::vector<double> xyz;             // per point 3
+    std::vector<int> rgb;                // per point 3
+    std::vector<double> xy;              // per projection 2
+    std::vector<int> pt_idx, cam_idx;
+    std::vector<long long> feat_id;
+    size_t ncam() const { return f.size(); }
+    size_t npt() const { return xyz.size() / 3; }
+    size_t nproj() const { return pt_idx.size(); }
+};
+
+static thread_local std::string g_err;
+
+namespace {
+
+void quat_to_R(const double q[4], double *R) // DataInterface.h:183-207
+{
+    const double qq = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    double qw = 1, qx = 0, qy = 0, qz = 0;
+    if (qq > 0) { qw = q[0] / qq; qx = q[1] / qq; qy = q[2] / qq; qz = q[3] / qq; }
+    R[0] = qw * qw + qx * qx - qz * qz - qy * qy; R[1] = 2 * qx * qy - 2 * qz * qw; R[2] = 2 * qy * qw + 2 * qz * qx;
+    R[3] = 2 * qx * qy + 2 * qw * qz; R[4] = qy * qy + qw * qw - qz * qz - qx * qx; R[5] = 2 * qz * qy - 2 * qx * qw;
+    R[6] = 2 * qx * qz - 2 * qy * qw; R[7] = 2 * qy * qz + 2 * qw * qx; R[8] = qz * qz + qw * qw - qy * qy - qx * qx;
+}
+
+void rodrigues_to_R(const double r[3], double *R) // DataInterface.h:93-107
+{
+    const double a = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    const double ct = a == 0.0 ? 0.5 : (1.0 - std::cos(a)) / a / a, st = a == 0.0 ? 1.0 : std::sin(a) / a;
+    R[0] = 1.0 - (r[1] * r[1] + r[2] * r[2]) * ct; R[1] = r[0] * r[1] * ct - r[2] * st; R[2] = r[2] * r[0] * ct + r[1] * st;
+    R[3] = r[0] * r[1] * ct + r[2] * st; R[4] = 1.0 - (r[2] * r[2] + r[0] * r[0]) * ct; R[5] = r[1] * r[2] * ct - r[0] * st;
+    R[6] = r[2] * r[0] * ct - r[1] * st; R[7] = r[1] * r[2] * ct + r[0] * st; R[8] = 1.0 - (r[0] * r[0] + r[1] * r[1]) * ct;
+}
+
+void R_to_rodrigues(const double *R, double r[3]) // generic branch of DataInterface.h:108-181
+{
+    double c = (R[0] + R[4] + R[8] - 1.0) / 2.0;
+    c = c > 1 ? 1 : (c < -1 ? -1 : c);
+    const double a = std::acos(c), s = std::sin(a);
+    const double b = std::fabs(s) < 1e-12 ? 0.5 : 0.5 * a / s;
+    r[0] = b * (R[7] - R[5]); r[1] = b * (R[2] - R[6]); r[2] = b * (R[3] - R[1]);
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mi_model_last_error(void) { return g_err.c_str(); }
+void mi_model_free(mi_model *m) { delete m; }
+
+mi_model *mi_model_load_nvm(const char *path)
+{
+    std::ifstream in(path);
+    if (!in) { g_err = std::string("cannot open ") + path; return nullptr; }
+    int nrot = 4; bool r9t = false;
+    std::string token;
+    if (in.peek() == 'N') { in >> token; if (token.find("R9T") != std::string::npos) { nrot = 9; r9t = true; } }
+    int ncam = 0, npt = 0;
+    in >> ncam;
+    if (!in || ncam <= 1) { g_err = "NVM: fewer than 2 cameras"; return nullptr; } // util_VSFM.h:158
+    mi_model *m = new mi_model;
+    m->names.resize(ncam); m->f.resize(ncam); m->R.resize((size_t)ncam * 9); m->t.resize((size_t)ncam * 3); m->d.resize((size_t)ncam * 2);
+    for (int i = 0; i < ncam; ++i) {
+        double q[9], c[3];
+        in >> m->names[i] >> m->f[i];
+        for (int j = 0; j < nrot; ++j) in >> q[j];
+        in >> c[0] >> c[1] >> c[2] >> m->d[2 * i] >> m->d[2 * i + 1];
+        double *R = &m->R[(size_t)i * 9], *t = &m->t[(size_t)i * 3];
+        if (r9t) { std::memcpy(R, q, sizeof(double) * 9); std::memcpy(t, c, sizeof(double) * 3); }
+        else { quat_to_R(q, R); for (int r = 0; r < 3; ++r) t[r] = -(R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2]); }
+    }
+    in >> npt;
+    if (!in || npt <= 0) { g_err = "NVM: no points"; delete m; return nullptr; }
+    m->xyz.resize((size_t)npt * 3); m->rgb.resize((size_t)npt * 3);
+    for (int i = 0; i < npt; ++i) {
+        int npj = 0;
+        in >> m->xyz[3 * (size_t)i] >> m->xyz[3 * (size_t)i + 1] >> m->xyz[3 * (size_t)i + 2] >> m->rgb[3 * (size_t)i] >>
+            m->rgb[3 * (size_t)i + 1] >> m->rgb[3 * (size_t)i + 2] >> npj;
+        if (!in) { g_err = "NVM: truncated point record"; delete m; return nullptr; }
+        for (int j = 0; j < npj; ++j) {
+            int cidx; long long fidx; double x, y;
+            in >> cidx >> fidx >> x >> y;
+            if (cidx < 0 || cidx >= ncam) { g_err = "NVM: camera index out of range"; delete m; return nullptr; }
+            m->cam_idx.push_back(cidx); m->pt_idx.push_back(i); m->feat_id.push_back(fidx);
+            m->xy.push_back(x); m->xy.push_back(y);
+        }
+    }
+    if (!in) { g_err = "NVM: truncated file"; delete m; return nullptr; }
+    return m;
+}
+
+int mi_model_save_nvm(const mi_model *m, const char *path)
+{
+    if (!m) return MI_BA_ERROR;
+    std::ofstream out(path);
+    if (!out) { g_err = std::string("cannot write ") + path; return MI_BA_ERROR; }
+    out << "NVM_V3_R9T\n" << m->ncam() << '\n' << std::setprecision(12);
+    for (size_t i = 0; i < m->ncam(); ++i) {
+        out << (m->names[i].empty() ? "unknown" : m->names[i]) << ' ' << m->f[i] << ' ';
+        for (int j = 0; j < 9; ++j) out << m->R[i * 9 + j] << ' ';
+        out << m->t[i * 3] << ' ' << m->t[i * 3 + 1] << ' ' << m->t[i * 3 + 2] << ' ' << m->d[2 * i] << ' ' << m->d[2 * i + 1] << '\n';
+    }
+    out << m->npt() << '\n';
+    size_t j = 0;
+    for (size_t i = 0; i < m->npt(); ++i) {
+        out << m->xyz[3 * i] << ' ' << m->xyz[3 * i + 1] << ' ' << m->xyz[3 * i + 2] << ' ' << m->rgb[3 * i] << ' ' << m->rgb[3 * i + 1]
+            << ' ' << m->rgb[3 * i + 2] << ' ';
+        size_t je = j;
+        while (je < m->nproj() && m->pt_idx[je] == (int)i) ++je;
+        out << (je - j) << ' ';
+        for (; j < je; ++j) out << m->cam_idx[j] << ' ' << m->feat_id[j] << ' ' << m->xy[2 * j] << ' ' << m->xy[2 * j + 1] << ' ';
+        out << '\n';
+    }
+    return out ? 0 : MI_BA_ERROR;
+}
+
+mi_model *mi_model_load_bal(const char *path)
+{
+    std::ifstream in(path);
+    if (!in) { g_err = std::string("cannot open ") + path; return nullptr; }
+    long long ncam = 0, npt = 0, nproj = 0;
+    if (!(in >> ncam >> npt >> nproj) || ncam <= 0 || npt <= 0 || nproj <= 0) { g_err = "BAL: bad header"; return nullptr; }
+    mi_model *m = new mi_model;
+    struct Obs { int p, c; double x, y; };
+    std::vector<Obs> obs; obs.reserve(nproj);
+    bool sorted = true;
+    for (long long i = 0; i < nproj; ++i) {
+        int cidx, pidx; double x, y;
+        in >> cidx >> pidx >> x >> y;
+        if (!in) { g_err = "BAL: truncated observations"; delete m; return nullptr; }
+        if (pidx < 0 || pidx >= npt || cidx < 0 || cidx >= ncam) continue;   // util_VSFM.h:475-477
+        if (!obs.empty() && obs.back().p > pidx) sorted = false;
+        obs.push_back({ pidx, cidx, x, -y });                                   // y negated, :480
+    }
+    if (!sorted) { // the engine wants observations grouped by point; a stable counting sort keeps file order inside a point
+        std::vector<long long> start(npt + 1, 0);
+        for (auto &o : obs) start[o.p + 1]++;
+        for (long long i = 0; i < npt; ++i) start[i + 1] += start[i];
+        std::vector<Obs> tmp(obs.size());
+        for (auto &o : obs) tmp[start[o.p]++] = o;
+        obs.swap(tmp);
+    }
+    for (auto &o : obs) { m->pt_idx.push_back(o.p); m->cam_idx.push_back(o.c); m->xy.push_back(o.x); m->xy.push_back(o.y); m->feat_id.push_back(0); }
+    m->names.assign(ncam, "unknown"); m->f.resize(ncam); m->R.resize(ncam * 9); m->t.resize(ncam * 3); m->d.assign(ncam * 2, 0.0);
+    for (long long i = 0; i < ncam; ++i) {
+        double p[9];
+        for (int j = 0; j < 9; ++j) in >> p[j];
+        m->f[i] = p[6];
+        double *R = &m->R[i * 9], *t = &m->t[i * 3];
+        rodrigues_to_R(p, R);                                                 // SetInvertedRT, DataInterface.h:290-296
+        for (int r = 3; r < 9; ++r) R[r] = -R[r];
+        t[0] = p[3]; t[1] = -p[4]; t[2] = -p[5];
+        m->d[2 * i] = p[7]; m->d[2 * i + 1] = p[8];
+    }
+    m->xyz.resize(npt * 3); m->rgb.assign(npt * 3, 0);
+    for (long long i = 0; i < npt * 3; ++i) in >> m->xyz[i];
+    if (!in) { g_err = "BAL: truncated file"; delete m; return nullptr; }
+    return m;
+}
+
+int mi_model_save_bal(const mi_model *m, const char *path)
+{
+    if (!m) return MI_BA_ERROR;
+    std::ofstream out(path);
+    if (!out) { g_err = std::string("cannot write ") + path; return MI_BA_ERROR; }
+    out << std::setprecision(12) << m->ncam() << ' ' << m->npt() << ' ' << m->nproj() << '\n';
+    for (size_t i = 0; i < m->nproj(); ++i) out << m->cam_idx[i] << ' ' << m->pt_idx[i] << ' ' << m->xy[2 * i] << ' ' << -m->xy[2 * i + 1] << '\n';
+    for (size_t i = 0; i < m->ncam(); ++i) {
+        double R[9], r[3];
+        std::memcpy(R, &m->R[i * 9], sizeof(R));
+        for (int k = 3; k < 9; ++k) R[k] = -R[k];
+        R_to_rodrigues(R, r);
+        out << r[0] << ' ' << r[1] << ' ' << r[2] << ' ' << m->t[3 * i] << ' ' << -m->t[3 * i + 1] << ' ' << -m->t[3 * i + 2] << ' '
+            << m->f[i] << ' ' << m->d[2 * i] << ' ' << m->d[2 * i + 1] << '\n';
+    }
+    for (size_t i = 0; i < m->npt(); ++i) out << m->xyz[3 * i] << ' ' << m->xyz[3 * i + 1] << ' ' << m->xyz[3 * i + 2] << '\n';
+    return out ? 0 : MI_BA_ERROR;
+}
+
+int mi_model_counts(const mi_model *m, int64_t c[3])
+{
+    if (!m) return MI_BA_ERROR;
+    c[0] = (int64_t)m->ncam(); c[1] = (int64_t)m->npt(); c[2] = (int64_t)m->nproj();
+    return 0;
+}
+
+int mi_model_get(const mi_model *m, double *f, double *R, double *t, double *d, double *xyz, int *rgb, double *xy, int *pt_idx,
+                 int *cam_idx, int64_t *feat_id)
+{
+    if (!m) return MI_BA_ERROR;
+#define CP(dst, src) if (dst) std::memcpy(dst, (src).data(), (src).size() * sizeof((src)[0]))
+    CP(f, m->f); CP(R, m->R); CP(t, m->t); CP(d, m->d); CP(xyz, m->xyz); CP(rgb, m->rgb); CP(xy, m->xy); CP(pt_idx, m->pt_idx); CP(cam_idx, m->cam_idx);
+#undef CP
+    if (feat_id) for (size_t i = 0; i < m->nproj(); ++i) feat_id[i] = m->feat_id[i];
+    return 0;
+}
+
+double mi_model_rmse(const mi_model *m)
+{
+    if (!m || !m->nproj()) return 0.0;
+    double s = 0.0;
+    for (size_t k = 0; k < m->nproj(); ++k) {
+        const double *R = &m->R[(size_t)m->cam_idx[k] * 9], *t = &m->t[(size_t)m->cam_idx[k] * 3], *X = &m->xyz[(size_t)m->pt_idx[k] * 3];
+        double q[3];
+        for (int r = 0; r < 3; ++r) q[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2] + t[r];
+        const double fx = m->f[m->cam_idx[k]];
+        const double ex = m->xy[2 * k] - fx * q[0] / q[2], ey = m->xy[2 * k + 1] - fx * q[1] / q[2];
+        s += ex * ex + ey * ey;
+    }
+    return std::sqrt(s / (double)m->nproj());
+}
+
+int mi_model_optimize(mi_model *m, const mi_ba_config *user, double info[MI_BA_INFOSZ])
+{
+    if (!m) return MI_BA_ERROR;
+    mi_ba_config cfg;
+    mi_ba_default_config(&cfg);
+    if (user) {
+        cfg.itmax = user->itmax; std::memcpy(cfg.opts, user->opts, sizeof(cfg.opts)); cfg.pcg_maxit = user->pcg_maxit; cfg.pcg_tol = user->pcg_tol;
+        cfg.est_focal = user->est_focal; cfg.mcon = user->mcon; cfg.device = user->device; cfg.verbose = user->verbose;
+    }
+    cfg.explicit_centers = 0; cfg.proj_sign = 1.0; // file convention: x^ = f (R X + t).xy / z
+    mi_ba_engine *e = mi_ba_create(&cfg);
+    if (!e) { g_err = mi_ba_last_error(nullptr); return MI_BA_ERROR; }
+    const int ncam = (int)m->ncam(), npt = (int)m->npt(), cnp = mi_ba_cnp(e);
+    std::vector<double> a0((size_t)ncam * cnp, 0.0);
+    for (int j = 0; j < ncam; ++j) {
+        for (int r = 0; r < 3; ++r) a0[(size_t)j * cnp + r] = m->t[(size_t)j * 3 + r];
+        if (cfg.est_focal) a0[(size_t)j * cnp + 6] = m->f[j] * cfg.f_scale;
+    }
+    int ret = MI_BA_ERROR;
+    if (mi_ba_set_cameras(e, ncam, a0.data(), m->R.data(), m->f.data()) == 0 && mi_ba_set_points(e, npt, m->xyz.data()) == 0 &&
+        mi_ba_set_observations(e, (int64_t)m->nproj(), m->xy.data(), m->pt_idx.data(), m->cam_idx.data()) == 0 && mi_ba_prepare(e) == 0) {
+        ret = mi_ba_run(e, info);
+        std::vector<double> a((size_t)ncam * cnp), R((size_t)ncam * 9);
+        if (mi_ba_get_params(e, a.data(), m->xyz.data()) == 0 && mi_ba_get_rotations(e, R.data()) == 0) {
+            m->R = R;
+            for (int j = 0; j < ncam; ++j) {
+                for (int r = 0; r < 3; ++r) m->t[(size_t)j * 3 + r] = a[(size_t)j * cnp + r];
+                if (cfg.est_focal) m->f[j] = a[(size_t)j * cnp + 6] / cfg.f_scale;
+            }
+        } else ret = MI_BA_ERROR;
+    }
+    if (ret == MI_BA_ERROR) g_err = mi_ba_last_error(e);
+    mi_ba_destroy(e);
+    return ret;
+}
+
+// optimizer_all <dir>/ A B C D E F.  The reference's main (Optimizer/main_all.cpp) is missing from its
+// tree, so the meaning of A..F is the one documented in INTEGRATION.md:
+//   A  which blocks are free (utils.h:112 whatToCalibrate): < 0 -> intrinsics held (cnp 6), >= 0 -> pose + focal (cnp 7)
+//   B  maximum LM iterations          C, D  accepted, unused (always 16 / 32 at the call sites)
+//   E  accepted, unused (curErrorThresh, utils.cpp:35)        F  back end selector: every value runs this engine
+int mi_optimizer_all_main(int argc, char **argv)
+{
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: %s <cluster dir>/ [A B C D E F]\n", argc ? argv[0] : "optimizer_all");
+        return 2;
+    }
+    std::string dir = argv[1];
+    if (!dir.empty() && dir.back() != '/') dir += '/';
+    const int A = argc > 2 ? std::atoi(argv[2]) : 0;
+    const int B = argc > 3 ? std::atoi(argv[3]) : 50;
+    const std::string nvm = dir + "outputVSFM_GB.nvm";
+    mi_model *m = mi_model_load_nvm(nvm.c_str());
+    if (!m) { std::fprintf(stderr, "optimizer_all: %s\n", mi_model_last_error()); return 1; }
+    mi_ba_config cfg;
+    mi_ba_default_config(&cfg);
+    cfg.est_focal = A >= 0 ? 1 : 0;
+    cfg.itmax = B > 0 ? B : 1;
+    if (const char *dev = std::getenv("MI_BA_DEVICE")) cfg.device = std::atoi(dev);
+    double info[MI_BA_INFOSZ] = { 0 };
+    const double rmse0 = mi_model_rmse(m);
+    std::printf("%zu cameras; %zu 3D points; %zu projections\n", m->ncam(), m->npt(), m->nproj());
+    const int it = mi_model_optimize(m, &cfg, info);
+    if (it == MI_BA_ERROR) { std::fprintf(stderr, "optimizer_all: %s\n", mi_model_last_error()); mi_model_free(m); return 1; }
+    std::printf("optimizer_all: %d LM iterations (stop %d), reprojection RMSE %.6f -> %.6f px\n", it, (int)info[6], rmse0, mi_model_rmse(m));
+    const int rc = mi_model_save_nvm(m, nvm.c_str());
+    mi_model_free(m);
+    return rc == 0 ? 0 : 1;
+}
+
+} // extern "C"

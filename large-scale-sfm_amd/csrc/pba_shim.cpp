@@ -1,0 +1,165 @@
+// pba_shim.cpp -- class ParallelBA (include/mi_pba.h) over the C ABI of include/mi_ba.h.
+// Mirrors the call sequence of the reference plugin (pba.cpp:27-154 forwarding to
+// SparseBundleCPU.cpp:2541-2674); the numbers come from the HIP engine.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_ba.h"
+#include "../../include/mi_pba.h"
+
+ConfigBA::ConfigBA()
+    : __lm_max_iteration(50), __cg_max_iteration(100), __cg_norm_threshold(1e-3f), __fixed_intrinsics(false),
+      __use_radial_distortion(0), __verbose_level(0), __selected_device(0), __bundle_return_code(0), __num_lm_success(0),
+      __num_lm_iteration(0), __initial_mse(0), __final_mse(0)
+{
+    __output_param[0] = 0;
+}
+
+// the reference's string-hashed option parser (ConfigBA.cpp:318-541), the options that apply here
+void ConfigBA::ParseParam(int argc, char **argv)
+{
+    for (int i = 0; i < argc; ++i) {
+        const char *a = argv[i];
+        if (!a || a[0] != '-') continue;
+        const char *v = (i + 1 < argc) ? argv[i + 1] : nullptr;
+        if (!std::strcmp(a, "-lmi") && v) { __lm_max_iteration = std::atoi(v); ++i; }
+        else if (!std::strcmp(a, "-cgi") && v) { __cg_max_iteration = std::atoi(v); ++i; }
+        else if (!std::strcmp(a, "-cgn") && v) { __cg_norm_threshold = (float)std::atof(v); ++i; }
+        else if (!std::strcmp(a, "-dev") && v) { __selected_device = std::atoi(v); ++i; }
+        else if (!std::strcmp(a, "-out") && v) { std::snprintf(__output_param, sizeof(__output_param), "%s", v); ++i; }
+        else if (!std::strcmp(a, "-v") && v) { __verbose_level = std::atoi(v); ++i; }
+        else if (!std::strcmp(a, "-cali")) __fixed_intrinsics = true;
+    }
+}
+
+struct ParallelBA::Impl {
+    ConfigBA cfg;
+    int device = 0;
+    bool valid_device = true;
+    CameraT *cams = nullptr; size_t ncam = 0;
+    Point3D *pts = nullptr; size_t npt = 0;
+    const Point2D *meas = nullptr; const int *ptidx = nullptr, *camidx = nullptr; size_t nproj = 0;
+    BundleModeT mode = BUNDLE_FULL;
+    std::atomic<float> mse{0.0f};
+    std::atomic<int> iteration{0};
+    std::atomic<bool> abort{false};
+};
+
+ParallelBA::ParallelBA(DeviceT device) : _optimizer(new Impl)
+{
+    _optimizer->valid_device = device != PBA_INVALID_DEVICE;
+    _optimizer->device = device >= 0 ? (int)device : 0;
+    _optimizer->cfg.__selected_device = _optimizer->device;
+}
+ParallelBA::~ParallelBA() { delete _optimizer; }
+void *ParallelBA::operator new(size_t size) { return std::malloc(size); }
+void ParallelBA::operator delete(void *p) { std::free(p); }
+
+void ParallelBA::ParseParam(int narg, char **argv) { _optimizer->cfg.ParseParam(narg, argv); _optimizer->device = _optimizer->cfg.__selected_device; }
+ConfigBA *ParallelBA::GetInternalConfig() { return &_optimizer->cfg; }
+void ParallelBA::SetFixedIntrinsics(bool fixed) { _optimizer->cfg.__fixed_intrinsics = fixed; }
+void ParallelBA::EnableRadialDistortion(DistortionT type) { _optimizer->cfg.__use_radial_distortion = (int)type; }
+void ParallelBA::SetNextTimeBudget(int) {}
+void ParallelBA::ReserveStorage(size_t, size_t, size_t) {}
+void ParallelBA::SetCameraData(size_t ncam, CameraT *cams) { _optimizer->ncam = ncam; _optimizer->cams = cams; }
+void ParallelBA::SetPointData(size_t npoint, Point3D *pts) { _optimizer->npt = npoint; _optimizer->pts = pts; }
+void ParallelBA::SetProjection(size_t nproj, const Point2D *imgpts, const int *point_idx, const int *cam_idx)
+{ _optimizer->nproj = nproj; _optimizer->meas = imgpts; _optimizer->ptidx = point_idx; _optimizer->camidx = cam_idx; }
+void ParallelBA::SetNextBundleMode(BundleModeT mode) { _optimizer->mode = mode; }
+float ParallelBA::GetMeanSquaredError() { return _optimizer->mse.load(); }
+void ParallelBA::AbortBundleAdjustment() { _optimizer->abort.store(true); }
+int ParallelBA::GetCurrentIteration() { return _optimizer->iteration.load(); }
+void ParallelBA::SetFocalMask(const int *, float) {} // shared-focal "Q" constraints: SURVEY 8f rank 2, not in this round
+
+int ParallelBA::RunBundleAdjustment()
+{
+    Impl &o = *_optimizer;
+    ConfigBA &c = o.cfg;
+    c.__bundle_return_code = 0; c.__num_lm_success = c.__num_lm_iteration = 0;
+    o.abort.store(false); o.iteration.store(0);
+    // silent "nothing done" on missing input, SparseBundleCPU.cpp:2587-2590
+    if (!o.valid_device || !o.cams || !o.pts || !o.meas || !o.ptidx || !o.camidx || !o.ncam || !o.npt || !o.nproj) return 0;
+    if (c.__use_radial_distortion != 0 || o.mode != BUNDLE_FULL) {
+        std::fprintf(stderr, "[mi_pba] radial distortion and the truncated bundle modes are not supported by this build\n");
+        c.__bundle_return_code = 'E';
+        return 0;
+    }
+    mi_ba_config cfg;
+    mi_ba_default_config(&cfg);
+    cfg.est_focal = c.__fixed_intrinsics ? 0 : 1;
+    cfg.explicit_centers = 0;              // CameraT holds T = -R C (DataInterface.h:51)
+    cfg.proj_sign = 1.0;                   // +z forward
+    cfg.itmax = c.__lm_max_iteration;
+    cfg.pcg_maxit = c.__cg_max_iteration; cfg.pcg_tol = c.__cg_norm_threshold;
+    cfg.device = o.device; cfg.verbose = c.__verbose_level;
+    mi_ba_engine *e = mi_ba_create(&cfg);
+    if (!e) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(nullptr)); c.__bundle_return_code = 'E'; return 0; }
+    const int m = (int)o.ncam, n = (int)o.npt, cnp = mi_ba_cnp(e);
+    std::vector<double> a0((size_t)m * cnp, 0.0), R0((size_t)m * 9), ff(m), xyz((size_t)n * 3), xy(o.nproj * 2);
+    std::vector<unsigned char> fixed(m, 0);
+    bool some_fixed_intrinsics = false;
+    for (int j = 0; j < m; ++j) {
+        const CameraT &cam = o.cams[j];
+        for (int r = 0; r < 3; ++r) a0[(size_t)j * cnp + r] = cam.t[r];
+        if (cfg.est_focal) a0[(size_t)j * cnp + 6] = (double)cam.f * cfg.f_scale;
+        for (int r = 0; r < 9; ++r) R0[(size_t)j * 9 + r] = cam.m[r / 3][r % 3];
+        ff[j] = cam.f;
+        fixed[j] = cam.constant_camera == 1.0f;
+        some_fixed_intrinsics |= cam.constant_camera == 2.0f;
+    }
+    if (some_fixed_intrinsics && cfg.est_focal)
+        std::fprintf(stderr, "[mi_pba] per-camera SetFixedIntrinsic() is ignored; use SetFixedIntrinsics(true) for all cameras\n");
+    for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) xyz[(size_t)i * 3 + r] = o.pts[i].xyz[r];
+    for (size_t k = 0; k < o.nproj; ++k) { xy[2 * k] = o.meas[k].x; xy[2 * k + 1] = o.meas[k].y; }
+    int ret = 0;
+    double info[MI_BA_INFOSZ] = { 0 };
+    if (mi_ba_set_cameras(e, m, a0.data(), R0.data(), ff.data()) || mi_ba_set_fixed_cameras(e, fixed.data()) ||
+        mi_ba_set_points(e, n, xyz.data()) || mi_ba_set_observations(e, (int64_t)o.nproj, xy.data(), o.ptidx, o.camidx) ||
+        mi_ba_prepare(e) || mi_ba_begin(e)) {
+        std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(e));
+        c.__bundle_return_code = 'E';
+        mi_ba_destroy(e);
+        return 0;
+    }
+    mi_ba_get_info(e, info);
+    c.__initial_mse = (float)(info[0] / (double)o.nproj);
+    o.mse.store(c.__initial_mse);
+    int st = 0;
+    while (!o.abort.load()) {
+        st = mi_ba_step(e);
+        if (st == MI_BA_ERROR) break;
+        mi_ba_get_info(e, info);
+        o.mse.store((float)(info[1] / (double)o.nproj));
+        o.iteration.store((int)info[5]);
+        c.__num_lm_iteration = (int)info[9];
+        if (st == 1) c.__num_lm_success++;
+        if (st == 2) break;
+    }
+    if (st == MI_BA_ERROR) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(e)); c.__bundle_return_code = 'E'; }
+    else {
+        const int stop = (int)info[6];   // sba stop reasons -> PBA return codes (SparseBundleCPU.cpp:3851-3935)
+        c.__bundle_return_code = stop == 7 ? 'E' : stop == 2 ? 'S' : stop == 1 ? 'G' : stop == 3 ? 'M' : 0;
+    }
+    // write the result back into the caller's arrays (TransferDataToHost, SparseBundleCPU.cpp:2660-2674)
+    std::vector<double> a((size_t)m * cnp), R((size_t)m * 9);
+    if (mi_ba_get_params(e, a.data(), xyz.data()) == 0 && mi_ba_get_rotations(e, R.data()) == 0) {
+        for (int j = 0; j < m; ++j) {
+            CameraT &cam = o.cams[j];
+            for (int r = 0; r < 3; ++r) cam.t[r] = (float)a[(size_t)j * cnp + r];
+            for (int r = 0; r < 9; ++r) cam.m[r / 3][r % 3] = (float)R[(size_t)j * 9 + r];
+            if (cfg.est_focal) cam.f = (float)(a[(size_t)j * cnp + 6] / cfg.f_scale);
+        }
+        for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) o.pts[i].xyz[r] = (float)xyz[(size_t)i * 3 + r];
+        ret = c.__num_lm_success;
+    }
+    c.__final_mse = o.mse.load();
+    mi_ba_destroy(e);
+    return ret;
+}
+
+extern "C" ParallelBA *NewParallelBA(ParallelBA::DeviceT device) { return new ParallelBA(device); }
+extern "C" int ParallelBA_GetVersion() { return 105; } // pba.cpp:151-154

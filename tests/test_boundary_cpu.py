@@ -1,0 +1,215 @@
+"""CPU-only checks of the drop-in boundary: the library loads, exports every symbol the headers
+declare (no compute without a GPU), the file formats round-trip, and the shard planner's tables
+are consistent."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, pkg
+from helpers import model_lib, read_model, vsfm_scene, write_nvm
+
+
+def test_library_exports_every_declared_symbol():
+    L = pkg("capi").lib()
+    names = set()
+    for h in ("mi_ba.h", "mi_model.h", "mi_sfm.h"):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(mi_[a-z_0-9]+|run_sfm)\s*\(", txt))
+    names |= {"NewParallelBA", "ParallelBA_GetVersion"}
+    assert len(names) > 40
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    L.ParallelBA_GetVersion.restype = C.c_int
+    assert L.ParallelBA_GetVersion() == 105            # pba.cpp:151-154
+
+
+def test_parallelba_has_the_reference_cxx_abi():
+    """mangled names of class ParallelBA = those of the reference's own libpba (symbol table data)"""
+    import subprocess
+    want = set(open(os.path.join(GOLDEN, "ref_pba_symbols.txt")).read().split())
+    out = subprocess.check_output(["nm", "-D", pkg("capi").LIB_PATH]).decode()
+    have = {l.split()[-1] for l in out.splitlines() if " T _ZN10ParallelBA" in l}
+    assert want <= have, sorted(want - have)
+
+
+def test_no_gpu_is_a_loud_error():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    capi = pkg("capi")
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        capi.Engine()
+
+
+def test_nvm_round_trip(tmp_path):
+    L = model_lib()
+    sc = vsfm_scene(m=8, n=120, d=4, seed=4)
+    a = str(tmp_path / "a.nvm"); b = str(tmp_path / "b.nvm")
+    write_nvm(a, sc)
+    h = L.mi_model_load_nvm(a.encode())
+    assert h, L.mi_model_last_error()
+    mdl = read_model(L, h)
+    assert mdl["f"].shape == (8,) and mdl["xyz"].shape == (120, 3) and len(mdl["pt"]) == sc.nobs
+    assert np.allclose(mdl["xy"], sc.x, rtol=1e-11) and np.array_equal(mdl["cam"], sc.obs_cam)
+    assert np.array_equal(mdl["pt"], sc.obs_pt()) and np.array_equal(mdl["fid"], 1000 + sc.obs_pt())
+    assert np.allclose(mdl["R"], sc.R0, atol=1e-11) and np.allclose(mdl["t"], sc.p0[:8 * 7].reshape(8, 7)[:, :3], rtol=1e-11)
+    # host-side RMSE of the loaded model = the oracle's cost function
+    from oracle import Oracle
+    assert abs(L.mi_model_rmse(h) - np.sqrt(Oracle().cost(sc, sc.p0) / sc.nobs)) < 1e-8
+    assert L.mi_model_save_nvm(h, b.encode()) == 0
+    h2 = L.mi_model_load_nvm(b.encode())
+    m2 = read_model(L, h2)
+    for k in mdl:
+        assert np.allclose(mdl[k], m2[k], rtol=1e-11, atol=1e-11), k
+    L.mi_model_free(h); L.mi_model_free(h2)
+    assert not L.mi_model_load_nvm(str(tmp_path / "missing.nvm").encode())
+
+
+def test_bal_round_trip_and_convention(tmp_path):
+    """BAL text is the -z (Bundler) camera; the loader flips it to +z exactly as LoadBundlerModel does"""
+    L = model_lib()
+    sc = pkg("scene").make_scene("x", m=7, n=90, d=3, seed=6, explicit_centers=0)      # Bundler frame, t-form
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    a = sc.p0[:m * cnp].reshape(m, cnp); X = sc.p0[m * cnp:].reshape(n, 3)
+    w = pkg("scene").log_so3(sc.R0.reshape(m, 3, 3))
+    path = str(tmp_path / "p.txt")
+    order = np.random.default_rng(0).permutation(sc.nobs)                              # BAL need not be sorted by point
+    with open(path, "w") as fo:
+        fo.write("%d %d %d\n" % (m, n, sc.nobs))
+        pt = sc.obs_pt()
+        for o in order:
+            fo.write("%d %d %.12g %.12g\n" % (sc.obs_cam[o], pt[o], sc.x[o, 0], sc.x[o, 1]))
+        for j in range(m):
+            fo.write(" ".join("%.14g" % v for v in (*w[j], *a[j, :3], a[j, 6] / 0.001, 0.0, 0.0)) + "\n")
+        for i in range(n):
+            fo.write("%.12g %.12g %.12g\n" % tuple(X[i]))
+    h = L.mi_model_load_bal(path.encode())
+    assert h, L.mi_model_last_error()
+    mdl = read_model(L, h)
+    assert np.all(np.diff(mdl["pt"]) >= 0)                                             # regrouped by point
+    F = np.diag([1.0, -1.0, -1.0])
+    assert np.allclose(mdl["R"].reshape(m, 3, 3), F @ sc.R0.reshape(m, 3, 3), atol=1e-9)
+    assert np.allclose(mdl["t"], a[:, :3] @ F, atol=1e-12)
+    # same reprojection error in both conventions
+    from oracle import Oracle
+    assert abs(L.mi_model_rmse(h) - np.sqrt(Oracle().cost(sc, sc.p0) / sc.nobs)) < 1e-7
+    out = str(tmp_path / "q.txt")
+    assert L.mi_model_save_bal(h, out.encode()) == 0
+    h2 = L.mi_model_load_bal(out.encode())
+    m2 = read_model(L, h2)
+    for k in ("f", "R", "t", "xyz", "xy", "pt", "cam"):
+        assert np.allclose(mdl[k], m2[k], rtol=1e-9, atol=1e-9), k
+    L.mi_model_free(h); L.mi_model_free(h2)
+
+
+def _check_plan(sc, rank=0, world=1, tmb=0):
+    capi = pkg("capi")
+    pl = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam, rank, world, tmb)
+    st = pl.stats()
+    g = {k: pl.get(k) for k in ("perm", "obs_cam", "obs_pt", "obs_src", "pt_obs", "batch_obs", "batch_pt", "batch_pair", "tile_batch",
+                                "tile_slot", "slot_gblk", "tile_cslot", "cslot_cam", "pair", "pair_gblk", "obs_cslot", "up_row",
+                                "up_col", "bsr_row", "bsr_col", "bsr_src", "bsr_trans", "tile_mode")}
+    assert sorted(g["perm"]) == list(range(sc.n))
+    # observations: a permutation of this shard's original observations, cameras ascending inside a point
+    assert np.array_equal(sc.obs_cam[g["obs_src"]], g["obs_cam"])
+    pts_local = g["perm"][st["pt_begin"]:st["pt_end"]]
+    assert np.array_equal(sc.obs_pt()[g["obs_src"]], pts_local[g["obs_pt"]])
+    # upper pattern lookup
+    up = {}
+    for j in range(sc.m):
+        for q in range(g["up_row"][j], g["up_row"][j + 1]):
+            up[(j, g["up_col"][q])] = q
+    # full pattern is symmetric and points at the right upper block
+    for j in range(sc.m):
+        cols = g["bsr_col"][g["bsr_row"][j]:g["bsr_row"][j + 1]]
+        assert np.all(np.diff(cols) > 0)
+        for q in range(g["bsr_row"][j], g["bsr_row"][j + 1]):
+            k = g["bsr_col"][q]
+            assert g["bsr_src"][q] == up[(min(j, k), max(j, k))] and g["bsr_trans"][q] == (k < j)
+    # pairs: every (a <= b) pair of every point exactly once, slot / gblk = the (cam_a, cam_b) block
+    nb, seen = len(g["batch_obs"]) - 1, 0
+    tile_of_batch = np.repeat(np.arange(len(g["tile_batch"]) - 1), np.diff(g["tile_batch"]))
+    npair_lds = int(g["batch_pair"][st["nbatch"] - st["nbatch_direct"]]) if st["nbatch_direct"] < st["nbatch"] or True else 0
+    for b in range(nb):
+        o0, o1 = g["batch_obs"][b], g["batch_obs"][b + 1]
+        assert 0 < o1 - o0 <= 64 and g["batch_pt"][b + 1] - g["batch_pt"][b] <= 32
+        t = tile_of_batch[b]
+        lds = g["tile_mode"][t] == 1
+        ents = g["pair"][g["batch_pair"][b]:g["batch_pair"][b + 1]]
+        if lds:
+            assert len(ents) % 64 == 0
+        got = set()
+        for q, e in enumerate(ents):
+            if e == 0xFFFFFFFF:
+                assert lds
+                continue
+            la, lb = int(e & 63), int((e >> 6) & 63)
+            assert la <= lb < o1 - o0 and g["obs_pt"][o0 + la] == g["obs_pt"][o0 + lb]
+            ja, jb = g["obs_cam"][o0 + la], g["obs_cam"][o0 + lb]
+            if lds:
+                blk = g["slot_gblk"][g["tile_slot"][t] + (e >> 12)]
+                assert (e >> 12) < g["tile_slot"][t + 1] - g["tile_slot"][t] <= 55
+                assert g["cslot_cam"][g["tile_cslot"][t] + g["obs_cslot"][o0 + la]] == ja
+            else:
+                blk = g["pair_gblk"][g["batch_pair"][b] + q - npair_lds]
+            assert blk == up[(ja, jb)]
+            got.add((la, lb))
+        want = set()
+        for p in range(g["batch_pt"][b], g["batch_pt"][b + 1]):
+            s, e_ = g["pt_obs"][p] - o0, g["pt_obs"][p + 1] - o0
+            want |= {(a, c) for a in range(s, e_) for c in range(a, e_)}
+        assert got == want
+        seen += o1 - o0
+    assert seen + sum(np.diff(g["pt_obs"])[pl.get("long_pts")]) == st["nobs_local"]
+    return st, g
+
+
+def test_plan_tables_coherent_scene():
+    sc = pkg("scene").make_scene("C1")
+    st, g = _check_plan(sc)
+    assert st["nbatch_direct"] == 0 and st["npts_local"] == sc.n and st["nb_upper"] == len(g["up_col"])
+
+
+def test_plan_tables_ragged_scene():
+    """track lengths 1..20 (LDS tiles and direct tiles), tiny tile budget"""
+    scene = pkg("scene")
+    rng = np.random.default_rng(1)
+    base = scene.make_scene("x", m=40, n=500, d=20, seed=2, strides=(1,))
+    keep = [np.sort(rng.permutation(np.arange(base.pt_ptr[i], base.pt_ptr[i + 1]))[:rng.integers(1, 21)]) for i in range(base.n)]
+    sel = np.concatenate(keep)
+    sc = scene.Scene(n=base.n, m=base.m, cnp=7, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0,
+                     pt_ptr=np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int32),
+                     obs_cam=base.obs_cam[sel], x=base.x[sel], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true)
+    st, g = _check_plan(sc, tmb=3)
+    assert 0 < st["nbatch_direct"] < st["nbatch"]
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_shards_partition_the_points(world):
+    sc = pkg("scene").make_scene("C1")
+    capi = pkg("capi")
+    owned, pattern = [], None
+    for r in range(world):
+        st, g = _check_plan(sc, r, world)
+        owned.append(g["perm"][st["pt_begin"]:st["pt_end"]])
+        pat = (tuple(g["up_row"]), tuple(g["up_col"]))
+        assert pattern in (None, pat)              # every rank derives the same block pattern of S
+        pattern = pat
+    allp = np.concatenate(owned)
+    assert len(allp) == sc.n and len(set(allp)) == sc.n
+    sizes = [len(o) for o in owned]
+    assert max(sizes) - min(sizes) <= 0.1 * sc.n / world + 8
+
+
+def test_plan_rejects_bad_input():
+    capi = pkg("capi")
+    with pytest.raises(ValueError, match="sorted by point"):
+        capi.Plan(3, 2, [0, 2, 1], [0, 0, 1])
+    with pytest.raises(ValueError, match="twice"):
+        capi.Plan(2, 2, [0, 0, 1], [1, 1, 0])
+    with pytest.raises(ValueError, match="out of range"):
+        capi.Plan(2, 2, [0, 1], [0, 5])
