@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cfloat>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace miba {
@@ -52,6 +53,14 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
 
 Engine::~Engine()
 {
+    if (d_dbg_.p) { // diagnostic build: per-phase cycle sums of k_build over the engine's life
+        unsigned long long h[8];
+        if (hipMemcpy(h, d_dbg_.p, 64, hipMemcpyDeviceToHost) == hipSuccess) {
+            double tot = 0; for (auto v : h) tot += (double)v;
+            std::fprintf(stderr, "[mi_ba stamps] k_build cycle shares: prologue %.3f | ph1 %.3f | ph2 %.3f | ph3 %.3f | ph4 %.3f | ph5 %.3f | flush %.3f (total %.3g)\n",
+                         h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, tot);
+        }
+    }
     if (comm_) ncclCommDestroy((ncclComm_t)comm_);
     if (h_scal_) (void)hipHostFree(h_scal_);
     for (auto &ev : ev_) if (ev) (void)hipEventDestroy(ev);
@@ -182,6 +191,9 @@ int Engine::prepare()
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
+    if (std::getenv("MI_BA_STAMPS")) {
+        if (!hipok(d_dbg_.alloc(8), "alloc dbg") || !hipok(hipMemset(d_dbg_.p, 0, 64), "memset dbg")) return MI_BA_ERROR;
+    }
     prepared_ = true;
     if (set_params(h_a0_.data(), h_xyz_.data()) != 0) return MI_BA_ERROR;
     // algorithmic HBM bytes of one k_build launch (DESIGN.md "k_build"): observation stream 25 B,
@@ -239,7 +251,7 @@ bool Engine::allreduce2()
 }
 
 // linearise at the current estimate with damping mu and build the reduced camera system
-bool Engine::linear_phase(double mu)
+bool Engine::linear_phase(double mu, bool want_diag)
 {
     const Plan &pl = plan_;
     const ModelCfg mc = model();
@@ -253,6 +265,7 @@ bool Engine::linear_phase(double mu)
     a.pair = d_pair_.p; a.pair_gblk = d_pair_gblk_.p; a.pair_gblk_base = pl.npair_lds;
     a.m = m_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
     a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc;
+    a.dbg = d_dbg_.p; a.want_diag = want_diag ? 1 : 0;
     (void)hipEventRecord(ev_[0], st_);
     a.tile0 = 0;
     launch_build(st_, cnp, true, pl.ntile_lds, a);
@@ -325,7 +338,7 @@ int Engine::begin()
     mu_ = 0; nu_ = 2; itno_ = 0; stop_ = 0; nfev_ = 1; njev_ = 0; nlss_ = 0; dp_L2_ = DBL_MAX; new_outer_ = true;
     trace.clear();
     // probe pass: cost at p0 and the largest diagonal entry of U, V -> mu0 = tau * max (sba_levmar.c:1124-1128)
-    if (!linear_phase(1.0) || !read_scalars()) return MI_BA_ERROR;
+    if (!linear_phase(1.0, true) || !read_scalars()) return MI_BA_ERROR;
     p_eL2_ = init_p_eL2_ = h_scal_[SC_COST];
     maxdiag_ = std::max(std::max(h_scal_[SC_MAXDIAG_U], h_scal_[SC_MAXDIAG_V]), DBL_MIN);
     eab_inf_ = std::max(h_scal_[SC_EA_INF], h_scal_[SC_EB_INF]);
@@ -348,7 +361,7 @@ int Engine::step()
     const bool stops = !cfg.disable_stops;
     if (new_outer_) { ++njev_; new_outer_ = false; }
     const double mu = mu_;
-    if (!linear_phase(mu) || !solve_phase(mu, nullptr) || !read_scalars()) return MI_BA_ERROR;
+    if (!linear_phase(mu, false) || !solve_phase(mu, nullptr) || !read_scalars()) return MI_BA_ERROR;
     float ms = 0;
     if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) { timing.build_ms += ms; timing.build_launches += 1; }
     if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) { timing.pcg_ms += ms; timing.pcg_solves += 1; }
@@ -358,7 +371,8 @@ int Engine::step()
     p_eL2_ = s[SC_COST];
     p_L2_ = s[SC_PL2_CAMS] + s[SC_PL2_PTS] + pl2_inactive_;
     eab_inf_ = std::max(s[SC_EA_INF], s[SC_EB_INF]);
-    maxdiag_ = std::max(std::max(s[SC_MAXDIAG_U], s[SC_MAXDIAG_V]), DBL_MIN);
+    // max diag(U, V) enters mu0 (begin) and info[4] only; diag U is not accumulated per trial, so
+    // info[4] is normalised by the value of the last linearisation that measured it
     int ret = 0;
     auto end_outer = [&]() { // tail of the outer for-loop body, sba_levmar.c:1614 + the ++itno
         if (p_eL2_ <= eps3_sq && stops) stop_ = 5;
@@ -432,6 +446,11 @@ int Engine::run(double info[MI_BA_INFOSZ])
         if (r == MI_BA_ERROR) return MI_BA_ERROR;
     }
     if (itno_ >= cfg.itmax) stop_ = 3;
+    // info[4] = mu / max diag(U, V) at the final estimate (sba_levmar.c:2033-2043): one more linearisation
+    if (info && stop_ != 7) {
+        if (!linear_phase(1.0, true) || !read_scalars()) return MI_BA_ERROR;
+        maxdiag_ = std::max(std::max(h_scal_[SC_MAXDIAG_U], h_scal_[SC_MAXDIAG_V]), DBL_MIN);
+    }
     if (info) fill_info(info);
     return stop_ != 7 ? itno_ : MI_BA_ERROR;
 }
@@ -486,7 +505,7 @@ int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double 
 {
     if (!prepared_) { err = "debug_linearize: prepare first"; return MI_BA_ERROR; }
     if (cfg.world > 1 && (eb || V)) { err = "debug_linearize: point outputs need world == 1"; return MI_BA_ERROR; }
-    if (!linear_phase(mu) || !read_scalars()) return MI_BA_ERROR;
+    if (!linear_phase(mu, true) || !read_scalars()) return MI_BA_ERROR;
     const Plan &pl = plan_;
     if (cost) *cost = h_scal_[SC_COST];
     const size_t vec = (size_t)m_ * kCP;

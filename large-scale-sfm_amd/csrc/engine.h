@@ -68,7 +68,7 @@ public:
 private:
     bool fail(const std::string &msg) { err = msg; return false; }
     bool hipok(hipError_t e, const char *what);
-    bool linear_phase(double mu);                 // cam_prep .. build .. all-reduce .. finalize .. block_inv
+    bool linear_phase(double mu, bool want_diag);                 // cam_prep .. build .. all-reduce .. finalize .. block_inv
     bool solve_phase(double mu, double *dB_dev);  // pcg .. cam_update .. backsub .. all-reduce
     bool read_scalars();
     bool allreduce1();
@@ -97,6 +97,7 @@ private:
     DevBuf<long long> d_batch_pair_;
     DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_;
     DevBuf<unsigned> d_pair_, d_pair_gblk_;
+    DevBuf<unsigned long long> d_dbg_;
     DevBuf<double2> d_obs_xy_;
     // device: state
     DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_Minv_, d_E_, d_dA_, d_dB_,

@@ -52,9 +52,10 @@ struct BuildArgs {
     const double2 *obs_xy;
     const unsigned *pair, *pair_gblk;
     long long pair_gblk_base;
-    int tile0, m;
+    int tile0, m, want_diag;                // want_diag: also accumulate diag U_j (mu0 and info[4] only)
     const double *cam_lin, *pts;
     double mu;
+    unsigned long long *dbg;                // diagnostic stamp sums (MIBA_STAMPS build), else NULL
     double *S_up, *camvec, *ptout, *part;   // part: [ntile][kPartW] cost, |X|^2, -, -, |eb|inf, max diag V, singular
     ModelCfg cfg;
 };

@@ -31,6 +31,15 @@ __device__ __forceinline__ void atomic_max_pos(double *p, double v)
 {
     atomicMax(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v));
 }
+// LDS hand-off inside a ONE-wavefront workgroup: the LDS unit executes a wave's DS instructions in
+// issue order, so all that is needed is that the compiler keeps the order and that outstanding DS
+// results have landed.  Unlike __syncthreads() this does NOT wait for vmcnt(0): global loads issued
+// for the next batch and the ptout / pts_new stores stay in flight across the phases.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ void gadd(double *p, double v) { unsafeAtomicAdd(p, v); } // global_atomic_add_f64
 __device__ __forceinline__ void ladd(double *p, double v)                           // ds_add_f64
 {
@@ -196,14 +205,103 @@ __global__ void k_cam_prep(int m, int cnp, ModelCfg cfg, const double *__restric
 //              flushed once per tile as contiguous f64 atomics (one S block = one wave instruction).
 //   direct mode (points with > kMaxViewsLds views): every pair adds straight into HBM.
 // ------------------------------------------------------------------------------------------
+// what one lane needs before it can start a batch; filled one batch ahead (software pipeline:
+// the kernel runs one wavefront per SIMD, so nothing else hides the global-load latency)
+template <bool LDS>
+struct BatchRegs {
+    int o0, nob, p0, npt;
+    long long q0, q1;
+    int j, ip, cs;
+    double2 xy;
+    unsigned ent[LDS ? kMaxRounds : 1];   // this lane's pair entry of every round (LDS tiles)
+};
+
+template <bool LDS>
+__device__ __forceinline__ void load_batch_level1(const BuildArgs &g, int b, int lane, BatchRegs<LDS> &r)
+{
+    r.o0 = g.batch_obs[b]; r.nob = g.batch_obs[b + 1] - r.o0;
+    r.p0 = g.batch_pt[b]; r.npt = g.batch_pt[b + 1] - r.p0;
+    r.q0 = g.batch_pair[b]; r.q1 = g.batch_pair[b + 1];
+    r.j = 0; r.ip = r.p0; r.cs = 0; r.xy = make_double2(0.0, 0.0);
+    if (lane < r.nob) {
+        const int o = r.o0 + lane;
+        r.j = g.obs_cam[o]; r.ip = g.obs_pt[o]; r.xy = g.obs_xy[o];
+        if constexpr (LDS) r.cs = g.obs_cslot[o];
+    }
+    if constexpr (LDS) {
+#pragma unroll
+        for (int k = 0; k < kMaxRounds; ++k) {
+            const long long q = r.q0 + (long long)k * kWave + lane;
+            r.ent[k] = (q < r.q1) ? g.pair[q] : kPairInvalid;
+        }
+    }
+}
+
+__device__ __forceinline__ void load_cam_record(const BuildArgs &g, int j, double cl[kCamLin])
+{
+    const double2 *src = reinterpret_cast<const double2 *>(g.cam_lin + (size_t)j * kCamLin);
+#pragma unroll
+    for (int k = 0; k < kCamLin / 2; ++k) { const double2 v = src[k]; cl[2 * k] = v.x; cl[2 * k + 1] = v.y; }
+}
+
+// one pair: T = (delta_ab I - G_a B_b^T) A_b with G_a = B_a V*^-1 of the pair's point
+template <int CNP, int SA, int SB, int SV>
+__device__ __forceinline__ void pair_block(const double *sA, const double *sB, const double *sv, int la, int lb,
+                                           double T0[CNP], double T1[CNP])
+{
+    const double *Ba = sB + la * SB, *Bb = sB + lb * SB;
+    const double i00 = sv[0], i01 = sv[1], i02 = sv[2], i11 = sv[3], i12 = sv[4], i22 = sv[5];
+    double G[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        G[r][0] = Ba[3 * r] * i00 + Ba[3 * r + 1] * i01 + Ba[3 * r + 2] * i02;
+        G[r][1] = Ba[3 * r] * i01 + Ba[3 * r + 1] * i11 + Ba[3 * r + 2] * i12;
+        G[r][2] = Ba[3 * r] * i02 + Ba[3 * r + 1] * i12 + Ba[3 * r + 2] * i22;
+    }
+    double M00 = G[0][0] * Bb[0] + G[0][1] * Bb[1] + G[0][2] * Bb[2];
+    double M01 = G[0][0] * Bb[3] + G[0][1] * Bb[4] + G[0][2] * Bb[5];
+    double M10 = G[1][0] * Bb[0] + G[1][1] * Bb[1] + G[1][2] * Bb[2];
+    double M11 = G[1][0] * Bb[3] + G[1][1] * Bb[4] + G[1][2] * Bb[5];
+    const double dg = (la == lb) ? 1.0 : 0.0;
+    M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
+    const double *Ab = sA + lb * SA;
+#pragma unroll
+    for (int c = 0; c < CNP; ++c) {
+        const double a0 = Ab[c], a1 = Ab[CNP + c];
+        T0[c] = fma(M01, a1, M00 * a0);
+        T1[c] = fma(M11, a1, M10 * a0);
+    }
+}
+
+// Diagnostic build only (make stamp): per-phase cycle shares through s_memtime, summed per
+// workgroup into g.dbg (cdna_hip_programming.md section 7, "In-kernel stamps").  Never timed.
+#ifdef MIBA_STAMPS
+#define STAMP(i)                                                                                   \
+    do {                                                                                           \
+        unsigned long long t_;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        stamp_acc[i] += t_ - stamp_prev;                                                           \
+        stamp_prev = t_;                                                                           \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <int CNP, bool LDS>
 __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
 {
+#ifdef MIBA_STAMPS
+    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
     constexpr int SA = 2 * CNP + 1;           // odd strides (in doubles) keep ds_read_b64 conflict-free
-    constexpr int SB = 9, SV = 9;             // sB row: B (6), e (2), local point index (1)
-    constexpr int BLK = CNP * CNP, SS = BLK | 1, SC = (3 * CNP) | 1;
+    constexpr int SB = 9, SV = 9;             // sB row: B (6), e (2), local point index (direct tiles)
+    constexpr int BLK = CNP * CNP, SS = BLK | 1, NCV = 2 * CNP, SC = (3 * CNP) | 1;
     __shared__ double sA[kWave * SA], sB[kWave * SB], sV[kMaxPtsBatch * SV];
     __shared__ double sS[LDS ? kNSlot * SS : 1], sC[LDS ? kNCSlot * SC : 1];
+    __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
 
     const int lane = threadIdx.x;
     const int tile = g.tile0 + blockIdx.x;
@@ -216,66 +314,85 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         for (int i = lane; i < ncs * SC; i += kWave) sC[i] = 0.0;
     }
     double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0;
-    double acc[LDS ? BLK : 1];                // this lane's register-resident block (LDS mode)
-    int cur_slot = -1;
+    // register-resident accumulators (LDS tiles): this lane's S block and this lane's camera vectors
+    // (ea_j, E_j); both follow the lane for as long as its block / camera slot does not change
+    double acc[LDS ? BLK : 1], cacc[LDS ? NCV : 1];
+    int cur_slot = -1, cur_cs = -1;
     if constexpr (LDS) {
 #pragma unroll
         for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NCV; ++i) cacc[i] = 0.0;
     }
 
-    for (int b = g.tile_batch[tile]; b < g.tile_batch[tile + 1]; ++b) {
-        const int o0 = g.batch_obs[b], nob = g.batch_obs[b + 1] - o0;
-        const int p0 = g.batch_pt[b], npt = g.batch_pt[b + 1] - p0;
+    const int b_begin = g.tile_batch[tile], b_end = g.tile_batch[tile + 1];
+    BatchRegs<LDS> cur, nxt;
+    double X[3];
+    load_batch_level1<LDS>(g, b_begin, lane, cur);
+    X[0] = g.pts[3 * (size_t)cur.ip]; X[1] = g.pts[3 * (size_t)cur.ip + 1]; X[2] = g.pts[3 * (size_t)cur.ip + 2];
+    nxt = cur;
+    STAMP(0); // prologue: LDS clear, first batch loads issued
+
+    for (int b = b_begin; b < b_end; ++b) {
+        const bool have_next = b + 1 < b_end;
+        const int nob = cur.nob, p0 = cur.p0, npt = cur.npt;
         const bool active = lane < nob;
         double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
-        int j = 0, lp = 0, cs = 0;
-        // ---- phase 1
-        if (active) {
-            const int o = o0 + lane;
-            j = g.obs_cam[o];
-            const int ip = g.obs_pt[o];
-            lp = ip - p0;
-            if constexpr (LDS) cs = g.obs_cslot[o];
-            const double2 xy = g.obs_xy[o];
-            const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
-            linearize_obs<CNP>(cfg, g.cam_lin + (size_t)j * kCamLin, X, xy, g.cam_fixed[j] != 0, e, A, B);
-            cost += e[0] * e[0] + e[1] * e[1];
+        const int j = cur.j, lp = cur.ip - p0, cs = cur.cs;
+        bool head = false;
+        // ---- phase 1 (the camera records are L2-resident: 192 B x m)
+        {
+            double cl[kCamLin];
+            load_cam_record(g, j, cl);
+            if (have_next) load_batch_level1<LDS>(g, b + 1, lane, nxt);   // streams + pair entries of the next batch
+            if (active) {
+                linearize_obs<CNP>(cfg, cl, X, cur.xy, g.cam_fixed[j] != 0, e, A, B);
+                cost += e[0] * e[0] + e[1] * e[1];
 #pragma unroll
-            for (int t = 0; t < CNP; ++t) { sA[lane * SA + t] = A[0][t]; sA[lane * SA + CNP + t] = A[1][t]; }
+                for (int t = 0; t < CNP; ++t) { sA[lane * SA + t] = A[0][t]; sA[lane * SA + CNP + t] = A[1][t]; }
 #pragma unroll
-            for (int t = 0; t < 3; ++t) { sB[lane * SB + t] = B[0][t]; sB[lane * SB + 3 + t] = B[1][t]; }
-            sB[lane * SB + 6] = e[0]; sB[lane * SB + 7] = e[1]; sB[lane * SB + 8] = (double)lp;
+                for (int t = 0; t < 3; ++t) { sB[lane * SB + t] = B[0][t]; sB[lane * SB + 3 + t] = B[1][t]; }
+                sB[lane * SB + 6] = e[0]; sB[lane * SB + 7] = e[1]; sB[lane * SB + 8] = (double)lp;
+            }
+            // point boundaries without touching memory: observations of a point are consecutive lanes
+            const int lp_prev = __shfl_up(active ? lp : -2, 1);
+            head = active && (lane == 0 || lp != lp_prev);
+            if (head) { sStart[lp] = lane; pl2 += X[0] * X[0] + X[1] * X[1] + X[2] * X[2]; }
+            if (lane == 0) sStart[npt] = nob;
         }
-        __syncthreads();
+        // the next batch's points stream from HBM: issue now, consumed in its phase 1
+        if (have_next) { X[0] = g.pts[3 * (size_t)nxt.ip]; X[1] = g.pts[3 * (size_t)nxt.ip + 1]; X[2] = g.pts[3 * (size_t)nxt.ip + 2]; }
+        wave_lds_sync();
+        STAMP(1);
         // ---- phase 2: V_i upper triangle (00 01 02 11 12 22) and eb_i, 7 points per sweep
         for (int base = 0; base < npt; base += 7) {
             const int qd = lane / 9, comp = lane - 9 * qd, lpp = base + qd;
             if (lane < 63 && lpp < npt) {
-                const int os = g.pt_obs[p0 + lpp] - o0, oe = g.pt_obs[p0 + lpp + 1] - o0;
-                double sum = 0.0;
-                if (comp < 6) {
-                    const int r = comp < 3 ? 0 : (comp < 5 ? 1 : 2);
-                    const int c = comp < 3 ? comp : (comp < 5 ? comp - 2 : 2);
-                    for (int o = os; o < oe; ++o)
-                        sum += sB[o * SB + r] * sB[o * SB + c] + sB[o * SB + 3 + r] * sB[o * SB + 3 + c];
-                } else {
-                    const int r = comp - 6;
-                    for (int o = os; o < oe; ++o) sum += sB[o * SB + r] * sB[o * SB + 6] + sB[o * SB + 3 + r] * sB[o * SB + 7];
+                const int os = sStart[lpp], oe = sStart[lpp + 1];
+                // V(r,c) = sum B0r*B0c + B1r*B1c ; eb(r) = sum B0r*e0 + B1r*e1 : same form, columns (c, 3+c) or (6, 7)
+                const int r = comp < 3 ? 0 : (comp < 5 ? 1 : (comp < 6 ? 2 : comp - 6));
+                const int c0 = comp < 3 ? comp : (comp < 5 ? comp - 2 : (comp < 6 ? 2 : 6));
+                const int c1 = comp < 6 ? c0 + 3 : 7;
+                double s0 = 0.0, s1 = 0.0;
+                int o = os;
+                for (; o + 1 < oe; o += 2) {
+                    const double *r0 = sB + o * SB, *r1 = r0 + SB;
+                    s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0));
+                    s1 = fma(r1[3 + r], r1[c1], fma(r1[r], r1[c0], s1));
                 }
-                sV[lpp * SV + comp] = sum;
+                if (o < oe) { const double *r0 = sB + o * SB; s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0)); }
+                sV[lpp * SV + comp] = s0 + s1;
             }
         }
-        __syncthreads();
-        // ---- phase 3: damped inverse per point (role of sba_symat_invert_BK on a 3x3)
-        if (lane < npt) {
-            const int ip = p0 + lane;
-            double v00 = sV[lane * SV], v01 = sV[lane * SV + 1], v02 = sV[lane * SV + 2];
-            double v11 = sV[lane * SV + 3], v12 = sV[lane * SV + 4], v22 = sV[lane * SV + 5];
-            const double eb0 = sV[lane * SV + 6], eb1 = sV[lane * SV + 7], eb2 = sV[lane * SV + 8];
+        wave_lds_sync();
+        STAMP(2);
+        // ---- phase 3: damped inverse per point (role of sba_symat_invert_BK on a 3x3), by the head lane
+        if (head) {
+            double v00 = sV[lp * SV], v01 = sV[lp * SV + 1], v02 = sV[lp * SV + 2];
+            double v11 = sV[lp * SV + 3], v12 = sV[lp * SV + 4], v22 = sV[lp * SV + 5];
+            const double eb0 = sV[lp * SV + 6], eb1 = sV[lp * SV + 7], eb2 = sV[lp * SV + 8];
             maxdv = fmax(maxdv, fmax(v00, fmax(v11, v22)));
             ebinf = fmax(ebinf, fmax(fabs(eb0), fmax(fabs(eb1), fabs(eb2))));
-            const double X0 = g.pts[3 * (size_t)ip], X1 = g.pts[3 * (size_t)ip + 1], X2 = g.pts[3 * (size_t)ip + 2];
-            pl2 += X0 * X0 + X1 * X1 + X2 * X2;
             v00 += g.mu; v11 += g.mu; v22 += g.mu;
             const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
             const double det = v00 * c00 + v01 * c01 + v02 * c02;
@@ -288,64 +405,58 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
             }
             const double h0 = i00 * eb0 + i01 * eb1 + i02 * eb2, h1 = i01 * eb0 + i11 * eb1 + i12 * eb2,
                          h2 = i02 * eb0 + i12 * eb1 + i22 * eb2;
-            double *sv = sV + lane * SV;
+            double *sv = sV + lp * SV;
             sv[0] = i00; sv[1] = i01; sv[2] = i02; sv[3] = i11; sv[4] = i12; sv[5] = i22; sv[6] = h0; sv[7] = h1; sv[8] = h2;
-            double *po = g.ptout + (size_t)ip * kPtOut;
+            double *po = g.ptout + (size_t)cur.ip * kPtOut;
             po[0] = i00; po[1] = i01; po[2] = i02; po[3] = i11; po[4] = i12; po[5] = i22;
             po[6] = h0; po[7] = h1; po[8] = h2; po[9] = eb0; po[10] = eb1; po[11] = eb2;
         }
-        __syncthreads();
-        // ---- phase 4: camera-side vectors
+        wave_lds_sync();
+        STAMP(3);
+        // ---- phase 4: camera-side vectors ea_j, E_j = A^T (e - B h)  (+ diag U_j on request)
         if (active && !g.cam_fixed[j]) {
             const double *sv = sV + lp * SV;
             double er[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) er[r] = e[r] - (B[r][0] * sv[6] + B[r][1] * sv[7] + B[r][2] * sv[8]);
+            if constexpr (LDS) {
+                if (cs != cur_cs) { // this lane now serves another camera: spill the finished vectors
+                    if (cur_cs >= 0) {
 #pragma unroll
-            for (int t = 0; t < CNP; ++t) {
-                const double vea = A[0][t] * e[0] + A[1][t] * e[1];
-                const double vE = A[0][t] * er[0] + A[1][t] * er[1];
-                const double vdu = A[0][t] * A[0][t] + A[1][t] * A[1][t];
-                if constexpr (LDS) {
-                    ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE); ladd(&sC[cs * SC + 2 * CNP + t], vdu);
-                } else {
-                    gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], vea);
-                    gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], vE);
-                    gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], vdu);
+                        for (int t = 0; t < NCV; ++t) { ladd(&sC[cur_cs * SC + t], cacc[t]); cacc[t] = 0.0; }
+                    }
+                    cur_cs = cs;
+                }
+#pragma unroll
+                for (int t = 0; t < CNP; ++t) {
+                    cacc[t] = fma(A[1][t], e[1], fma(A[0][t], e[0], cacc[t]));
+                    cacc[CNP + t] = fma(A[1][t], er[1], fma(A[0][t], er[0], cacc[CNP + t]));
+                }
+                if (g.want_diag) {
+#pragma unroll
+                    for (int t = 0; t < CNP; ++t) ladd(&sC[cs * SC + 2 * CNP + t], A[0][t] * A[0][t] + A[1][t] * A[1][t]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < CNP; ++t) {
+                    gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], A[0][t] * e[0] + A[1][t] * e[1]);
+                    gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], A[0][t] * er[0] + A[1][t] * er[1]);
+                    if (g.want_diag) gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], A[0][t] * A[0][t] + A[1][t] * A[1][t]);
                 }
             }
         }
+        STAMP(4);
         // ---- phase 5: pair products (reads sA, sB, sV only: no barrier needed after phase 4)
-        for (long long q = g.batch_pair[b] + lane; q < g.batch_pair[b + 1]; q += kWave) {
-            const unsigned ent = g.pair[q];
-            if (LDS && ent == kPairInvalid) continue;
-            const int la = ent & 63, lb = (ent >> 6) & 63;
-            const double *Ba = sB + la * SB, *Bb = sB + lb * SB;
-            const double *sv = sV + (int)Ba[8] * SV;
-            const double i00 = sv[0], i01 = sv[1], i02 = sv[2], i11 = sv[3], i12 = sv[4], i22 = sv[5];
-            double G[2][3];
+        if constexpr (LDS) {
+            const int nrounds = (int)((cur.q1 - cur.q0) / kWave);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                G[r][0] = Ba[3 * r] * i00 + Ba[3 * r + 1] * i01 + Ba[3 * r + 2] * i02;
-                G[r][1] = Ba[3 * r] * i01 + Ba[3 * r + 1] * i11 + Ba[3 * r + 2] * i12;
-                G[r][2] = Ba[3 * r] * i02 + Ba[3 * r + 1] * i12 + Ba[3 * r + 2] * i22;
-            }
-            double M00 = G[0][0] * Bb[0] + G[0][1] * Bb[1] + G[0][2] * Bb[2];
-            double M01 = G[0][0] * Bb[3] + G[0][1] * Bb[4] + G[0][2] * Bb[5];
-            double M10 = G[1][0] * Bb[0] + G[1][1] * Bb[1] + G[1][2] * Bb[2];
-            double M11 = G[1][0] * Bb[3] + G[1][1] * Bb[4] + G[1][2] * Bb[5];
-            const double dg = (la == lb) ? 1.0 : 0.0;
-            M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
-            double T0[CNP], T1[CNP];
-            const double *Ab = sA + lb * SA, *Aa = sA + la * SA;
-#pragma unroll
-            for (int c = 0; c < CNP; ++c) {
-                const double a0 = Ab[c], a1 = Ab[CNP + c];
-                T0[c] = M00 * a0 + M01 * a1;
-                T1[c] = M10 * a0 + M11 * a1;
-            }
-            if constexpr (LDS) {
-                const int slot = (int)(ent >> 12);
+            for (int k = 0; k < kMaxRounds; ++k) {
+                if (k >= nrounds) break;
+                const unsigned ent = cur.ent[k];
+                if (ent == kPairInvalid) continue;
+                const int la = ent & 63, lb = (ent >> 6) & 63, slot = (ent >> 12) & 63, plp = (ent >> 18) & 31;
+                double T0[CNP], T1[CNP];
+                pair_block<CNP, SA, SB, SV>(sA, sB, sV + plp * SV, la, lb, T0, T1);
                 if (slot != cur_slot) { // this lane's block changed: spill the finished one
                     if (cur_slot >= 0) {
                         double *dst = sS + cur_slot * SS;
@@ -354,13 +465,21 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
                     }
                     cur_slot = slot;
                 }
+                const double *Aa = sA + la * SA;
 #pragma unroll
                 for (int r = 0; r < CNP; ++r) {
                     const double a0 = Aa[r], a1 = Aa[CNP + r];
 #pragma unroll
-                    for (int c = 0; c < CNP; ++c) acc[r * CNP + c] += a0 * T0[c] + a1 * T1[c];
+                    for (int c = 0; c < CNP; ++c) acc[r * CNP + c] = fma(a1, T1[c], fma(a0, T0[c], acc[r * CNP + c]));
                 }
-            } else {
+            }
+        } else {
+            for (long long q = cur.q0 + lane; q < cur.q1; q += kWave) {
+                const unsigned ent = g.pair[q];
+                const int la = ent & 63, lb = (ent >> 6) & 63;
+                double T0[CNP], T1[CNP];
+                pair_block<CNP, SA, SB, SV>(sA, sB, sV + (int)sB[la * SB + 8] * SV, la, lb, T0, T1);
+                const double *Aa = sA + la * SA;
                 double *dst = g.S_up + (size_t)g.pair_gblk[q - g.pair_gblk_base] * (kCP * kCP);
 #pragma unroll
                 for (int r = 0; r < CNP; ++r) {
@@ -370,7 +489,9 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
+        STAMP(5);
+        if (have_next) cur = nxt;
     }
     // ---- flush: registers -> LDS table -> HBM (one S block = one contiguous f64 atomic wave instruction)
     if constexpr (LDS) {
@@ -379,19 +500,30 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
 #pragma unroll
             for (int i = 0; i < BLK; ++i) ladd(&dst[i], acc[i]);
         }
-        __syncthreads();
-        const int s0 = g.tile_slot[tile], c0 = g.tile_cslot[tile];
-        if (lane < BLK) {
-            const int r = lane / CNP, c = lane - r * CNP;
-            for (int s = 0; s < nslots; ++s)
-                gadd(&g.S_up[(size_t)g.slot_gblk[s0 + s] * (kCP * kCP) + r * kCP + c], sS[s * SS + lane]);
+        if (cur_cs >= 0) {
+#pragma unroll
+            for (int t = 0; t < NCV; ++t) ladd(&sC[cur_cs * SC + t], cacc[t]);
         }
-        if (lane < 3 * CNP) {
-            const int which = lane / CNP, t = lane - which * CNP;
-            for (int c = 0; c < ncs; ++c)
-                gadd(&g.camvec[((size_t)which * g.m + g.cslot_cam[c0 + c]) * kCP + t], sC[c * SC + lane]);
+        wave_lds_sync();
+        // slot -> block and camera-slot -> camera tables: one coalesced load, then lane broadcasts
+        const int my_gblk = lane < nslots ? g.slot_gblk[g.tile_slot[tile] + lane] : 0;
+        const int my_cam = lane < ncs ? g.cslot_cam[g.tile_cslot[tile] + lane] : 0;
+        const int r = lane / CNP, c = lane - r * CNP;
+        for (int s = 0; s < nslots; ++s) {
+            const int gb = __shfl(my_gblk, s);
+            if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + r * kCP + c], sS[s * SS + lane]);
+        }
+        const int which = lane / CNP, t = lane - which * CNP;
+        for (int k = 0; k < ncs; ++k) {
+            const int cam = __shfl(my_cam, k);
+            if (lane < 3 * CNP) gadd(&g.camvec[((size_t)which * g.m + cam) * kCP + t], sC[k * SC + lane]);
         }
     }
+    STAMP(6); // flush
+#ifdef MIBA_STAMPS
+    if (lane == 0 && g.dbg)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g.dbg[i], stamp_acc[i]);
+#endif
     cost = wave_sum(cost); pl2 = wave_sum(pl2);
     ebinf = wave_max(ebinf); maxdv = wave_max(maxdv); sing = wave_max(sing);
     if (lane == 0) { // one partial row per tile; k_reduce_partials folds them (no same-address atomics)
@@ -602,17 +734,35 @@ __global__ __launch_bounds__(64) void k_pcg_spmv(const PcgArgs a)
     const double *pprev = (a.it & 1) ? a.p0 : a.p1;   // p_{it-1}
     double *pcur = (a.it & 1) ? a.p1 : a.p0;          // p_it (it = 0: p0 = z, written by k_pcg_init)
     const double beta = a.it ? rz / a.rz_hist[a.it - 1] : 0.0;
-    double acc = 0.0;
-    for (int q = a.bsr_row[j]; q < a.bsr_row[j + 1]; ++q) {
-        const int k = a.bsr_col[q];
-        const double pk = a.it ? a.z[k * 8 + c] + beta * pprev[k * 8 + c] : a.z[k * 8 + c];
-        acc += a.S[(size_t)q * 64 + lane] * pk;
+    // four independent 512-B block loads in flight per wavefront: with one load at a time the chip holds
+    // ~0.5 MB in flight and the MALL-resident S streams at only ~3 TB/s
+    const double *__restrict__ Sv = a.S;
+    const double *__restrict__ zv = a.z;
+    const int q0 = a.bsr_row[j], q1 = a.bsr_row[j + 1];
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    int q = q0;
+    for (; q + 3 < q1; q += 4) {
+        const int k0 = a.bsr_col[q], k1 = a.bsr_col[q + 1], k2 = a.bsr_col[q + 2], k3 = a.bsr_col[q + 3];
+        const double s0 = Sv[(size_t)q * 64 + lane], s1 = Sv[(size_t)(q + 1) * 64 + lane];
+        const double s2 = Sv[(size_t)(q + 2) * 64 + lane], s3 = Sv[(size_t)(q + 3) * 64 + lane];
+        double p0 = zv[k0 * 8 + c], p1 = zv[k1 * 8 + c], p2 = zv[k2 * 8 + c], p3 = zv[k3 * 8 + c];
+        if (a.it) {
+            p0 = fma(beta, pprev[k0 * 8 + c], p0); p1 = fma(beta, pprev[k1 * 8 + c], p1);
+            p2 = fma(beta, pprev[k2 * 8 + c], p2); p3 = fma(beta, pprev[k3 * 8 + c], p3);
+        }
+        acc0 = fma(s0, p0, acc0); acc1 = fma(s1, p1, acc1); acc2 = fma(s2, p2, acc2); acc3 = fma(s3, p3, acc3);
     }
+    for (; q < q1; ++q) {
+        const int k = a.bsr_col[q];
+        const double pk = a.it ? fma(beta, pprev[k * 8 + c], zv[k * 8 + c]) : zv[k * 8 + c];
+        acc0 = fma(Sv[(size_t)q * 64 + lane], pk, acc0);
+    }
+    double acc = (acc0 + acc1) + (acc2 + acc3);
     acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
     double part = 0.0;
     if (c == 0) {
         const int idx = j * 8 + r;
-        const double pj = a.it ? a.z[idx] + beta * pprev[idx] : a.z[idx];
+        const double pj = a.it ? fma(beta, pprev[idx], a.z[idx]) : a.z[idx];   // same expression as in the products above
         a.q[idx] = acc;
         pcur[idx] = pj;
         part = acc * pj;
@@ -723,7 +873,7 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
 #pragma unroll
             for (int t = 0; t < 3; ++t) sT[lane * 3 + t] = B[0][t] * w0 + B[1][t] * w1;
         }
-        __syncthreads();
+        wave_lds_sync();
         if (lane < npt) {
             const int ip = p0 + lane;
             const int os = g.pt_obs[ip] - o0, oe = g.pt_obs[ip + 1] - o0;
@@ -740,7 +890,7 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
             dl += d0 * (g.mu * d0 + po[9]) + d1 * (g.mu * d1 + po[10]) + d2 * (g.mu * d2 + po[11]);
             dp2 += d0 * d0 + d1 * d1 + d2 * d2;
         }
-        __syncthreads();
+        wave_lds_sync();
         if (active) {
             const double Xn[3] = { sX[lp * 3], sX[lp * 3 + 1], sX[lp * 3 + 2] };
             double u, v;
@@ -753,7 +903,7 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
             if (!(e[1] < g.eps5 && en1 < g.eps5)) pc = fmax(pc, fabs((e[1] - en1) / e[1]));
             if (pc == pc) pct = fmax(pct, pc); // skip 0/0 when both residuals vanish
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     cn = wave_sum(cn); dl = wave_sum(dl); dp2 = wave_sum(dp2); pct = wave_max(pct);
     if (lane == 0) {

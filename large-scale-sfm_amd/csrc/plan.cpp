@@ -201,8 +201,10 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     std::vector<uint32_t> round_buf;  // pair entries of the round being filled (LDS tiles)
     bool rounds_mode = true;
     int pts_in_batch = 0;
+    int rounds_in_batch = 0;
     auto flush_round = [&]() {
         if (round_buf.empty()) return;
+        rounds_in_batch++;
         round_buf.resize(kWave, kPairInvalid);
         pl.pair.insert(pl.pair.end(), round_buf.begin(), round_buf.end());
         round_buf.clear();
@@ -213,7 +215,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         pl.batch_obs.push_back(pl.pt_obs[t_end]);
         pl.batch_pt.push_back(t_end);
         pl.batch_pair.push_back((int64_t)pl.pair.size());
-        cur_obs = 0; pts_in_batch = 0;
+        cur_obs = 0; pts_in_batch = 0; rounds_in_batch = 0;
         batches_in_tile++;
     };
     auto close_tile = [&](uint8_t mode) {
@@ -233,7 +235,9 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         if (point_class(d) != 0) break;
         const int *c = pl.obs_cam.data() + pl.pt_obs[t];
         bool same_sig = (d == sig_d && sig_cams && std::memcmp(sig_cams, c, sizeof(int) * d) == 0);
-        if (cur_obs + d > kWave || pts_in_batch >= kMaxPtsBatch) {
+        // a point that would open a 9th pair round starts a new batch
+        const bool round_full = (int)round_buf.size() + d * (d + 1) / 2 > kWave;
+        if (cur_obs + d > kWave || pts_in_batch >= kMaxPtsBatch || (round_full && rounds_in_batch + 1 >= kMaxRounds)) {
             close_batch(t);
             if (batches_in_tile >= tile_max_batches) { close_tile(1); same_sig = false; }
         }
@@ -275,7 +279,8 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         for (int a = 0; a < d; ++a) {
             pl.obs_cslot[pl.pt_obs[t] + a] = (uint8_t)cmap[c[a]];
             for (int b = a; b < d; ++b)
-                round_buf.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6) | ((uint32_t)sig_slots[q++] << 12));
+                round_buf.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6) | ((uint32_t)sig_slots[q++] << 12) |
+                                    ((uint32_t)pts_in_batch << 18));
         }
         cur_obs += d; pts_in_batch++;
     }

@@ -26,6 +26,7 @@ constexpr int kWave = 64;        // observations per batch
 constexpr int kNSlot = 55;       // S-block accumulators per LDS tile (55 = pairs of a 10-view point)
 constexpr int kNCSlot = 24;      // camera accumulators per LDS tile
 constexpr int kMaxPtsBatch = 32; // points per batch (bounds the per-point LDS staging)
+constexpr int kMaxRounds = 8;    // pair rounds per LDS-tile batch (k_build preloads them into registers)
 constexpr uint32_t kPairInvalid = 0xFFFFFFFFu; // padding entry of a pair round
 constexpr int kMaxViewsLds = 10; // d(d+1)/2 <= kNSlot
 constexpr int kCP = 8;           // padded camera block dimension (cnp <= 8)
@@ -52,7 +53,7 @@ struct Plan {
     std::vector<int> tile_batch, tile_slot, tile_cslot; // ntile+1
     std::vector<uint8_t> tile_mode;                  // 1 LDS accumulate, 0 direct global atomics
     std::vector<int> slot_gblk, cslot_cam;
-    std::vector<uint32_t> pair;                      // la | lb<<6 | slot<<12
+    std::vector<uint32_t> pair;                      // la | lb<<6 | slot<<12 (6 bits) | local point<<18 (LDS tiles)
     std::vector<uint32_t> pair_gblk;                 // direct pairs only: upper block id
     int64_t npair_lds = 0;                           // pairs [0,npair_lds) belong to LDS tiles
     int ntile_lds = 0, nbatch_lds = 0;

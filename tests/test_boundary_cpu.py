@@ -151,8 +151,9 @@ def _check_plan(sc, rank=0, world=1, tmb=0):
             assert la <= lb < o1 - o0 and g["obs_pt"][o0 + la] == g["obs_pt"][o0 + lb]
             ja, jb = g["obs_cam"][o0 + la], g["obs_cam"][o0 + lb]
             if lds:
-                blk = g["slot_gblk"][g["tile_slot"][t] + (e >> 12)]
-                assert (e >> 12) < g["tile_slot"][t + 1] - g["tile_slot"][t] <= 55
+                blk = g["slot_gblk"][g["tile_slot"][t] + ((e >> 12) & 63)]
+                assert ((e >> 12) & 63) < g["tile_slot"][t + 1] - g["tile_slot"][t] <= 55
+                assert g["obs_pt"][o0 + la] - g["batch_pt"][b] == (e >> 18) & 31
                 assert g["cslot_cam"][g["tile_cslot"][t] + g["obs_cslot"][o0 + la]] == ja
             else:
                 blk = g["pair_gblk"][g["batch_pair"][b] + q - npair_lds]

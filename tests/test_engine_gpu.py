@@ -223,11 +223,13 @@ def test_error_paths():
         capi.Engine(capi.default_config(undistort=1))
 
 
-def test_c2_size_properties(oracle):
-    """BASELINE config C2 (200 cams / 100k pts / 1M obs): size-independent properties --
-    monotone cost, converged RMSE at the noise level, agreement with the oracle's cost function
-    at the returned parameters, idempotence of a second solve."""
-    sc = pkg("scene").make_scene("C2")
+@pytest.mark.parametrize("name", ["C2", "C3"])
+def test_full_size_properties(oracle, name):
+    """BASELINE configs C2 (200 cams / 100k pts / 1M obs) and C3 (1k / 1M / 10M) at full size:
+    size-independent properties -- monotone cost, converged RMSE at the noise level, the CPU cost
+    function evaluated at the GPU's answer equals the GPU's own cost, idempotence of a second solve,
+    and every trial accepted with the reference's stop rule 8 ending the run."""
+    sc = pkg("scene").make_scene(name)
     eng = make_engine(sc)
     ret, info = eng.run()
     tr = eng.trace()
@@ -241,3 +243,4 @@ def test_c2_size_properties(oracle):
     eng.set_params(a, xyz)
     ret2, info2 = eng.run()
     assert info2[1] <= info[1] * (1 + 1e-12) and info2[0] == pytest.approx(info[1], rel=1e-12)
+    assert info[6] == 8 and info[9] == ret          # Bundler's stop rule, no rejected trial
