@@ -142,10 +142,6 @@ int Engine::prepare()
     }
     std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches);
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
-    if (!plan_.long_pts.empty()) {
-        err = "plan: a point has more than 64 observations (long-track path not implemented yet)";
-        return MI_BA_ERROR;
-    }
     const Plan &pl = plan_;
 #define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
     UP(d_tile_batch_, pl.tile_batch); UP(d_tile_slot_, pl.tile_slot); UP(d_tile_cslot_, pl.tile_cslot);
@@ -167,6 +163,17 @@ int Engine::prepare()
         UP(d_obs_xy_, xy);
     }
     UP(d_R0_, h_R0_); UP(d_ff_, h_ff_);
+    {   // long tracks: scratch rows and the upper pattern for the block lookup
+        std::vector<int> scr(pl.long_pts.size() + 1, 0);
+        long_max_pairs_ = 0;
+        for (size_t l = 0; l < pl.long_pts.size(); ++l) {
+            const long long d = pl.pt_obs[pl.long_pts[l] + 1] - pl.pt_obs[pl.long_pts[l]];
+            scr[l + 1] = scr[l] + (int)d;
+            long_max_pairs_ = std::max(long_max_pairs_, d * (d + 1) / 2);
+        }
+        UP(d_long_pts_, pl.long_pts); UP(d_long_scr_, scr); UP(d_up_row_, pl.up_row); UP(d_up_col_, pl.up_col);
+        if (!hipok(d_long_scratch_.alloc((size_t)scr.back() * 30), "alloc long scratch")) return MI_BA_ERROR;
+    }
     {
         if ((int)h_fixed_.size() != m_) h_fixed_.assign(m_, 0);
         std::vector<unsigned char> fx(h_fixed_);
@@ -187,7 +194,7 @@ int Engine::prepare()
         !hipok(d_E_.alloc((size_t)m_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)m_ * kCP), "alloc dA") ||
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)m_ * kCP * 7), "alloc pcg") ||
         !hipok(d_rzpq_.alloc((size_t)(cfg.pcg_maxit + 4) + 2 * (size_t)((m_ + 7) / 8) + (size_t)m_), "alloc rz/pq") ||
-        !hipok(d_part_.alloc((size_t)std::max(pl.ntile(), kBacksubGrid) * kPartW), "alloc partials"))
+        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGrid) + pl.long_pts.size() + 1) * kPartW), "alloc partials"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
@@ -250,6 +257,18 @@ bool Engine::allreduce2()
     return true;
 }
 
+LongArgs Engine::long_args(double mu, bool want_diag, double *dB_dev, int part_row0)
+{
+    LongArgs a{};
+    a.long_pts = d_long_pts_.p; a.long_scr = d_long_scr_.p; a.pt_obs = d_pt_obs_.p; a.obs_cam = d_obs_cam_.p;
+    a.up_row = d_up_row_.p; a.up_col = d_up_col_.p; a.cam_fixed = d_fixed_.p; a.obs_xy = d_obs_xy_.p;
+    a.cam_lin = d_cam_lin_[cur_].p; a.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; a.pts = d_pts_[cur_].p; a.dA = d_dA_.p;
+    a.scratch = d_long_scratch_.p; a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p;
+    a.pts_new = d_pts_[cur_ ^ 1].p; a.dB = dB_dev; a.mu = mu; a.eps5 = cfg.opts[5]; a.max_pairs = long_max_pairs_;
+    a.nlong = (int)plan_.long_pts.size(); a.m = m_; a.want_diag = want_diag ? 1 : 0; a.part_row0 = part_row0; a.cfg = model();
+    return a;
+}
+
 // linearise at the current estimate with damping mu and build the reduced camera system
 bool Engine::linear_phase(double mu, bool want_diag)
 {
@@ -271,8 +290,9 @@ bool Engine::linear_phase(double mu, bool want_diag)
     launch_build(st_, cnp, true, pl.ntile_lds, a);
     a.tile0 = pl.ntile_lds;
     launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
+    launch_long_build(st_, cnp, long_args(mu, want_diag, nullptr, pl.ntile()));
     (void)hipEventRecord(ev_[1], st_);
-    launch_reduce_partials(st_, pl.ntile(), d_part_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
+    launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
                     S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_E_.p, scal_());
@@ -320,8 +340,9 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = pl.nbatch(); b.ngrid = std::min(pl.nbatch(), kBacksubGrid); b.cfg = mc;
     (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
+    launch_long_backsub(st_, cnp, long_args(mu, false, dB_dev, b.ngrid));
     (void)hipEventRecord(ev_[5], st_);
-    launch_reduce_partials(st_, b.ngrid, d_part_.p, scal_() + SC_COST_NEW, scal_() + SC_MAX_PCT);
+    launch_reduce_partials(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, scal_() + SC_COST_NEW, scal_() + SC_MAX_PCT);
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }

@@ -98,6 +98,10 @@ private:
     DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_;
     DevBuf<unsigned> d_pair_, d_pair_gblk_;
     DevBuf<unsigned long long> d_dbg_;
+    DevBuf<int> d_long_pts_, d_long_scr_, d_up_row_, d_up_col_;
+    DevBuf<double> d_long_scratch_;
+    long long long_max_pairs_ = 0;
+    LongArgs long_args(double mu, bool want_diag, double *dB_dev, int part_row0);
     DevBuf<double2> d_obs_xy_;
     // device: state
     DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_Minv_, d_E_, d_dA_, d_dB_,

@@ -71,6 +71,19 @@ struct BacksubArgs {
     ModelCfg cfg;
 };
 
+// long tracks (> 64 views): one workgroup per point, HBM scratch row per observation
+struct LongArgs {
+    const int *long_pts, *long_scr, *pt_obs, *obs_cam, *up_row, *up_col;
+    const unsigned char *cam_fixed;
+    const double2 *obs_xy;
+    const double *cam_lin, *cam_lin_new, *pts, *dA;
+    double *scratch, *S_up, *camvec, *ptout, *part, *pts_new, *dB;
+    double mu, eps5;
+    long long max_pairs;
+    int nlong, m, want_diag, part_row0;
+    ModelCfg cfg;
+};
+
 struct PcgArgs {
     const int *bsr_row, *bsr_col;
     const double *S, *Minv, *E;
@@ -95,6 +108,8 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, cons
                        const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
                        double *cam_lin_new, double *scal);
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a);
+void launch_long_build(hipStream_t st, int cnp, const LongArgs &a);   // k_long_reduce + k_long_pairs
+void launch_long_backsub(hipStream_t st, int cnp, const LongArgs &a);
 void launch_rotations(hipStream_t st, int m, const double *cam_lin, double *R);
 
 } // namespace miba

@@ -532,6 +532,195 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Long tracks: points seen by more than 64 cameras do not fit a wavefront batch.  They take a
+// workgroup each (k_long_reduce: phases 1-4 with block reductions, A/B/e/G parked in an HBM scratch
+// row per observation) and their d(d+1)/2 pair blocks are spread over a 2-D grid (k_long_pairs,
+// direct f64 atomics, block found by binary search in the upper pattern).  Same arithmetic as k_build.
+// ------------------------------------------------------------------------------------------
+constexpr int kLongRow = 2 * 8 + 6 + 2 + 6; // A (2 x 8 padded), B (6), e (2), G (6) doubles per observation
+
+__device__ __forceinline__ double block_sum_256(double v, double *sh)
+{
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+template <int CNP>
+__global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
+{
+    __shared__ double sh[4], sVh[9];
+    const int l = blockIdx.x, ip = g.long_pts[l], tid = threadIdx.x;
+    const int os = g.pt_obs[ip], oe = g.pt_obs[ip + 1];
+    const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
+    double *scr = g.scratch + (size_t)g.long_scr[l] * kLongRow;
+    double v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, cost = 0.0;
+    for (int o = os + tid; o < oe; o += 256) {
+        const int j = g.obs_cam[o];
+        double A[2][CNP], B[2][3], e[2];
+        linearize_obs<CNP>(g.cfg, g.cam_lin + (size_t)j * kCamLin, X, g.obs_xy[o], g.cam_fixed[j] != 0, e, A, B);
+        cost += e[0] * e[0] + e[1] * e[1];
+        v[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0]; v[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
+        v[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2]; v[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
+        v[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2]; v[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) v[6 + r] += B[0][r] * e[0] + B[1][r] * e[1];
+        double *row = scr + (size_t)(o - os) * kLongRow;
+#pragma unroll
+        for (int t = 0; t < CNP; ++t) { row[t] = A[0][t]; row[8 + t] = A[1][t]; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { row[16 + t] = B[0][t]; row[19 + t] = B[1][t]; }
+        row[22] = e[0]; row[23] = e[1];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) v[c] = block_sum_256(v[c], sh);
+    cost = block_sum_256(cost, sh);
+    if (tid == 0) {
+        double v00 = v[0], v01 = v[1], v02 = v[2], v11 = v[3], v12 = v[4], v22 = v[5];
+        const double maxdv = fmax(v00, fmax(v11, v22)), ebinf = fmax(fabs(v[6]), fmax(fabs(v[7]), fabs(v[8])));
+        v00 += g.mu; v11 += g.mu; v22 += g.mu;
+        const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
+        const double det = v00 * c00 + v01 * c01 + v02 * c02;
+        double inv[6] = { 0, 0, 0, 0, 0, 0 }, sing = 0.0;
+        if (det == 0.0 || !isfinite(det)) sing = 1.0;
+        else {
+            const double id = 1.0 / det;
+            inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+            inv[3] = (v00 * v22 - v02 * v02) * id; inv[4] = (v01 * v02 - v00 * v12) * id; inv[5] = (v00 * v11 - v01 * v01) * id;
+        }
+        const double h0 = inv[0] * v[6] + inv[1] * v[7] + inv[2] * v[8], h1 = inv[1] * v[6] + inv[3] * v[7] + inv[4] * v[8],
+                     h2 = inv[2] * v[6] + inv[4] * v[7] + inv[5] * v[8];
+        double *po = g.ptout + (size_t)ip * kPtOut;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { po[c] = inv[c]; sVh[c] = inv[c]; }
+        po[6] = h0; po[7] = h1; po[8] = h2; po[9] = v[6]; po[10] = v[7]; po[11] = v[8];
+        sVh[6] = h0; sVh[7] = h1; sVh[8] = h2;
+        double *pr = g.part + (size_t)(g.part_row0 + l) * kPartW;
+        pr[0] = cost; pr[1] = X[0] * X[0] + X[1] * X[1] + X[2] * X[2]; pr[2] = 0.0; pr[3] = 0.0;
+        pr[4] = ebinf; pr[5] = maxdv; pr[6] = sing; pr[7] = 0.0;
+    }
+    __syncthreads();
+    const double i00 = sVh[0], i01 = sVh[1], i02 = sVh[2], i11 = sVh[3], i12 = sVh[4], i22 = sVh[5];
+    for (int o = os + tid; o < oe; o += 256) {
+        const int j = g.obs_cam[o];
+        double *row = scr + (size_t)(o - os) * kLongRow; // written by this same thread above
+        const double B0[3] = { row[16], row[17], row[18] }, B1[3] = { row[19], row[20], row[21] };
+        row[24] = B0[0] * i00 + B0[1] * i01 + B0[2] * i02; row[25] = B0[0] * i01 + B0[1] * i11 + B0[2] * i12;
+        row[26] = B0[0] * i02 + B0[1] * i12 + B0[2] * i22; row[27] = B1[0] * i00 + B1[1] * i01 + B1[2] * i02;
+        row[28] = B1[0] * i01 + B1[1] * i11 + B1[2] * i12; row[29] = B1[0] * i02 + B1[1] * i12 + B1[2] * i22;
+        if (g.cam_fixed[j]) continue;
+        const double e0 = row[22], e1 = row[23];
+        const double er0 = e0 - (B0[0] * sVh[6] + B0[1] * sVh[7] + B0[2] * sVh[8]);
+        const double er1 = e1 - (B1[0] * sVh[6] + B1[1] * sVh[7] + B1[2] * sVh[8]);
+#pragma unroll
+        for (int t = 0; t < CNP; ++t) {
+            const double a0 = row[t], a1 = row[8 + t];
+            gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], a0 * e0 + a1 * e1);
+            gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], a0 * er0 + a1 * er1);
+            if (g.want_diag) gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], a0 * a0 + a1 * a1);
+        }
+    }
+}
+
+template <int CNP>
+__global__ __launch_bounds__(256) void k_long_pairs(const LongArgs g)
+{
+    const int l = blockIdx.y, ip = g.long_pts[l];
+    const int os = g.pt_obs[ip], d = g.pt_obs[ip + 1] - os;
+    const long long np = (long long)d * (d + 1) / 2, t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= np) return;
+    // pair index -> (a <= b): t = a*d - a(a-1)/2 + (b - a)
+    int a = (int)floor(((2.0 * d + 1.0) - sqrt((2.0 * d + 1.0) * (2.0 * d + 1.0) - 8.0 * (double)t)) * 0.5);
+    if (a < 0) a = 0;
+    while ((long long)a * d - (long long)a * (a - 1) / 2 > t) --a;
+    while ((long long)(a + 1) * d - (long long)(a + 1) * a / 2 <= t) ++a;
+    const int b = a + (int)(t - ((long long)a * d - (long long)a * (a - 1) / 2));
+    const double *scr = g.scratch + (size_t)g.long_scr[l] * kLongRow;
+    const double *ra = scr + (size_t)a * kLongRow, *rb = scr + (size_t)b * kLongRow;
+    const int ja = g.obs_cam[os + a], jb = g.obs_cam[os + b];
+    if (g.cam_fixed[ja] || g.cam_fixed[jb]) return; // A is zero: the block vanishes
+    int lo = g.up_row[ja], hi = g.up_row[ja + 1] - 1, blk = -1; // cameras ascend inside a point: ja <= jb
+    while (lo <= hi) { const int mid = (lo + hi) >> 1, c = g.up_col[mid]; if (c < jb) lo = mid + 1; else if (c > jb) hi = mid - 1; else { blk = mid; break; } }
+    if (blk < 0) return;
+    double M00 = ra[24] * rb[16] + ra[25] * rb[17] + ra[26] * rb[18], M01 = ra[24] * rb[19] + ra[25] * rb[20] + ra[26] * rb[21];
+    double M10 = ra[27] * rb[16] + ra[28] * rb[17] + ra[29] * rb[18], M11 = ra[27] * rb[19] + ra[28] * rb[20] + ra[29] * rb[21];
+    const double dg = (a == b) ? 1.0 : 0.0;
+    M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
+    double T0[CNP], T1[CNP];
+#pragma unroll
+    for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, rb[8 + c], M00 * rb[c]); T1[c] = fma(M11, rb[8 + c], M10 * rb[c]); }
+    double *dst = g.S_up + (size_t)blk * (kCP * kCP);
+#pragma unroll
+    for (int r = 0; r < CNP; ++r) {
+        const double a0 = ra[r], a1 = ra[8 + r];
+#pragma unroll
+        for (int c = 0; c < CNP; ++c) gadd(&dst[r * kCP + c], fma(a1, T1[c], a0 * T0[c]));
+    }
+}
+
+template <int CNP>
+__global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
+{
+    __shared__ double sh[4], sX[3];
+    const int l = blockIdx.x, ip = g.long_pts[l], tid = threadIdx.x;
+    const int os = g.pt_obs[ip], oe = g.pt_obs[ip + 1];
+    const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
+    const double *scr = g.scratch + (size_t)g.long_scr[l] * kLongRow; // A, B, e of this trial's k_long_reduce
+    double t3[3] = { 0, 0, 0 };
+    for (int o = os + tid; o < oe; o += 256) {
+        const int j = g.obs_cam[o];
+        const double *row = scr + (size_t)(o - os) * kLongRow;
+        double w0 = 0.0, w1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < CNP; ++t) { const double dd = g.dA[j * kCP + t]; w0 += row[t] * dd; w1 += row[8 + t] * dd; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) t3[t] += row[16 + t] * w0 + row[19 + t] * w1;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t3[c] = block_sum_256(t3[c], sh);
+    double dl = 0.0, dp2 = 0.0;
+    if (tid == 0) {
+        const double *po = g.ptout + (size_t)ip * kPtOut;
+        const double d0 = po[6] - (po[0] * t3[0] + po[1] * t3[1] + po[2] * t3[2]);
+        const double d1 = po[7] - (po[1] * t3[0] + po[3] * t3[1] + po[4] * t3[2]);
+        const double d2 = po[8] - (po[2] * t3[0] + po[4] * t3[1] + po[5] * t3[2]);
+        sX[0] = X[0] + d0; sX[1] = X[1] + d1; sX[2] = X[2] + d2;
+        g.pts_new[3 * (size_t)ip] = sX[0]; g.pts_new[3 * (size_t)ip + 1] = sX[1]; g.pts_new[3 * (size_t)ip + 2] = sX[2];
+        if (g.dB) { g.dB[3 * (size_t)ip] = d0; g.dB[3 * (size_t)ip + 1] = d1; g.dB[3 * (size_t)ip + 2] = d2; }
+        dl = d0 * (g.mu * d0 + po[9]) + d1 * (g.mu * d1 + po[10]) + d2 * (g.mu * d2 + po[11]);
+        dp2 = d0 * d0 + d1 * d1 + d2 * d2;
+    }
+    __syncthreads();
+    const double Xn[3] = { sX[0], sX[1], sX[2] };
+    double cn = 0.0, pct = 0.0;
+    for (int o = os + tid; o < oe; o += 256) {
+        const int j = g.obs_cam[o];
+        const double *row = scr + (size_t)(o - os) * kLongRow;
+        const double2 xy = g.obs_xy[o];
+        double u, v;
+        project_obs(g.cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, u, v);
+        const double en0 = xy.x - u, en1 = xy.y - v, e0 = row[22], e1 = row[23];
+        cn += en0 * en0 + en1 * en1;
+        double pc = 0.0;
+        if (!(e0 < g.eps5 && en0 < g.eps5)) pc = fmax(pc, fabs((e0 - en0) / e0));
+        if (!(e1 < g.eps5 && en1 < g.eps5)) pc = fmax(pc, fabs((e1 - en1) / e1));
+        if (pc == pc) pct = fmax(pct, pc);
+    }
+    cn = block_sum_256(cn, sh);
+    pct = wave_max(pct);
+    __syncthreads();
+    if ((tid & 63) == 0) sh[tid >> 6] = pct;
+    __syncthreads();
+    if (tid == 0) {
+        double *pr = g.part + (size_t)(g.part_row0 + l) * kPartW;
+        pr[0] = cn; pr[1] = dl; pr[2] = dp2; pr[3] = 0.0; pr[4] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3])); pr[5] = 0.0; pr[6] = 0.0; pr[7] = 0.0;
+    }
+}
+
 // folds per-workgroup partial rows: columns [0,4) are sums, [4,8) maxima.  One workgroup.
 __global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const double *__restrict__ part, double *__restrict__ out_sum,
                                                         double *__restrict__ out_max)
@@ -985,6 +1174,26 @@ void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
     if (a.nbatch <= 0) return;
     if (cnp == 7) hipLaunchKernelGGL((k_backsub<7>), dim3(a.ngrid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_backsub<6>), dim3(a.ngrid), dim3(64), 0, st, a);
+}
+
+void launch_long_build(hipStream_t st, int cnp, const LongArgs &a)
+{
+    if (a.nlong <= 0) return;
+    const unsigned gx = (unsigned)((a.max_pairs + 255) / 256);
+    if (cnp == 7) {
+        hipLaunchKernelGGL((k_long_reduce<7>), dim3(a.nlong), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_long_pairs<7>), dim3(gx, a.nlong), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_long_reduce<6>), dim3(a.nlong), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_long_pairs<6>), dim3(gx, a.nlong), dim3(256), 0, st, a);
+    }
+}
+
+void launch_long_backsub(hipStream_t st, int cnp, const LongArgs &a)
+{
+    if (a.nlong <= 0) return;
+    if (cnp == 7) hipLaunchKernelGGL((k_long_backsub<7>), dim3(a.nlong), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_long_backsub<6>), dim3(a.nlong), dim3(256), 0, st, a);
 }
 
 void launch_rotations(hipStream_t st, int m, const double *cam_lin, double *R)

@@ -171,6 +171,55 @@ def test_long_tracks_use_direct_tiles(oracle):
     assert abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
 
 
+def test_tracks_longer_than_a_wavefront(oracle):
+    """points seen by 70..90 cameras (> 64 = one wavefront) take the workgroup-per-point kernels;
+    mixed with short tracks in one problem"""
+    scene = pkg("scene")
+    rng = np.random.default_rng(11)
+    base = scene.make_scene("x", m=96, n=260, d=90, seed=13, strides=(1,))
+    keep = []
+    for i in range(base.n):
+        d = int(rng.integers(70, 91)) if i < 40 else int(rng.integers(3, 20))
+        idx = np.arange(base.pt_ptr[i], base.pt_ptr[i + 1])
+        keep.append(np.sort(rng.permutation(idx)[:d]))
+    sel = np.concatenate(keep)
+    sc = scene.Scene(n=base.n, m=base.m, cnp=7, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0,
+                     pt_ptr=np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int32),
+                     obs_cam=base.obs_cam[sel], x=base.x[sel], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true)
+    st = pkg("capi").Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).stats()
+    assert st["nlong"] == 40
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    g = eng.debug_linearize(mu)
+    S, E, Vinv = reduced_system(lin, sc, mu)
+    assert abs(g["cost"] - lin["cost"]) <= 1e-11 * lin["cost"]
+    assert rel(g["ea"], lin["ea"]) < 1e-10 and rel(g["eb"], lin["eb"]) < 1e-10
+    assert rel(g["diagU"], np.einsum("jrr->jr", lin["U"])) < 1e-10
+    assert np.abs(g["S"] - S).max() < 1e-10 * np.abs(lin["U"]).max()
+    assert rel(g["E"].reshape(-1), E) < 1e-9
+    sol = eng.debug_solve(mu)
+    da = np.linalg.solve(S, E).reshape(sc.m, sc.cnp)
+    t = np.zeros((sc.n, 3))
+    np.add.at(t, sc.obs_pt(), np.einsum("oab,oa->ob", lin["W"], da[sc.obs_cam]))
+    db = np.einsum("iab,ib->ia", Vinv, lin["eb"] - t)
+    assert rel(sol["da"], da) < 1e-7 and rel(sol["db"], db) < 1e-7
+    want = oracle.cost(sc, sc.p0 + np.concatenate([da.reshape(-1), db.reshape(-1)]))
+    assert abs(sol["cost_new"] - want) < 1e-7 * want
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert ret == o["ret"] and info[6] == o["info"][6]
+    assert abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
+    # only long tracks: no wavefront batch at all
+    sub = scene.Scene(n=40, m=sc.m, cnp=7, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0,
+                      pt_ptr=sc.pt_ptr[:41].copy(), obs_cam=sc.obs_cam[:sc.pt_ptr[40]], x=sc.x[:sc.pt_ptr[40]], R0=sc.R0,
+                      f_fixed=sc.f_fixed, p0=np.concatenate([sc.p0[:sc.m * 7], sc.p0[sc.m * 7:sc.m * 7 + 120]]), p_true=sc.p0)
+    eng2 = make_engine(sub)
+    ret2, info2 = eng2.run()
+    o2 = oracle.run(sub, itmax=150, fd_jacobian=0)
+    assert ret2 == o2["ret"] and abs(np.sqrt(info2[1] / sub.nobs) - np.sqrt(o2["info"][1] / sub.nobs)) < 1e-6
+
+
 def test_mixed_track_lengths_and_unsorted_cameras(oracle):
     """ragged input: track lengths 2..14, cameras NOT sorted inside a point, some points unobserved"""
     scene = pkg("scene")
