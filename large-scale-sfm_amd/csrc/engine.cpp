@@ -57,8 +57,8 @@ Engine::~Engine()
         unsigned long long h[8];
         if (hipMemcpy(h, d_dbg_.p, 64, hipMemcpyDeviceToHost) == hipSuccess) {
             double tot = 0; for (auto v : h) tot += (double)v;
-            std::fprintf(stderr, "[mi_ba stamps] k_build cycle shares: prologue %.3f | ph1 %.3f | ph2 %.3f | ph3 %.3f | ph4 %.3f | ph5 %.3f | flush %.3f (total %.3g)\n",
-                         h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, tot);
+            std::fprintf(stderr, "[mi_ba stamps] k_build cycle shares: prologue %.3f | ph1 %.3f | ph2 %.3f | ph3 %.3f | ph4 %.3f | ph5 %.3f | flush %.3f | ph1 loads issued %.3f (total %.3g)\n",
+                         h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot, tot);
         }
     }
     if (comm_) ncclCommDestroy((ncclComm_t)comm_);

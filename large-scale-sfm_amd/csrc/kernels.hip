@@ -216,12 +216,19 @@ struct BatchRegs {
     unsigned ent[LDS ? kMaxRounds : 1];   // this lane's pair entry of every round (LDS tiles)
 };
 
+// batch descriptors of a whole tile (<= 32 batches) sit in registers, one batch per lane, loaded once in
+// the prologue; the loop reads them with v_readlane (no scalar-load latency inside the loop)
+struct TileDesc { int obs, pt, pair_lo, pair_hi; };
+
+__device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+
 template <bool LDS>
-__device__ __forceinline__ void load_batch_level1(const BuildArgs &g, int b, int lane, BatchRegs<LDS> &r)
+__device__ __forceinline__ void load_batch_level1(const BuildArgs &g, const TileDesc &td, int k, int lane, BatchRegs<LDS> &r)
 {
-    r.o0 = g.batch_obs[b]; r.nob = g.batch_obs[b + 1] - r.o0;
-    r.p0 = g.batch_pt[b]; r.npt = g.batch_pt[b + 1] - r.p0;
-    r.q0 = g.batch_pair[b]; r.q1 = g.batch_pair[b + 1];
+    r.o0 = rl(td.obs, k); r.nob = rl(td.obs, k + 1) - r.o0;
+    r.p0 = rl(td.pt, k); r.npt = rl(td.pt, k + 1) - r.p0;
+    r.q0 = ((long long)rl(td.pair_hi, k) << 32) | (unsigned)rl(td.pair_lo, k);
+    r.q1 = ((long long)rl(td.pair_hi, k + 1) << 32) | (unsigned)rl(td.pair_lo, k + 1);
     r.j = 0; r.ip = r.p0; r.cs = 0; r.xy = make_double2(0.0, 0.0);
     if (lane < r.nob) {
         const int o = r.o0 + lane;
@@ -230,9 +237,9 @@ __device__ __forceinline__ void load_batch_level1(const BuildArgs &g, int b, int
     }
     if constexpr (LDS) {
 #pragma unroll
-        for (int k = 0; k < kMaxRounds; ++k) {
-            const long long q = r.q0 + (long long)k * kWave + lane;
-            r.ent[k] = (q < r.q1) ? g.pair[q] : kPairInvalid;
+        for (int t = 0; t < kMaxRounds; ++t) {
+            const long long q = r.q0 + (long long)t * kWave + lane;
+            r.ent[t] = (q < r.q1) ? g.pair[q] : kPairInvalid;
         }
     }
 }
@@ -244,32 +251,40 @@ __device__ __forceinline__ void load_cam_record(const BuildArgs &g, int j, doubl
     for (int k = 0; k < kCamLin / 2; ++k) { const double2 v = src[k]; cl[2 * k] = v.x; cl[2 * k + 1] = v.y; }
 }
 
-// one pair: T = (delta_ab I - G_a B_b^T) A_b with G_a = B_a V*^-1 of the pair's point
-template <int CNP, int SA, int SB, int SV>
-__device__ __forceinline__ void pair_block(const double *sA, const double *sB, const double *sv, int la, int lb,
-                                           double T0[CNP], double T1[CNP])
+// one pair: T = (delta_ab I - G_a B_b^T) A_b with G_a = B_a V*^-1 of the pair's point.
+// Rows and sv are 16-byte aligned: every operand comes in through ds_read_b128.
+template <int CNP, int SR>
+__device__ __forceinline__ void pair_block(const double *sR, const double *sv, int la, int lb, double T0[CNP], double T1[CNP])
 {
-    const double *Ba = sB + la * SB, *Bb = sB + lb * SB;
-    const double i00 = sv[0], i01 = sv[1], i02 = sv[2], i11 = sv[3], i12 = sv[4], i22 = sv[5];
+    constexpr int OB = 2 * CNP;
+    const double2 *Ba2 = reinterpret_cast<const double2 *>(sR + la * SR + OB);
+    const double2 *Bb2 = reinterpret_cast<const double2 *>(sR + lb * SR + OB);
+    const double2 *sv2 = reinterpret_cast<const double2 *>(sv);
+    const double2 a01 = Ba2[0], a23 = Ba2[1], a45 = Ba2[2], b01 = Bb2[0], b23 = Bb2[1], b45 = Bb2[2];
+    const double2 v01 = sv2[0], v23 = sv2[1], v45 = sv2[2];
+    const double Ba[6] = { a01.x, a01.y, a23.x, a23.y, a45.x, a45.y }, Bb[6] = { b01.x, b01.y, b23.x, b23.y, b45.x, b45.y };
+    const double i00 = v01.x, i01 = v01.y, i02 = v23.x, i11 = v23.y, i12 = v45.x, i22 = v45.y;
     double G[2][3];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        G[r][0] = Ba[3 * r] * i00 + Ba[3 * r + 1] * i01 + Ba[3 * r + 2] * i02;
-        G[r][1] = Ba[3 * r] * i01 + Ba[3 * r + 1] * i11 + Ba[3 * r + 2] * i12;
-        G[r][2] = Ba[3 * r] * i02 + Ba[3 * r + 1] * i12 + Ba[3 * r + 2] * i22;
+        G[r][0] = fma(Ba[3 * r + 2], i02, fma(Ba[3 * r + 1], i01, Ba[3 * r] * i00));
+        G[r][1] = fma(Ba[3 * r + 2], i12, fma(Ba[3 * r + 1], i11, Ba[3 * r] * i01));
+        G[r][2] = fma(Ba[3 * r + 2], i22, fma(Ba[3 * r + 1], i12, Ba[3 * r] * i02));
     }
-    double M00 = G[0][0] * Bb[0] + G[0][1] * Bb[1] + G[0][2] * Bb[2];
-    double M01 = G[0][0] * Bb[3] + G[0][1] * Bb[4] + G[0][2] * Bb[5];
-    double M10 = G[1][0] * Bb[0] + G[1][1] * Bb[1] + G[1][2] * Bb[2];
-    double M11 = G[1][0] * Bb[3] + G[1][1] * Bb[4] + G[1][2] * Bb[5];
+    double M00 = fma(G[0][2], Bb[2], fma(G[0][1], Bb[1], G[0][0] * Bb[0]));
+    double M01 = fma(G[0][2], Bb[5], fma(G[0][1], Bb[4], G[0][0] * Bb[3]));
+    double M10 = fma(G[1][2], Bb[2], fma(G[1][1], Bb[1], G[1][0] * Bb[0]));
+    double M11 = fma(G[1][2], Bb[5], fma(G[1][1], Bb[4], G[1][0] * Bb[3]));
     const double dg = (la == lb) ? 1.0 : 0.0;
     M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
-    const double *Ab = sA + lb * SA;
+    const double2 *Ab2 = reinterpret_cast<const double2 *>(sR + lb * SR);
+    double Ab[2 * CNP];
+#pragma unroll
+    for (int k = 0; k < CNP; ++k) { const double2 v = Ab2[k]; Ab[2 * k] = v.x; Ab[2 * k + 1] = v.y; }
 #pragma unroll
     for (int c = 0; c < CNP; ++c) {
-        const double a0 = Ab[c], a1 = Ab[CNP + c];
-        T0[c] = fma(M01, a1, M00 * a0);
-        T1[c] = fma(M11, a1, M10 * a0);
+        T0[c] = fma(M01, Ab[CNP + c], M00 * Ab[c]);
+        T1[c] = fma(M11, Ab[CNP + c], M10 * Ab[c]);
     }
 }
 
@@ -296,12 +311,18 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-    constexpr int SA = 2 * CNP + 1;           // odd strides (in doubles) keep ds_read_b64 conflict-free
-    constexpr int SB = 9, SV = 9;             // sB row: B (6), e (2), local point index (direct tiles)
+    // one 16-byte aligned LDS row per observation: A (2 x CNP) | B (6) | e (2).  Row stride SR doubles with
+    // SR/2 odd (22 doubles = 176 B): 16 distinct rows fall into 16 distinct 16-byte bank slots, so the
+    // pair phase reads its operands with conflict-free ds_read_b128.
+    constexpr int OB = 2 * CNP;               // offset of B inside the row (even)
+    constexpr int SR = (((OB + 8) / 2) % 2 == 1) ? OB + 8 : OB + 10;
+    constexpr int SV = 10;                    // sV row: Vinv (6) h (3) pad; 80 B, 16-byte aligned
     constexpr int BLK = CNP * CNP, SS = BLK | 1, NCV = 2 * CNP, SC = (3 * CNP) | 1;
-    __shared__ double sA[kWave * SA], sB[kWave * SB], sV[kMaxPtsBatch * SV];
+    __shared__ __attribute__((aligned(16))) double sR[kWave * SR];
+    __shared__ __attribute__((aligned(16))) double sV[kMaxPtsBatch * SV];
     __shared__ double sS[LDS ? kNSlot * SS : 1], sC[LDS ? kNCSlot * SC : 1];
     __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
+    __shared__ int sLp[LDS ? 1 : kWave];      // local point of every observation (direct tiles; LDS tiles carry it in the pair entry)
 
     const int lane = threadIdx.x;
     const int tile = g.tile0 + blockIdx.x;
@@ -326,9 +347,17 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
     }
 
     const int b_begin = g.tile_batch[tile], b_end = g.tile_batch[tile + 1];
+    TileDesc td;
+    {
+        const int bi = min(b_begin + lane, b_end);        // lanes 0..nb hold batches b_begin..b_end
+        td.obs = g.batch_obs[bi]; td.pt = g.batch_pt[bi];
+        const long long pq = g.batch_pair[bi];
+        td.pair_lo = (int)(unsigned)pq; td.pair_hi = (int)(pq >> 32);
+    }
     BatchRegs<LDS> cur, nxt;
-    double X[3];
-    load_batch_level1<LDS>(g, b_begin, lane, cur);
+    double X[3], cl[kCamLin];
+    int cl_cam = -1;
+    load_batch_level1<LDS>(g, td, 0, lane, cur);
     X[0] = g.pts[3 * (size_t)cur.ip]; X[1] = g.pts[3 * (size_t)cur.ip + 1]; X[2] = g.pts[3 * (size_t)cur.ip + 2];
     nxt = cur;
     STAMP(0); // prologue: LDS clear, first batch loads issued
@@ -340,19 +369,23 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
         const int j = cur.j, lp = cur.ip - p0, cs = cur.cs;
         bool head = false;
-        // ---- phase 1 (the camera records are L2-resident: 192 B x m)
+        // ---- phase 1.  The 192-byte camera record is gathered from L2 only when this lane's camera
+        // changed since the previous batch: with signature-sorted points lane l keeps its camera for
+        // hundreds of points, and an uncoalesced 64-row gather costs ~1k cycles per batch.
         {
-            double cl[kCamLin];
-            load_cam_record(g, j, cl);
-            if (have_next) load_batch_level1<LDS>(g, b + 1, lane, nxt);   // streams + pair entries of the next batch
+            if (j != cl_cam) { load_cam_record(g, j, cl); cl_cam = j; }
+            if (have_next) load_batch_level1<LDS>(g, td, b + 1 - b_begin, lane, nxt);   // streams + pair entries of the next batch
+            STAMP(7);
             if (active) {
                 linearize_obs<CNP>(cfg, cl, X, cur.xy, g.cam_fixed[j] != 0, e, A, B);
                 cost += e[0] * e[0] + e[1] * e[1];
+                double *row = sR + lane * SR;
 #pragma unroll
-                for (int t = 0; t < CNP; ++t) { sA[lane * SA + t] = A[0][t]; sA[lane * SA + CNP + t] = A[1][t]; }
+                for (int t = 0; t < CNP; ++t) { row[t] = A[0][t]; row[CNP + t] = A[1][t]; }
 #pragma unroll
-                for (int t = 0; t < 3; ++t) { sB[lane * SB + t] = B[0][t]; sB[lane * SB + 3 + t] = B[1][t]; }
-                sB[lane * SB + 6] = e[0]; sB[lane * SB + 7] = e[1]; sB[lane * SB + 8] = (double)lp;
+                for (int t = 0; t < 3; ++t) { row[OB + t] = B[0][t]; row[OB + 3 + t] = B[1][t]; }
+                row[OB + 6] = e[0]; row[OB + 7] = e[1];
+                if constexpr (!LDS) sLp[lane] = lp;
             }
             // point boundaries without touching memory: observations of a point are consecutive lanes
             const int lp_prev = __shfl_up(active ? lp : -2, 1);
@@ -376,11 +409,11 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
                 double s0 = 0.0, s1 = 0.0;
                 int o = os;
                 for (; o + 1 < oe; o += 2) {
-                    const double *r0 = sB + o * SB, *r1 = r0 + SB;
+                    const double *r0 = sR + o * SR + OB, *r1 = r0 + SR;
                     s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0));
                     s1 = fma(r1[3 + r], r1[c1], fma(r1[r], r1[c0], s1));
                 }
-                if (o < oe) { const double *r0 = sB + o * SB; s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0)); }
+                if (o < oe) { const double *r0 = sR + o * SR + OB; s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0)); }
                 sV[lpp * SV + comp] = s0 + s1;
             }
         }
@@ -446,7 +479,7 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
             }
         }
         STAMP(4);
-        // ---- phase 5: pair products (reads sA, sB, sV only: no barrier needed after phase 4)
+        // ---- phase 5: pair products (reads sR, sV only: no barrier needed after phase 4)
         if constexpr (LDS) {
             const int nrounds = (int)((cur.q1 - cur.q0) / kWave);
 #pragma unroll
@@ -456,7 +489,7 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
                 if (ent == kPairInvalid) continue;
                 const int la = ent & 63, lb = (ent >> 6) & 63, slot = (ent >> 12) & 63, plp = (ent >> 18) & 31;
                 double T0[CNP], T1[CNP];
-                pair_block<CNP, SA, SB, SV>(sA, sB, sV + plp * SV, la, lb, T0, T1);
+                pair_block<CNP, SR>(sR, sV + plp * SV, la, lb, T0, T1);
                 if (slot != cur_slot) { // this lane's block changed: spill the finished one
                     if (cur_slot >= 0) {
                         double *dst = sS + cur_slot * SS;
@@ -465,7 +498,10 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
                     }
                     cur_slot = slot;
                 }
-                const double *Aa = sA + la * SA;
+                const double2 *Aa2 = reinterpret_cast<const double2 *>(sR + la * SR);
+                double Aa[2 * CNP];
+#pragma unroll
+                for (int k2 = 0; k2 < CNP; ++k2) { const double2 v = Aa2[k2]; Aa[2 * k2] = v.x; Aa[2 * k2 + 1] = v.y; }
 #pragma unroll
                 for (int r = 0; r < CNP; ++r) {
                     const double a0 = Aa[r], a1 = Aa[CNP + r];
@@ -478,8 +514,8 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
                 const unsigned ent = g.pair[q];
                 const int la = ent & 63, lb = (ent >> 6) & 63;
                 double T0[CNP], T1[CNP];
-                pair_block<CNP, SA, SB, SV>(sA, sB, sV + (int)sB[la * SB + 8] * SV, la, lb, T0, T1);
-                const double *Aa = sA + la * SA;
+                pair_block<CNP, SR>(sR, sV + sLp[la] * SV, la, lb, T0, T1);
+                const double *Aa = sR + la * SR;
                 double *dst = g.S_up + (size_t)g.pair_gblk[q - g.pair_gblk_base] * (kCP * kCP);
 #pragma unroll
                 for (int r = 0; r < CNP; ++r) {

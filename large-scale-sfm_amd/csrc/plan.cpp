@@ -38,7 +38,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     if ((int64_t)m * m / 8 > (int64_t)1 << 30) return "more than ~92k cameras is not supported yet";
     if (nobs >= ((int64_t)1 << 31)) return "more than 2^31 observations is not supported yet";
     const bool auto_tile = tile_max_batches <= 0;
-    if (auto_tile) tile_max_batches = 32;
+    if (auto_tile || tile_max_batches > kMaxTileBatches) tile_max_batches = kMaxTileBatches;
     pl = Plan();
     pl.n = n; pl.m = m; pl.nobs = nobs; pl.rank = rank; pl.world = world;
 
@@ -187,7 +187,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     // enough that the grid still has ~8 workgroups per CU (256 CUs) to balance
     if (auto_tile) {
         const int est_batches = nol / kWave + 1;
-        tile_max_batches = std::min(32, std::max(2, (est_batches + 2047) / 2048));
+        tile_max_batches = std::min(kMaxTileBatches, std::max(2, (est_batches + 2047) / 2048));
     }
     pl.batch_obs.assign(1, 0); pl.batch_pt.assign(1, 0); pl.batch_pair.assign(1, 0);
     pl.tile_batch.assign(1, 0); pl.tile_slot.assign(1, 0); pl.tile_cslot.assign(1, 0);
