@@ -194,7 +194,8 @@ int Engine::prepare()
         !hipok(d_E_.alloc((size_t)m_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)m_ * kCP), "alloc dA") ||
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)m_ * kCP * 7), "alloc pcg") ||
         !hipok(d_rzpq_.alloc((size_t)(cfg.pcg_maxit + 4) + 2 * (size_t)((m_ + 7) / 8) + (size_t)m_), "alloc rz/pq") ||
-        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGrid) + pl.long_pts.size() + 1) * kPartW), "alloc partials"))
+        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGrid) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
+        !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
@@ -292,7 +293,7 @@ bool Engine::linear_phase(double mu, bool want_diag)
     launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
     launch_long_build(st_, cnp, long_args(mu, want_diag, nullptr, pl.ntile()));
     (void)hipEventRecord(ev_[1], st_);
-    launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
+    launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
                     S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_E_.p, scal_());
@@ -342,7 +343,7 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, false, dB_dev, b.ngrid));
     (void)hipEventRecord(ev_[5], st_);
-    launch_reduce_partials(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, scal_() + SC_COST_NEW, scal_() + SC_MAX_PCT);
+    launch_reduce_partials(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW, scal_() + SC_MAX_PCT);
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }

@@ -19,7 +19,8 @@ namespace miba {
 constexpr int kCamLin = 24;
 constexpr int kPtOut = 12;
 constexpr int kPartW = 8;      // per-workgroup partial row: [0,4) sums, [4,8) maxima
-constexpr int kBacksubGrid = 8192;
+constexpr int kBacksubGrid = 8192;    // workgroups of k_backsub (each walks a contiguous chunk of batches)
+constexpr int kReduceStage = 64;      // first-stage workgroups of k_reduce_partials
 
 struct ModelCfg {
     int explicit_centers, est_focal, undistort, mcon;
@@ -103,7 +104,7 @@ void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // spmv + update for iteration a.it
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . z_it
-void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *out_sum, double *out_max);
+void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max);
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
                        const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
                        double *cam_lin_new, double *scal);
