@@ -129,6 +129,12 @@ def main():
 
     if rank == 0:
         build_ms = tm["build_ms"] / max(tm["build_launches"], 1)
+        # HBM traffic of one k_build launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
+        # inside this process); only quoted for the configuration it was measured on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_kbuild_traffic.json")
+        if world == 1 and args.config == "C3" and os.path.exists(tpath):
+            traffic = json.load(open(tpath))["hbm_bytes_gfx950_corrected"]
         achieved = tm["build_bytes"] / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
         out = {
             "metric": "LM iterations/sec (+ final reprojection RMSE), 1k cams / 1M pts",
@@ -147,7 +153,8 @@ def main():
             "setup_s": {"scene": t_gen, "plan_upload": t_plan},
             "roofline": {"bound": "hbm", "kernel": "k_build<7,LDS> (fused linearise + Schur complement)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": tm["build_bytes"], "avg_launch_ms": build_ms},
+                         "traffic": traffic, "traffic_source": "profiles/r01_kbuild_traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes)" if traffic else None,
+                         "algorithmic_bytes_per_launch": tm["build_bytes"], "avg_launch_ms": build_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_mod)
