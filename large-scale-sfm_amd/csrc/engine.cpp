@@ -135,6 +135,17 @@ int Engine::prepare()
     if (!m_ || !n_ || !nobs_) { err = "prepare: cameras, points and observations must be set first"; return MI_BA_ERROR; }
     if (cfg.mcon < 0 || cfg.mcon > m_) { err = "prepare: bad mcon"; return MI_BA_ERROR; }
     if (cfg.world > 1 && !comm_) { err = "prepare: world > 1 needs mi_ba_comm_init first"; return MI_BA_ERROR; }
+    if (cfg.world == 1 && !comm_ && std::getenv("MI_BA_FORCE_COMM")) {
+        // test hook: run the RCCL exchange on a one-rank communicator, so the collective calls (buffers,
+        // counts, stream) are exercised on a single-GPU box
+        ncclUniqueId uid;
+        ncclComm_t c;
+        if (ncclGetUniqueId(&uid) != ncclSuccess || ncclCommInitRank(&c, 1, uid, 0) != ncclSuccess) {
+            err = "prepare: MI_BA_FORCE_COMM: cannot create a one-rank RCCL communicator";
+            return MI_BA_ERROR;
+        }
+        comm_ = c;
+    }
     // sba_levmar.c:645-650: fewer measurements than unknowns is an error
     if (2 * nobs_ < (int64_t)m_ * cnp + 3 * (int64_t)n_) {
         err = "cannot solve a problem with fewer measurements than unknowns";
@@ -239,7 +250,7 @@ int Engine::set_params(const double *a, const double *xyz)
 
 bool Engine::allreduce1()
 {
-    if (cfg.world <= 1) return true;
+    if (!comm_) return true;
     double t0 = now_ms();
     const size_t nsum = (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP + 8;
     ncclResult_t r = ncclAllReduce(d_acc_.p, d_acc_.p, nsum, ncclDouble, ncclSum, (ncclComm_t)comm_, st_);
@@ -251,7 +262,7 @@ bool Engine::allreduce1()
 
 bool Engine::allreduce2()
 {
-    if (cfg.world <= 1) return true;
+    if (!comm_) return true;
     ncclResult_t r = ncclAllReduce(scal_() + 32, scal_() + 32, 8, ncclDouble, ncclSum, (ncclComm_t)comm_, st_);
     if (r == ncclSuccess) r = ncclAllReduce(scal_() + 40, scal_() + 40, 8, ncclDouble, ncclMax, (ncclComm_t)comm_, st_);
     if (r != ncclSuccess) return fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r));

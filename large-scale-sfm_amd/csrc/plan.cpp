@@ -182,13 +182,16 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         }
     }
 
-    // ---- batches and tiles
-    // tile length: long enough that the per-tile flush of the LDS accumulators is amortised, short
-    // enough that the grid still has ~8 workgroups per CU (256 CUs) to balance
-    if (auto_tile) {
-        const int est_batches = nol / kWave + 1;
-        tile_max_batches = std::min(kMaxTileBatches, std::max(2, (est_batches + 2047) / 2048));
-    }
+    // ---- batches and tiles (as a lambda: the automatic tile length needs a first pass to see where the
+    // slot / camera budgets force tiles to end)
+    std::vector<std::pair<int, bool>> tile_log; // per LDS tile: batches, closed only because of the length cap
+    int t = 0;
+    std::string tiling_error;
+    auto do_tiling = [&](int tile_max_batches) {
+    tile_log.clear();
+    pl.pair.clear(); pl.pair_gblk.clear(); pl.slot_gblk.clear(); pl.cslot_cam.clear(); pl.tile_mode.clear();
+    pl.long_pts.clear(); pl.max_slots = 0;
+    std::fill(pl.obs_cslot.begin(), pl.obs_cslot.end(), 0);
     pl.batch_obs.assign(1, 0); pl.batch_pt.assign(1, 0); pl.batch_pair.assign(1, 0);
     pl.tile_batch.assign(1, 0); pl.tile_slot.assign(1, 0); pl.tile_cslot.assign(1, 0);
     std::unordered_map<uint64_t, int> smap;
@@ -196,7 +199,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     std::vector<int> sig_slots;       // slots of the previous point's pairs (signature cache)
     const int *sig_cams = nullptr; int sig_d = -1;
     int cur_obs = 0, batches_in_tile = 0;
-    int t = 0;
+    t = 0;
 
     std::vector<uint32_t> round_buf;  // pair entries of the round being filled (LDS tiles)
     bool rounds_mode = true;
@@ -224,6 +227,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         pl.tile_slot.push_back((int)pl.slot_gblk.size());
         pl.tile_cslot.push_back((int)pl.cslot_cam.size());
         pl.tile_mode.push_back(mode);
+        if (mode == 1) tile_log.emplace_back(batches_in_tile, batches_in_tile >= tile_max_batches);
         pl.max_slots = std::max(pl.max_slots, (int)smap.size());
         smap.clear(); cmap.clear(); sig_cams = nullptr; sig_d = -1;
         batches_in_tile = 0;
@@ -266,7 +270,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                         s = (int)smap.size();
                         smap.emplace(key, s);
                         int g = pl.upper_block(c[a], c[b]);
-                        if (g < 0) return "internal: block missing from pattern";
+                        if (g < 0) { tiling_error = "internal: block missing from pattern"; return; }
                         pl.slot_gblk.push_back(g);
                     } else s = it->second;
                     sig_slots.push_back(s);
@@ -303,7 +307,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         for (int a = 0; a < d; ++a)
             for (int b = a; b < d; ++b) {
                 int g = pl.upper_block(c[a], c[b]);
-                if (g < 0) return "internal: block missing from pattern";
+                if (g < 0) { tiling_error = "internal: block missing from pattern"; return; }
                 pl.pair.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6));
                 pl.pair_gblk.push_back((uint32_t)g);
             }
@@ -314,6 +318,35 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
 
     // class 2: long points
     for (; t < npl; ++t) pl.long_pts.push_back(t);
+    };
+
+    do_tiling(tile_max_batches);
+    if (!tiling_error.empty()) return tiling_error;
+    if (auto_tile) {
+        // k_build runs 4 one-wave workgroups per CU = kTileSlots tiles at a time.  Natural segments = runs of
+        // batches between two forced tile ends; choose the length cap whose tile count fills whole rounds of
+        // slots best (a 5.1-round grid costs 6 rounds), preferring long tiles; small problems get many tiles.
+        std::vector<int> segs;
+        int run = 0;
+        for (auto &tl : tile_log) { run += tl.first; if (!tl.second) { segs.push_back(run); run = 0; } }
+        if (run) segs.push_back(run);
+        double best = -1e30; int best_tmb = tile_max_batches;
+        long long total_batches = 0;
+        for (int sg : segs) total_batches += sg;
+        if (total_batches < 4LL * kTileSlots) { // small problem: spread over as many workgroups as possible
+            best_tmb = (int)std::max<long long>(2, (total_batches + kTileSlots - 1) / kTileSlots);
+            segs.clear();
+        }
+        for (int tmb = kMaxTileBatches; tmb >= 2 && !segs.empty(); --tmb) {
+            long long tiles = 0;
+            for (int sg : segs) tiles += (sg + tmb - 1) / tmb;
+            if (!tiles) break;
+            const long long rounds = (tiles + kTileSlots - 1) / kTileSlots;
+            const double eff = (double)tiles / ((double)rounds * kTileSlots) - 0.003 * (kMaxTileBatches - tmb);
+            if (eff > best) { best = eff; best_tmb = tmb; }
+        }
+        if (best_tmb != tile_max_batches) { do_tiling(best_tmb); if (!tiling_error.empty()) return tiling_error; }
+    }
     return "";
 }
 

@@ -253,6 +253,17 @@ def test_mixed_track_lengths_and_unsorted_cameras(oracle):
     assert np.array_equal(p[m * cnp:].reshape(n, 3)[unobserved], sc.p0[m * cnp:].reshape(n, 3)[unobserved])
 
 
+def test_rccl_exchange_on_a_one_rank_communicator(oracle, monkeypatch):
+    """the all-reduce calls of the multi-GPU path (same buffers, counts and stream) on this single GPU"""
+    monkeypatch.setenv("MI_BA_FORCE_COMM", "1")
+    sc, z = scene_from_golden("C1")
+    eng = make_engine(sc)
+    ret, info = eng.run()
+    assert eng.timing()["allreduces"] > 0
+    assert ret == int(z["ret_final"]) and info[6] == z["info_final"][6]
+    assert abs(np.sqrt(info[1] / sc.nobs) - np.sqrt(z["info_final"][1] / sc.nobs)) < 1e-6
+
+
 def test_error_paths():
     capi = pkg("capi")
     sc, _ = scene_from_golden("micro")
