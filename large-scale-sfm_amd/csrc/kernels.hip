@@ -213,7 +213,6 @@ struct BatchRegs {
     long long q0, q1;
     int j, ip, cs;
     double2 xy;
-    unsigned ent[LDS ? kMaxRounds : 1];   // this lane's pair entry of every round (LDS tiles)
 };
 
 // batch descriptors of a whole tile (<= 32 batches) sit in registers, one batch per lane, loaded once in
@@ -234,13 +233,6 @@ __device__ __forceinline__ void load_batch_level1(const BuildArgs &g, const Tile
         const int o = r.o0 + lane;
         r.j = g.obs_cam[o]; r.ip = g.obs_pt[o]; r.xy = g.obs_xy[o];
         if constexpr (LDS) r.cs = g.obs_cslot[o];
-    }
-    if constexpr (LDS) {
-#pragma unroll
-        for (int t = 0; t < kMaxRounds; ++t) {
-            const long long q = r.q0 + (long long)t * kWave + lane;
-            r.ent[t] = (q < r.q1) ? g.pair[q] : kPairInvalid;
-        }
     }
 }
 
@@ -305,7 +297,7 @@ __device__ __forceinline__ void pair_block(const double *sR, const double *sv, i
 #endif
 
 template <int CNP, bool LDS>
-__global__ __launch_bounds__(64) void k_build(const BuildArgs g)
+__global__ __launch_bounds__(64, 2) void k_build(const BuildArgs g)
 {
 #ifdef MIBA_STAMPS
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
@@ -317,10 +309,14 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
     constexpr int OB = 2 * CNP;               // offset of B inside the row (even)
     constexpr int SR = (((OB + 8) / 2) % 2 == 1) ? OB + 8 : OB + 10;
     constexpr int SV = 10;                    // sV row: Vinv (6) h (3) pad; 80 B, 16-byte aligned
-    constexpr int BLK = CNP * CNP, SS = BLK | 1, NCV = 2 * CNP, SC = (3 * CNP) | 1;
+    constexpr int BLK = CNP * CNP, SC = (3 * CNP) | 1;
     __shared__ __attribute__((aligned(16))) double sR[kWave * SR];
     __shared__ __attribute__((aligned(16))) double sV[kMaxPtsBatch * SV];
-    __shared__ double sS[LDS ? kNSlot * SS : 1], sC[LDS ? kNCSlot * SC : 1];
+    // LDS budget: <= 20 KB so that TWO tiles share a SIMD (8 workgroups per CU).  The S blocks live in
+    // registers; sStage only transposes them (kStageLanes lanes at a time) into the contiguous 49-double
+    // shape a global f64 atomic wants.
+    constexpr int kStageLanes = 5;
+    __shared__ double sStage[LDS ? kStageLanes * BLK : 1], sC[LDS ? kNCSlot * SC : 1];
     __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
     __shared__ int sLp[LDS ? 1 : kWave];      // local point of every observation (direct tiles; LDS tiles carry it in the pair entry)
 
@@ -331,20 +327,52 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
     if constexpr (LDS) {
         nslots = g.tile_slot[tile + 1] - g.tile_slot[tile];
         ncs = g.tile_cslot[tile + 1] - g.tile_cslot[tile];
-        for (int i = lane; i < nslots * SS; i += kWave) sS[i] = 0.0;
         for (int i = lane; i < ncs * SC; i += kWave) sC[i] = 0.0;
     }
     double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0;
-    // register-resident accumulators (LDS tiles): this lane's S block and this lane's camera vectors
-    // (ea_j, E_j); both follow the lane for as long as its block / camera slot does not change
-    double acc[LDS ? BLK : 1], cacc[LDS ? NCV : 1];
-    int cur_slot = -1, cur_cs = -1;
+    // register-resident accumulator (LDS tiles): this lane's S block follows the lane for as long as its
+    // block does not change
+    double acc[LDS ? BLK : 1];
+    int cur_slot = -1;
     if constexpr (LDS) {
 #pragma unroll
         for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < NCV; ++i) cacc[i] = 0.0;
     }
+
+    // slot -> block and camera-slot -> camera tables of the tile: one coalesced load, one entry per lane
+    int my_gblk = 0, my_cam = 0;
+    if constexpr (LDS) {
+        my_gblk = lane < nslots ? g.slot_gblk[g.tile_slot[tile] + lane] : 0;
+        my_cam = lane < ncs ? g.cslot_cam[g.tile_cslot[tile] + lane] : 0;
+    }
+    // wave-collective: every lane hands its register-resident block to HBM.  kStageLanes blocks at a time go
+    // through sStage so that ONE global f64 atomic instruction adds ONE contiguous 7x7 block (the full-rate
+    // atomic shape); then the accumulators restart from zero.
+    auto flush_blocks = [&]() {
+        if constexpr (LDS) {
+            const int rr = lane / CNP, cc = lane - rr * CNP;
+            for (int base = 0; base < kWave; base += kStageLanes) {
+                const int q = lane - base;
+                if (q >= 0 && q < kStageLanes && cur_slot >= 0) {
+                    double *dst = sStage + q * BLK;
+#pragma unroll
+                    for (int i = 0; i < BLK; ++i) dst[i] = acc[i];
+                }
+                wave_lds_sync();
+                for (int q2 = 0; q2 < kStageLanes && base + q2 < kWave; ++q2) {
+                    const int cL = rl(cur_slot, base + q2);
+                    if (cL >= 0) {
+                        const int gb = rl(my_gblk, cL);
+                        if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + rr * kCP + cc], sStage[q2 * BLK + lane]);
+                    }
+                }
+                wave_lds_sync();
+            }
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
+            cur_slot = -1;
+        }
+    };
 
     const int b_begin = g.tile_batch[tile], b_end = g.tile_batch[tile + 1];
     TileDesc td;
@@ -355,8 +383,7 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         td.pair_lo = (int)(unsigned)pq; td.pair_hi = (int)(pq >> 32);
     }
     BatchRegs<LDS> cur, nxt;
-    double X[3], cl[kCamLin];
-    int cl_cam = -1;
+    double X[3];
     load_batch_level1<LDS>(g, td, 0, lane, cur);
     X[0] = g.pts[3 * (size_t)cur.ip]; X[1] = g.pts[3 * (size_t)cur.ip + 1]; X[2] = g.pts[3 * (size_t)cur.ip + 2];
     nxt = cur;
@@ -369,11 +396,10 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
         const int j = cur.j, lp = cur.ip - p0, cs = cur.cs;
         bool head = false;
-        // ---- phase 1.  The 192-byte camera record is gathered from L2 only when this lane's camera
-        // changed since the previous batch: with signature-sorted points lane l keeps its camera for
-        // hundreds of points, and an uncoalesced 64-row gather costs ~1k cycles per batch.
+        // ---- phase 1 (camera records are L2-resident, 192 B x m)
         {
-            if (j != cl_cam) { load_cam_record(g, j, cl); cl_cam = j; }
+            double cl[kCamLin];
+            load_cam_record(g, j, cl);
             if (have_next) load_batch_level1<LDS>(g, td, b + 1 - b_begin, lane, nxt);   // streams + pair entries of the next batch
             STAMP(7);
             if (active) {
@@ -446,35 +472,33 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         }
         wave_lds_sync();
         STAMP(3);
-        // ---- phase 4: camera-side vectors ea_j, E_j = A^T (e - B h)  (+ diag U_j on request)
+        // ---- phase 4: camera-side vectors ea_j, E_j = A^T (e - B h)  (+ diag U_j on request).
+        // The pair entries of this batch are requested first; phase 4 and the other wavefront of the SIMD
+        // cover their latency.
+        unsigned ent_r[LDS ? kMaxRounds : 1];
+        if constexpr (LDS) {
+#pragma unroll
+            for (int t = 0; t < kMaxRounds; ++t) {
+                const long long q = cur.q0 + (long long)t * kWave + lane;
+                ent_r[t] = (q < cur.q1) ? g.pair[q] : kPairInvalid;
+            }
+        }
         if (active && !g.cam_fixed[j]) {
             const double *sv = sV + lp * SV;
             double er[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) er[r] = e[r] - (B[r][0] * sv[6] + B[r][1] * sv[7] + B[r][2] * sv[8]);
-            if constexpr (LDS) {
-                if (cs != cur_cs) { // this lane now serves another camera: spill the finished vectors
-                    if (cur_cs >= 0) {
 #pragma unroll
-                        for (int t = 0; t < NCV; ++t) { ladd(&sC[cur_cs * SC + t], cacc[t]); cacc[t] = 0.0; }
-                    }
-                    cur_cs = cs;
-                }
-#pragma unroll
-                for (int t = 0; t < CNP; ++t) {
-                    cacc[t] = fma(A[1][t], e[1], fma(A[0][t], e[0], cacc[t]));
-                    cacc[CNP + t] = fma(A[1][t], er[1], fma(A[0][t], er[0], cacc[CNP + t]));
-                }
-                if (g.want_diag) {
-#pragma unroll
-                    for (int t = 0; t < CNP; ++t) ladd(&sC[cs * SC + 2 * CNP + t], A[0][t] * A[0][t] + A[1][t] * A[1][t]);
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < CNP; ++t) {
-                    gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], A[0][t] * e[0] + A[1][t] * e[1]);
-                    gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], A[0][t] * er[0] + A[1][t] * er[1]);
-                    if (g.want_diag) gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], A[0][t] * A[0][t] + A[1][t] * A[1][t]);
+            for (int t = 0; t < CNP; ++t) {
+                const double vea = fma(A[1][t], e[1], A[0][t] * e[0]);
+                const double vE = fma(A[1][t], er[1], A[0][t] * er[0]);
+                if constexpr (LDS) {
+                    ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE);
+                    if (g.want_diag) ladd(&sC[cs * SC + 2 * CNP + t], fma(A[1][t], A[1][t], A[0][t] * A[0][t]));
+                } else {
+                    gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], vea);
+                    gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], vE);
+                    if (g.want_diag) gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], fma(A[1][t], A[1][t], A[0][t] * A[0][t]));
                 }
             }
         }
@@ -482,31 +506,29 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         // ---- phase 5: pair products (reads sR, sV only: no barrier needed after phase 4)
         if constexpr (LDS) {
             const int nrounds = (int)((cur.q1 - cur.q0) / kWave);
+            for (int k = 0; k < nrounds; ++k) {
+                unsigned ent = ent_r[0];
 #pragma unroll
-            for (int k = 0; k < kMaxRounds; ++k) {
-                if (k >= nrounds) break;
-                const unsigned ent = cur.ent[k];
-                if (ent == kPairInvalid) continue;
+                for (int t = 1; t < kMaxRounds; ++t) ent = (k == t) ? ent_r[t] : ent;
+                const bool valid = ent != kPairInvalid;
                 const int la = ent & 63, lb = (ent >> 6) & 63, slot = (ent >> 12) & 63, plp = (ent >> 18) & 31;
-                double T0[CNP], T1[CNP];
-                pair_block<CNP, SR>(sR, sV + plp * SV, la, lb, T0, T1);
-                if (slot != cur_slot) { // this lane's block changed: spill the finished one
-                    if (cur_slot >= 0) {
-                        double *dst = sS + cur_slot * SS;
-#pragma unroll
-                        for (int i = 0; i < BLK; ++i) { ladd(&dst[i], acc[i]); acc[i] = 0.0; }
-                    }
+                // some lane is about to start another block: everybody flushes (in signature-sorted data all
+                // lanes change together, once per few hundred points)
+                if (__any(valid && cur_slot >= 0 && slot != cur_slot)) flush_blocks();
+                if (valid) {
                     cur_slot = slot;
-                }
-                const double2 *Aa2 = reinterpret_cast<const double2 *>(sR + la * SR);
-                double Aa[2 * CNP];
+                    double T0[CNP], T1[CNP];
+                    pair_block<CNP, SR>(sR, sV + plp * SV, la, lb, T0, T1);
+                    const double2 *Aa2 = reinterpret_cast<const double2 *>(sR + la * SR);
+                    double Aa[2 * CNP];
 #pragma unroll
-                for (int k2 = 0; k2 < CNP; ++k2) { const double2 v = Aa2[k2]; Aa[2 * k2] = v.x; Aa[2 * k2 + 1] = v.y; }
+                    for (int k2 = 0; k2 < CNP; ++k2) { const double2 v = Aa2[k2]; Aa[2 * k2] = v.x; Aa[2 * k2 + 1] = v.y; }
 #pragma unroll
-                for (int r = 0; r < CNP; ++r) {
-                    const double a0 = Aa[r], a1 = Aa[CNP + r];
+                    for (int r = 0; r < CNP; ++r) {
+                        const double a0 = Aa[r], a1 = Aa[CNP + r];
 #pragma unroll
-                    for (int c = 0; c < CNP; ++c) acc[r * CNP + c] = fma(a1, T1[c], fma(a0, T0[c], acc[r * CNP + c]));
+                        for (int c = 0; c < CNP; ++c) acc[r * CNP + c] = fma(a1, T1[c], fma(a0, T0[c], acc[r * CNP + c]));
+                    }
                 }
             }
         } else {
@@ -529,29 +551,13 @@ __global__ __launch_bounds__(64) void k_build(const BuildArgs g)
         STAMP(5);
         if (have_next) cur = nxt;
     }
-    // ---- flush: registers -> LDS table -> HBM (one S block = one contiguous f64 atomic wave instruction)
+    // ---- flush: S blocks registers -> HBM, camera vectors registers -> LDS slots -> HBM
     if constexpr (LDS) {
-        if (cur_slot >= 0) {
-            double *dst = sS + cur_slot * SS;
-#pragma unroll
-            for (int i = 0; i < BLK; ++i) ladd(&dst[i], acc[i]);
-        }
-        if (cur_cs >= 0) {
-#pragma unroll
-            for (int t = 0; t < NCV; ++t) ladd(&sC[cur_cs * SC + t], cacc[t]);
-        }
+        flush_blocks();
         wave_lds_sync();
-        // slot -> block and camera-slot -> camera tables: one coalesced load, then lane broadcasts
-        const int my_gblk = lane < nslots ? g.slot_gblk[g.tile_slot[tile] + lane] : 0;
-        const int my_cam = lane < ncs ? g.cslot_cam[g.tile_cslot[tile] + lane] : 0;
-        const int r = lane / CNP, c = lane - r * CNP;
-        for (int s = 0; s < nslots; ++s) {
-            const int gb = __shfl(my_gblk, s);
-            if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + r * kCP + c], sS[s * SS + lane]);
-        }
         const int which = lane / CNP, t = lane - which * CNP;
         for (int k = 0; k < ncs; ++k) {
-            const int cam = __shfl(my_cam, k);
+            const int cam = rl(my_cam, k);
             if (lane < 3 * CNP) gadd(&g.camvec[((size_t)which * g.m + cam) * kCP + t], sC[k * SC + lane]);
         }
     }

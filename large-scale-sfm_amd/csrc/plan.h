@@ -27,7 +27,7 @@ constexpr int kNSlot = 55;       // S-block accumulators per LDS tile (55 = pair
 constexpr int kNCSlot = 24;      // camera accumulators per LDS tile
 constexpr int kMaxPtsBatch = 32; // points per batch (bounds the per-point LDS staging)
 constexpr int kMaxTileBatches = 32; // batches per tile (k_build keeps a tile's batch descriptors one per lane)
-constexpr int kTileSlots = 1024;     // concurrently resident k_build workgroups: 256 CUs x 4
+constexpr int kTileSlots = 2048;     // concurrently resident k_build workgroups: 256 CUs x 8 (two per SIMD)
 constexpr int kMaxRounds = 8;    // pair rounds per LDS-tile batch (k_build preloads them into registers)
 constexpr uint32_t kPairInvalid = 0xFFFFFFFFu; // padding entry of a pair round
 constexpr int kMaxViewsLds = 10; // d(d+1)/2 <= kNSlot
