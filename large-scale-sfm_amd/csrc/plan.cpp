@@ -330,20 +330,16 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         int run = 0;
         for (auto &tl : tile_log) { run += tl.first; if (!tl.second) { segs.push_back(run); run = 0; } }
         if (run) segs.push_back(run);
-        double best = -1e30; int best_tmb = tile_max_batches;
-        long long total_batches = 0;
-        for (int sg : segs) total_batches += sg;
-        if (total_batches < 4LL * kTileSlots) { // small problem: spread over as many workgroups as possible
-            best_tmb = (int)std::max<long long>(2, (total_batches + kTileSlots - 1) / kTileSlots);
-            segs.clear();
-        }
-        for (int tmb = kMaxTileBatches; tmb >= 2 && !segs.empty(); --tmb) {
-            long long tiles = 0;
-            for (int sg : segs) tiles += (sg + tmb - 1) / tmb;
+        // cost model: the grid runs in rounds of kTileSlots tiles; a round lasts as long as its longest tile,
+        // a tile costs (batches x Tb + Tf) with Tf the fixed prologue/flush share (~1.5 batches, measured)
+        double best = 1e300; int best_tmb = tile_max_batches;
+        for (int tmb = kMaxTileBatches; tmb >= 2; --tmb) {
+            long long tiles = 0; int longest = 0;
+            for (int sg : segs) { tiles += (sg + tmb - 1) / tmb; longest = std::max(longest, std::min(sg, tmb)); }
             if (!tiles) break;
             const long long rounds = (tiles + kTileSlots - 1) / kTileSlots;
-            const double eff = (double)tiles / ((double)rounds * kTileSlots) - 0.003 * (kMaxTileBatches - tmb);
-            if (eff > best) { best = eff; best_tmb = tmb; }
+            const double cost = (double)rounds * ((double)longest + 1.5);
+            if (cost < best * 0.999) { best = cost; best_tmb = tmb; }
         }
         if (best_tmb != tile_max_batches) { do_tiling(best_tmb); if (!tiling_error.empty()) return tiling_error; }
     }
