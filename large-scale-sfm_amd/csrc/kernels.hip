@@ -1084,32 +1084,51 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
 template <int CNP>
 __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
 {
-    __shared__ double sT[kWave * 3], sX[kWave * 3];
+    __shared__ double sT[kWave * 3], sX[kMaxPtsBatch * 3];
+    __shared__ int sStart[kMaxPtsBatch + 1];
     const int lane = threadIdx.x;
     const ModelCfg cfg = g.cfg;
     double cn = 0.0, pct = 0.0, dl = 0.0, dp2 = 0.0;
     // Each workgroup walks a CONTIGUOUS chunk of batches: with signature-sorted points lane l sees the
     // same camera batch after batch, so the three per-camera gathers (record at p, record at p + dp, da)
-    // stay in registers and are re-fetched only when the lane's camera changes.  The kernel was bound by
-    // the texture addresser (TA_BUSY 85 %, 29 cache accesses per observation) before this.
+    // stay in registers and are re-fetched only when the lane's camera changes (the kernel was bound by the
+    // texture addresser before: TA_BUSY 85 %, 29 cache accesses per observation).  The observation stream
+    // of the next batch is requested one batch ahead; everything a batch needs from HBM (point, ptout row
+    // of the head lane) is requested at its top, so no load sits behind an LDS hand-off.
     const int chunk = (g.nbatch + gridDim.x - 1) / gridDim.x;
     const int b0 = blockIdx.x * chunk, b1 = min(g.nbatch, b0 + chunk);
     double cl[kCamLin], cln[16], da[kCP];
     int jc = -1;
+    // software pipeline registers: the next batch's descriptor and observation stream
+    int n_o0 = 0, n_nob = 0, n_p0 = 0, n_npt = 0, n_j = 0, n_ip = 0;
+    double2 n_xy = make_double2(0.0, 0.0);
+    auto load_stream = [&](int b) {
+        n_o0 = g.batch_obs[b]; n_nob = g.batch_obs[b + 1] - n_o0;
+        n_p0 = g.batch_pt[b]; n_npt = g.batch_pt[b + 1] - n_p0;
+        n_j = 0; n_ip = n_p0; n_xy = make_double2(0.0, 0.0);
+        if (lane < n_nob) { const int o = n_o0 + lane; n_j = g.obs_cam[o]; n_ip = g.obs_pt[o]; n_xy = g.obs_xy[o]; }
+    };
+    if (b0 < b1) load_stream(b0);
     for (int b = b0; b < b1; ++b) {
-        const int o0 = g.batch_obs[b], nob = g.batch_obs[b + 1] - o0;
-        const int p0 = g.batch_pt[b], npt = g.batch_pt[b + 1] - p0;
+        const int nob = n_nob, p0 = n_p0, npt = n_npt, j = n_j, ip = n_ip;
+        const double2 xy = n_xy;
         const bool active = lane < nob;
+        const int lp = ip - p0;
+        if (b + 1 < b1) load_stream(b + 1);
+        // everything this batch needs from HBM, requested now
+        const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
+        const int lp_prev = __shfl_up(active ? lp : -2, 1);
+        const bool head = active && (lane == 0 || lp != lp_prev);
+        double2 po[6];
+        if (head) {
+            const double2 *po2 = reinterpret_cast<const double2 *>(g.ptout + (size_t)ip * kPtOut);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) po[k] = po2[k];
+            sStart[lp] = lane;
+        }
+        if (lane == 0) sStart[npt] = nob;
         double e[2] = { 0.0, 0.0 };
-        int j = 0, lp = 0;
-        double2 xy = make_double2(0.0, 0.0);
         if (active) {
-            const int o = o0 + lane;
-            j = g.obs_cam[o];
-            const int ip = g.obs_pt[o];
-            lp = ip - p0;
-            xy = g.obs_xy[o];
-            const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
             if (j != jc) {
                 const double2 *s0 = reinterpret_cast<const double2 *>(g.cam_lin + (size_t)j * kCamLin);
                 const double2 *s1 = reinterpret_cast<const double2 *>(g.cam_lin_new + (size_t)j * kCamLin);
@@ -1133,20 +1152,18 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
             for (int t = 0; t < 3; ++t) sT[lane * 3 + t] = B[0][t] * w0 + B[1][t] * w1;
         }
         wave_lds_sync();
-        if (lane < npt) {
-            const int ip = p0 + lane;
-            const int os = g.pt_obs[ip] - o0, oe = g.pt_obs[ip + 1] - o0;
+        if (head) { // the head lane of a point owns the point: it already holds X and the ptout row
+            const int oe = sStart[lp + 1];
             double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-            for (int o = os; o < oe; ++o) { t0 += sT[o * 3]; t1 += sT[o * 3 + 1]; t2 += sT[o * 3 + 2]; }
-            const double2 *po2 = reinterpret_cast<const double2 *>(g.ptout + (size_t)ip * kPtOut);
-            const double2 i01 = po2[0], i23 = po2[1], i45 = po2[2], h01 = po2[3], h2e0 = po2[4], e12 = po2[5];
+            for (int o = lane; o < oe; ++o) { t0 += sT[o * 3]; t1 += sT[o * 3 + 1]; t2 += sT[o * 3 + 2]; }
+            const double2 i01 = po[0], i23 = po[1], i45 = po[2], h01 = po[3], h2e0 = po[4], e12 = po[5];
             const double d0 = h01.x - (i01.x * t0 + i01.y * t1 + i23.x * t2);
             const double d1 = h01.y - (i01.y * t0 + i23.y * t1 + i45.x * t2);
             const double d2 = h2e0.x - (i23.x * t0 + i45.x * t1 + i45.y * t2);
-            const double X0 = g.pts[3 * (size_t)ip] + d0, X1 = g.pts[3 * (size_t)ip + 1] + d1, X2 = g.pts[3 * (size_t)ip + 2] + d2;
+            const double X0 = X[0] + d0, X1 = X[1] + d1, X2 = X[2] + d2;
             g.pts_new[3 * (size_t)ip] = X0; g.pts_new[3 * (size_t)ip + 1] = X1; g.pts_new[3 * (size_t)ip + 2] = X2;
             if (g.dB) { g.dB[3 * (size_t)ip] = d0; g.dB[3 * (size_t)ip + 1] = d1; g.dB[3 * (size_t)ip + 2] = d2; }
-            sX[lane * 3] = X0; sX[lane * 3 + 1] = X1; sX[lane * 3 + 2] = X2;
+            sX[lp * 3] = X0; sX[lp * 3 + 1] = X1; sX[lp * 3 + 2] = X2;
             dl += d0 * (g.mu * d0 + h2e0.y) + d1 * (g.mu * d1 + e12.x) + d2 * (g.mu * d2 + e12.y);
             dp2 += d0 * d0 + d1 * d1 + d2 * d2;
         }
