@@ -59,7 +59,11 @@ typedef struct {
     int verbose;
     /* planner knobs (0 = default) */
     int tile_max_batches;
-    int reserved[7];
+    /* 0: cameras + points (sba_motstr_levmar), 1: cameras only, points fixed (sba_mot_levmar, sba.h:110-116;
+     * ParallelBA::BUNDLE_ONLY_MOTION), 2: points only, cameras fixed (sba_str_levmar, sba.h:118-123;
+     * BUNDLE_ONLY_STRUCTURE) */
+    int mode;
+    int reserved[6];
 } mi_ba_config;
 
 /* fills the defaults above (Bundler's run_sfm settings, cnp 7, explicit centres) */

@@ -36,6 +36,7 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
 {
     cnp = 6 + (cfg.est_focal ? 1 : 0);
     if (cfg.undistort) { err = "undistort (k1,k2 as parameters, cnp 8/9) is not supported yet"; return; }
+    if (cfg.mode < 0 || cfg.mode > 2) { err = "bad bundle mode"; return; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -71,7 +72,7 @@ ModelCfg Engine::model() const
 {
     ModelCfg mc;
     mc.explicit_centers = cfg.explicit_centers; mc.est_focal = cfg.est_focal; mc.undistort = cfg.undistort;
-    mc.mcon = cfg.mcon; mc.proj_sign = cfg.proj_sign; mc.f_scale = cfg.f_scale; mc.k_scale = cfg.k_scale;
+    mc.mcon = cfg.mcon; mc.points_fixed = cfg.mode == 1; mc.proj_sign = cfg.proj_sign; mc.f_scale = cfg.f_scale; mc.k_scale = cfg.k_scale;
     return mc;
 }
 
@@ -147,7 +148,7 @@ int Engine::prepare()
         comm_ = c;
     }
     // sba_levmar.c:645-650: fewer measurements than unknowns is an error
-    if (2 * nobs_ < (int64_t)m_ * cnp + 3 * (int64_t)n_) {
+    if (2 * nobs_ < (cfg.mode == 1 ? 0 : 3 * (int64_t)n_) + (cfg.mode == 2 ? 0 : (int64_t)m_ * cnp)) {
         err = "cannot solve a problem with fewer measurements than unknowns";
         return MI_BA_ERROR;
     }
@@ -189,8 +190,11 @@ int Engine::prepare()
         if ((int)h_fixed_.size() != m_) h_fixed_.assign(m_, 0);
         std::vector<unsigned char> fx(h_fixed_);
         for (int j = 0; j < cfg.mcon && j < m_; ++j) fx[j] = 1; // sba's leading mcon cameras
+        if (cfg.mode == 2) std::fill(fx.begin(), fx.end(), (unsigned char)1); // structure-only: A_ij := 0 everywhere
         UP(d_fixed_, fx);
         h_fixed_eff_ = fx;
+        nfree_cams_ = 0;
+        for (unsigned char f : fx) nfree_cams_ += f ? 0 : 1;
     }
 #undef UP
     const size_t npl = (size_t)pl.npts_local();
@@ -373,7 +377,7 @@ int Engine::begin()
     // probe pass: cost at p0 and the largest diagonal entry of U, V -> mu0 = tau * max (sba_levmar.c:1124-1128)
     if (!linear_phase(1.0, true) || !read_scalars()) return MI_BA_ERROR;
     p_eL2_ = init_p_eL2_ = h_scal_[SC_COST];
-    maxdiag_ = std::max(std::max(h_scal_[SC_MAXDIAG_U], h_scal_[SC_MAXDIAG_V]), DBL_MIN);
+    maxdiag_ = measured_maxdiag();
     eab_inf_ = std::max(h_scal_[SC_EA_INF], h_scal_[SC_EB_INF]);
     mu_ = std::fabs(cfg.opts[0]) * maxdiag_;
     if (!std::isfinite(p_eL2_)) stop_ = 7;
@@ -382,6 +386,13 @@ int Engine::begin()
 }
 
 void Engine::accept_trial() { cur_ ^= 1; }
+
+// largest diagonal entry of the free blocks: U and V, U only (points fixed) or V only (cameras fixed)
+double Engine::measured_maxdiag() const
+{
+    const double u = cfg.mode == 2 ? 0.0 : h_scal_[SC_MAXDIAG_U], v = cfg.mode == 1 ? 0.0 : h_scal_[SC_MAXDIAG_V];
+    return std::max(std::max(u, v), DBL_MIN);
+}
 
 // one damping trial; the control flow is sba_levmar.c:1085-1614 unrolled into a resumable step
 int Engine::step()
@@ -402,7 +413,8 @@ int Engine::step()
     const double *s = h_scal_;
     timing.pcg_iters += s[SC_PCG_ITERS];
     p_eL2_ = s[SC_COST];
-    p_L2_ = s[SC_PL2_CAMS] + s[SC_PL2_PTS] + pl2_inactive_;
+    // the truncated drivers' parameter vector is the free block only (sba_levmar.c:2234, 2838)
+    p_L2_ = (cfg.mode == 2 ? 0.0 : s[SC_PL2_CAMS]) + (cfg.mode == 1 ? 0.0 : s[SC_PL2_PTS] + pl2_inactive_);
     eab_inf_ = std::max(s[SC_EA_INF], s[SC_EB_INF]);
     // max diag(U, V) enters mu0 (begin) and info[4] only; diag U is not accumulated per trial, so
     // info[4] is normalised by the value of the last linearisation that measured it
@@ -419,7 +431,7 @@ int Engine::step()
     do {
         if (eab_inf_ <= eps1 && stops) { dp_L2_ = 0.0; stop_ = 1; ret = 2; break; }          // :1117-1121
         if (s[SC_SINGULAR] != 0.0) { push_trace(NAN, 0); goto moredamping; }                 // :1156-1158
-        ++nlss_;
+        nlss_ += cfg.mode == 1 ? nfree_cams_ : cfg.mode == 2 ? n_ : 1; // one system per camera / point there (:2510, :3083)
         if (s[SC_PCG_STATUS] != 0.0 || s[SC_NOT_PD] != 0.0) { push_trace(NAN, 0); goto moredamping; } // issolved == 0
         dp_L2_ = s[SC_DP2_CAMS] + s[SC_DP2_PTS];
         if (dp_L2_ <= eps2_sq * p_L2_ && stops) { stop_ = 2; end_outer(); ret = 2; break; }  // :1450-1454
@@ -442,7 +454,7 @@ int Engine::step()
                 if (stops) {
                     if (pdp_eL2 - 2.0 * std::sqrt(p_eL2_ * pdp_eL2) < (eps4_sq - 1.0) * p_eL2_) stop_ = 4; // :1567
                     // QUIRK kept (sba_levmar.c:1569-1572): stop 8 leaves before p <- p + dp
-                    if (s[SC_MAX_PCT] < eps5 && itno_ >= 4) { stop_ = 8; discard = true; }
+                    if (cfg.mode == 0 && s[SC_MAX_PCT] < eps5 && itno_ >= 4) { stop_ = 8; discard = true; } // motstr only
                 }
                 if (!discard) { accept_trial(); p_eL2_ = pdp_eL2; }
                 end_outer();
@@ -482,7 +494,7 @@ int Engine::run(double info[MI_BA_INFOSZ])
     // info[4] = mu / max diag(U, V) at the final estimate (sba_levmar.c:2033-2043): one more linearisation
     if (info && stop_ != 7) {
         if (!linear_phase(1.0, true) || !read_scalars()) return MI_BA_ERROR;
-        maxdiag_ = std::max(std::max(h_scal_[SC_MAXDIAG_U], h_scal_[SC_MAXDIAG_V]), DBL_MIN);
+        maxdiag_ = measured_maxdiag();
     }
     if (info) fill_info(info);
     return stop_ != 7 ? itno_ : MI_BA_ERROR;

@@ -74,6 +74,7 @@ private:
     bool allreduce1();
     bool allreduce2();
     void accept_trial();
+    double measured_maxdiag() const;
     ModelCfg model() const;
 
     bool created_ = false, prepared_ = false, begun_ = false;
@@ -116,6 +117,7 @@ private:
     double mu_ = 0, p_eL2_ = 0, init_p_eL2_ = 0, eab_inf_ = 0, dp_L2_ = 0, p_L2_ = 0, maxdiag_ = 0;
     int nu_ = 2, itno_ = 0, stop_ = 0, nfev_ = 0, njev_ = 0, nlss_ = 0;
     bool new_outer_ = true;
+    int nfree_cams_ = 0;
 };
 
 } // namespace miba

@@ -24,6 +24,7 @@ constexpr int kReduceStage = 64;      // first-stage workgroups of k_reduce_part
 
 struct ModelCfg {
     int explicit_centers, est_focal, undistort, mcon;
+    int points_fixed;   // motion-only bundle: B_ij := 0 (sba_mot_levmar_x has no structure block)
     double proj_sign, f_scale, k_scale;
 };
 

@@ -108,6 +108,12 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int t = 0; t < CNP; ++t) A[r][t] = 0.0;
+        if (cfg.points_fixed) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) B[r][t] = 0.0;
+        }
         return;
     }
     // M = -[qr]x Jl
@@ -127,6 +133,12 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
             A[r][3 + t] = Pq[r][0] * M[0][t] + Pq[r][1] * M[1][t] + Pq[r][2] * M[2][t];
         }
         if constexpr (CNP >= 7) A[r][6] = s * (r == 0 ? mx : my) * D / cfg.f_scale;
+    }
+    if (cfg.points_fixed) { // after A (A_C = -B above): no structure block in a motion-only bundle
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) B[r][t] = 0.0;
     }
 }
 

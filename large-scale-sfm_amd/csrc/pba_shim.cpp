@@ -83,8 +83,8 @@ int ParallelBA::RunBundleAdjustment()
     o.abort.store(false); o.iteration.store(0);
     // silent "nothing done" on missing input, SparseBundleCPU.cpp:2587-2590
     if (!o.valid_device || !o.cams || !o.pts || !o.meas || !o.ptidx || !o.camidx || !o.ncam || !o.npt || !o.nproj) return 0;
-    if (c.__use_radial_distortion != 0 || o.mode != BUNDLE_FULL) {
-        std::fprintf(stderr, "[mi_pba] radial distortion and the truncated bundle modes are not supported by this build\n");
+    if (c.__use_radial_distortion != 0) {
+        std::fprintf(stderr, "[mi_pba] radial distortion is not supported by this build\n");
         c.__bundle_return_code = 'E';
         return 0;
     }
@@ -96,6 +96,8 @@ int ParallelBA::RunBundleAdjustment()
     cfg.itmax = c.__lm_max_iteration;
     cfg.pcg_maxit = c.__cg_max_iteration; cfg.pcg_tol = c.__cg_norm_threshold;
     cfg.device = o.device; cfg.verbose = c.__verbose_level;
+    cfg.mode = o.mode == BUNDLE_ONLY_MOTION ? 1 : o.mode == BUNDLE_ONLY_STRUCTURE ? 2 : 0; // SetNextBundleMode, pba.h:103
+    o.mode = BUNDLE_FULL;                                                                 // "next" = one run
     mi_ba_engine *e = mi_ba_create(&cfg);
     if (!e) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(nullptr)); c.__bundle_return_code = 'E'; return 0; }
     const int m = (int)o.ncam, n = (int)o.npt, cnp = mi_ba_cnp(e);

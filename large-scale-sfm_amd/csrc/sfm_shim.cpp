@@ -11,7 +11,7 @@
 namespace {
 
 int solve(int n, int m, int mcon, const char *vmask, double *p, int cnp, const double *x, const double *R0,
-          const double *f_fixed, int explicit_centers, int itmax, int verbose, const double opts[6], double info[10])
+          const double *f_fixed, int explicit_centers, int itmax, int verbose, const double opts[6], double info[10], int mode = 0)
 {
     if (n <= 0 || m <= 0 || !vmask || !p || !x || !R0 || (cnp != 6 && cnp != 7)) {
         std::fprintf(stderr, "mi_sba_motstr_levmar: bad arguments (cnp must be 6 or 7)\n");
@@ -24,7 +24,7 @@ int solve(int n, int m, int mcon, const char *vmask, double *p, int cnp, const d
     mi_ba_config cfg;
     mi_ba_default_config(&cfg);
     cfg.est_focal = cnp == 7; cfg.explicit_centers = explicit_centers; cfg.mcon = mcon; cfg.proj_sign = -1.0;
-    cfg.itmax = itmax; cfg.verbose = verbose;
+    cfg.itmax = itmax; cfg.verbose = verbose; cfg.mode = mode;
     if (opts) std::memcpy(cfg.opts, opts, sizeof(cfg.opts));
     mi_ba_engine *e = mi_ba_create(&cfg);
     if (!e) { std::fprintf(stderr, "mi_sba_motstr_levmar: %s\n", mi_ba_last_error(nullptr)); return MI_BA_ERROR; }
@@ -56,10 +56,10 @@ int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *pro
                v3_t *, double, int fix_points, int optimize_for_fisheye,
                double eps2, double *Vout, double *Sout, double *Uout, double *Wout, double info_out[10])
 {
-    if (const_focal_length || undistort || use_constraints || use_point_constraints || fix_points || optimize_for_fisheye ||
+    if (const_focal_length || undistort || use_constraints || use_point_constraints || optimize_for_fisheye ||
         Vout || Sout || Uout || Wout) {
-        std::fprintf(stderr, "[run_sfm] this build supports est_focal_length / explicit_camera_centers / ncons only "
-                             "(no constraints, distortion, fisheye, fixed points or Vout/Sout/Uout/Wout)\n");
+        std::fprintf(stderr, "[run_sfm] this build supports est_focal_length / explicit_camera_centers / ncons / fix_points only "
+                             "(no constraints, distortion, fisheye or Vout/Sout/Uout/Wout)\n");
         return MI_BA_ERROR;
     }
     const int m = num_cameras, n = num_pts, cnp = est_focal_length ? 7 : 6;
@@ -76,7 +76,7 @@ int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *pro
     const double opts[6] = { 1.0e-3, 1.0e-10, eps2, 1.0e-12, 0.0, 4.0e-2 };                                         // :711-719
     double info[10] = { 0 };
     const int ret = solve(n, m, ncons, vmask, p.data(), cnp, projections, R0.data(), ff.data(), explicit_camera_centers,
-                          150 /* MAX_ITERS, sfm.c:820 */, 0, opts, info);
+                          150 /* MAX_ITERS, sfm.c:820 */, 0, opts, info, fix_points ? 1 : 0 /* sba_mot_levmar, sfm.c:845-852 */);
     if (info_out) std::memcpy(info_out, info, sizeof(info));
     if (ret == MI_BA_ERROR) return ret;
     std::printf("[run_sfm] Number of iterations: %d\n", (int)info[5]);

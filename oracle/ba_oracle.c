@@ -516,7 +516,7 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
                  eps4_sq = op->opts[4] * op->opts[4], eps5 = op->opts[5];
     int nt = 0;
     if (ntrace) *ntrace = 0;
-    if (nobs2 < nvars) { /* sba_levmar.c:647-650 */
+    if (nobs2 < ((op->mode == 1) ? (size_t)m * cnp : (op->mode == 2) ? 3 * (size_t)n : nvars)) { /* sba_levmar.c:647-650 */
         fprintf(stderr, "ba_oracle: fewer measurements [%zu] than unknowns [%zu]\n", nobs2, nvars);
         return -1;
     }
@@ -543,12 +543,22 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
     init_p_eL2 = p_eL2;
     if (!isfinite(p_eL2)) stop = 7;
 
+    /* mode 1 / 2: the truncated drivers keep one block of parameters fixed.  With B := 0 (points fixed) V, eb and
+     * W vanish, S = blockdiag(U*), E = ea and db = 0: exactly the m independent systems of sba_mot_levmar_x
+     * (sba_levmar.c:2489-2513).  With A := 0 the same gives the n systems of sba_str_levmar_x (:3073-3079).
+     * Their parameter vector (norms, dL) covers the free block only (nvars, :2234 / :2838), they have no
+     * Bundler stop rule 8 (:2589-2605), and they count one linear system per camera / point (:2510, :3083). */
+    const int mode = op->mode;
+    const size_t v0 = (mode == 2) ? (size_t)m * cnp : 0, v1 = (mode == 1) ? (size_t)m * cnp : nvars;
+    const int ABsz_ = 2 * cnp + 6;
     for (itno = 0; itno < op->itmax && !stop; ++itno) {
         jacobian(pb, op->fd_jacobian, p, jac); ++njev;
+        if (mode == 1) for (size_t o = 0; o < nobs; ++o) memset(jac + o * ABsz_ + 2 * cnp, 0, 6 * sizeof(double));
+        if (mode == 2) for (size_t o = 0; o < nobs; ++o) memset(jac + o * ABsz_, 0, 2 * cnp * sizeof(double));
         build_blocks(pb, jac, e, &bk);
         /* ||J^T e||_inf and ||p||^2, sba_levmar.c:1085-1088 */
         p_L2 = eab_inf = 0.0;
-        for (size_t i = 0; i < nvars; ++i) {
+        for (size_t i = v0; i < v1; ++i) {
             double t = fabs(eab[i]);
             if (eab_inf < t) eab_inf = t;
             p_L2 += p[i] * p[i];
@@ -561,7 +571,7 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
         if (eab_inf <= eps1 && !op->disable_stops) { dp_L2 = 0.0; stop = 1; break; }
         if (itno == 0) { /* sba_levmar.c:1124-1128 */
             double t = DBL_MIN;
-            for (size_t i = (size_t)mcon * cnp; i < nvars; ++i) if (diagUV[i] > t) t = diagUV[i];
+            for (size_t i = (mode == 2) ? v0 : (size_t)mcon * cnp; i < v1; ++i) if (diagUV[i] > t) t = diagUV[i];
             mu = tau * t;
         }
         while (1) {
@@ -576,7 +586,8 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
             }
             if (!singular) {
                 build_schur(pb, &bk, Vinv, S, E);
-                if (op->solver == 0) {
+                if (mode == 2) { issolved = 1; lin_it = 0; for (int i = 0; i < Sdim; ++i) dpa[(size_t)mcon * cnp + i] = 0.0; }
+                else if (op->solver == 0) {
                     issolved = chol_solve(S, E + (size_t)mcon * cnp, dpa + (size_t)mcon * cnp, Sdim);
                     lin_it = 0;
                 } else {
@@ -584,7 +595,7 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
                                        op->pcg_maxit, op->pcg_tol);
                     issolved = lin_it >= 0;
                 }
-                ++nlss;
+                nlss += (mode == 1) ? mmcon : (mode == 2) ? n : 1;
                 for (int i = 0; i < mcon * cnp; ++i) dpa[i] = 0.0;
             }
             double cost_trial = NAN;
@@ -604,7 +615,8 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
                     for (int r = 0; r < 3; ++r) dpb[3 * (size_t)i + r] = Vi[3 * r] * t[0] + Vi[3 * r + 1] * t[1] + Vi[3 * r + 2] * t[2];
                 }
                 dp_L2 = 0.0;
-                for (size_t i = 0; i < nvars; ++i) { pdp[i] = p[i] + dp[i]; dp_L2 += dp[i] * dp[i]; }
+                for (size_t i = 0; i < nvars; ++i) pdp[i] = p[i] + dp[i];
+                for (size_t i = v0; i < v1; ++i) dp_L2 += dp[i] * dp[i];
                 if (dp_L2 <= eps2_sq * p_L2 && !op->disable_stops) { stop = 2; break; } /* sba_levmar.c:1450 */
                 if (dp_L2 >= (p_L2 + eps2) / ORA_EPSILON_SQ) { /* sba_levmar.c:1456-1462 */
                     fprintf(stderr, "ba_oracle: augmented normal equations almost singular\n");
@@ -615,7 +627,7 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
                 cost_trial = pdp_eL2;
                 if (!isfinite(pdp_eL2)) { stop = 7; break; }
                 double dL = 0.0;
-                for (size_t i = 0; i < nvars; ++i) dL += dp[i] * (mu * dp[i] + eab[i]);
+                for (size_t i = v0; i < v1; ++i) dL += dp[i] * (mu * dp[i] + eab[i]);
                 double dF = p_eL2 - pdp_eL2;
                 if (dL > 0.0 && dF > 0.0) {
                     accepted = 1;
@@ -638,7 +650,7 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
                     }
                     if (!op->disable_stops) {
                         if (pdp_eL2 - 2.0 * sqrt(p_eL2 * pdp_eL2) < (eps4_sq - 1.0) * p_eL2) stop = 4;
-                        if (max_pct_change < eps5 && itno >= 4) { stop = 8; break; }
+                        if (mode == 0 && max_pct_change < eps5 && itno >= 4) { stop = 8; break; }
                     }
                     memcpy(p, pdp, sizeof(double) * nvars);
                     memcpy(e, hx, sizeof(double) * nobs2);
@@ -662,9 +674,11 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
 
     if (info) {
         double t = DBL_MIN;
-        for (int j = mcon; j < m; ++j)
-            for (int r = 0; r < cnp; ++r) if (t < diagU[(size_t)j * cnp + r]) t = diagU[(size_t)j * cnp + r];
-        for (size_t i = 0; i < 3 * (size_t)n; ++i) if (t < diagV[i]) t = diagV[i];
+        if (op->mode != 2)
+            for (int j = mcon; j < m; ++j)
+                for (int r = 0; r < cnp; ++r) if (t < diagU[(size_t)j * cnp + r]) t = diagU[(size_t)j * cnp + r];
+        if (op->mode != 1)
+            for (size_t i = 0; i < 3 * (size_t)n; ++i) if (t < diagV[i]) t = diagV[i];
         info[0] = init_p_eL2; info[1] = p_eL2; info[2] = eab_inf; info[3] = dp_L2;
         info[4] = mu / t; info[5] = itno; info[6] = stop;
         /* sba_motstr_levmar scales these two by nvis, sba_levmar_wrap.c:688-700 */

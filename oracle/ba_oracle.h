@@ -64,6 +64,8 @@ typedef struct {
     double pcg_tol;
     double opts[6];        /* tau, eps1, eps2, eps3, eps4, eps5 (sfm.c:711-719; sba_levmar.c:609-610) */
     int disable_stops;     /* bench: ignore stop rules 1,2,4,5,8 so exactly itmax linear systems are solved */
+    int mode;              /* 0 cameras + points (sba_motstr_levmar_x), 1 cameras only (sba_mot_levmar_x,
+                            * sba_levmar.c:2090-2690), 2 points only (sba_str_levmar_x, :2698-3230) */
 } ora_options;
 
 /* p: m*cnp + 3n parameters, updated in place.  Returns iterations or -1. */

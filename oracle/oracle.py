@@ -41,7 +41,7 @@ class _Problem(C.Structure):
 class _Options(C.Structure):
     _fields_ = [("itmax", C.c_int), ("fd_jacobian", C.c_int), ("solver", C.c_int),
                 ("pcg_maxit", C.c_int), ("pcg_tol", C.c_double), ("opts", C.c_double * 6),
-                ("disable_stops", C.c_int)]
+                ("disable_stops", C.c_int), ("mode", C.c_int)]
 
 
 #: Bundler's options, sfm.c:711-719 (eps2 is run_sfm's argument; Bundler passes 1e-12)
@@ -89,9 +89,9 @@ class Oracle:
         return pb, keep
 
     def run(self, sc, p0=None, itmax=150, fd_jacobian=1, solver=0, pcg_maxit=200, pcg_tol=1e-10,
-            opts=BUNDLER_OPTS, mcon=0, disable_stops=0):
+            opts=BUNDLER_OPTS, mcon=0, disable_stops=0, mode=0):
         pb, keep = self._problem(sc, mcon)
-        op = _Options(itmax, fd_jacobian, solver, pcg_maxit, pcg_tol, (C.c_double * 6)(*opts), disable_stops)
+        op = _Options(itmax, fd_jacobian, solver, pcg_maxit, pcg_tol, (C.c_double * 6)(*opts), disable_stops, mode)
         p = np.array(sc.p0 if p0 is None else p0, np.float64, copy=True)
         info = np.zeros(10)
         cap = 16 * max(itmax, 1) + 16
@@ -150,6 +150,21 @@ class Reference:
                                           sc.est_focal, sc.undistort, sc.explicit_centers, itmax, verbose, o6,
                                           _d(info), _d(V), _d(S), _d(U), _d(W))
         return dict(ret=ret, p=p, info=info, V=V, S=S, U=U, W=W)
+
+    def run_partial(self, sc, mode, itmax=150, opts=BUNDLER_OPTS, mcon=0):
+        """mode 1: sba_mot_levmar (points fixed), mode 2: sba_str_levmar (cameras fixed); returns the full p"""
+        m, n, cnp = sc.m, sc.n, sc.cnp
+        cams = np.ascontiguousarray(sc.p0[:m * cnp]).copy(); pts = np.ascontiguousarray(sc.p0[m * cnp:]).copy()
+        pt_ptr = np.ascontiguousarray(sc.pt_ptr, np.int32); obs_cam = np.ascontiguousarray(sc.obs_cam, np.int32)
+        x = np.ascontiguousarray(sc.x, np.float64); R0 = np.ascontiguousarray(sc.R0, np.float64)
+        ff = np.ascontiguousarray(sc.f_fixed, np.float64)
+        info = np.zeros(10)
+        free, fixed = (cams, pts) if mode == 1 else (pts, cams)
+        self.lib.ref_sba_partial.restype = C.c_int
+        with quiet_stdout():
+            ret = self.lib.ref_sba_partial(mode, n, m, mcon, cnp, _i(pt_ptr), _i(obs_cam), _d(x), _d(free), _d(fixed), _d(R0), _d(ff),
+                                           sc.est_focal, sc.explicit_centers, itmax, (C.c_double * 6)(*opts), _d(info))
+        return dict(ret=ret, p=np.concatenate([cams, pts]), info=info)
 
     def run_sfm(self, sc, eps2=1e-12):
         """Bundler's run_sfm end to end (MAX_ITERS 150 hard-coded, sfm.c:820)."""

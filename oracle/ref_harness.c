@@ -73,6 +73,57 @@ int ref_sba_motstr(int n, int m, int mcon, int cnp, const int *pt_ptr, const int
     return ret;
 }
 
+/* motion-only (points fixed) and structure-only (cameras fixed) solves of the reference:
+ * sba_mot_levmar (sba.h:110-116; what run_sfm calls with fix_points, sfm.c:847) and sba_str_levmar
+ * (sba.h:118-123), with the same projection glue. */
+typedef struct { glue_t g; const double *pts; const double *cams; int cnp; } glue_ms_t;
+
+static void glue_project_mot(int j, int i, double *aj, double *xij, void *adata)
+{
+    glue_ms_t *m = (glue_ms_t *)adata;
+    double b[3] = { m->pts[3 * i], m->pts[3 * i + 1], m->pts[3 * i + 2] };
+    glue_project(j, i, aj, b, xij, &m->g);
+}
+
+static void glue_project_str(int j, int i, double *bi, double *xij, void *adata)
+{
+    glue_ms_t *m = (glue_ms_t *)adata;
+    double a[9];
+    memcpy(a, m->cams + (size_t)j * m->cnp, sizeof(double) * m->cnp);
+    glue_project(j, i, a, bi, xij, &m->g);
+}
+
+/* mode 1: p = m*cnp camera parameters (updated), pts n*3 fixed; mode 2: p = n*3 points (updated), cams m*cnp fixed */
+int ref_sba_partial(int mode, int n, int m, int mcon, int cnp, const int *pt_ptr, const int *obs_cam,
+                    const double *x, double *p, const double *fixed_part, const double *R0, const double *f_fixed,
+                    int est_focal, int explicit_centers, int itmax, const double *opts6, double *info10)
+{
+    int nobs = pt_ptr[n], i, j, o, ret;
+    char *vmask = (char *)calloc((size_t)n * m, 1);
+    camera_params_t *cams = (camera_params_t *)calloc(m, sizeof(camera_params_t));
+    double *xx = (double *)malloc(sizeof(double) * 2 * nobs);
+    glue_ms_t ms;
+    for (i = 0; i < n; ++i)
+        for (o = pt_ptr[i]; o < pt_ptr[i + 1]; ++o) vmask[(size_t)i * m + obs_cam[o]] = 1;
+    memcpy(xx, x, sizeof(double) * 2 * nobs);
+    for (j = 0; j < m; ++j) {
+        memcpy(cams[j].R, R0 + 9 * j, 9 * sizeof(double));
+        cams[j].f = f_fixed ? f_fixed[j] : 1.0;
+        cams[j].f_scale = 0.001; cams[j].k_scale = 5.0;
+    }
+    ms.g.cams = cams; ms.g.est_focal = est_focal; ms.g.undistort = 0; ms.g.explicit_centers = explicit_centers;
+    ms.cnp = cnp;
+    if (mode == 1) {
+        ms.pts = fixed_part; ms.cams = NULL;
+        ret = sba_mot_levmar(n, m, mcon, vmask, p, cnp, xx, NULL, 2, glue_project_mot, NULL, &ms, itmax, 0, opts6, info10, 0, NULL);
+    } else {
+        ms.pts = NULL; ms.cams = fixed_part;
+        ret = sba_str_levmar(n, m, vmask, p, 3, xx, NULL, 2, glue_project_str, NULL, &ms, itmax, 0, opts6, info10);
+    }
+    free(vmask); free(cams); free(xx);
+    return ret;
+}
+
 /* Bundler's driver as is.  cams_R m*9, cams_t m*3 (t or C), cams_f m, cams_k m*2 are read
  * and written back; pts n*3 likewise. */
 void ref_run_sfm(int n, int m, int ncons, const int *pt_ptr, const int *obs_cam, const double *x,

@@ -8,7 +8,8 @@ opts of sfm.c:711-719) produced for them:
   blocks at p0 through the Uout/Vout/Sout(/Wout) hooks (sba_levmar.c:1633-2026; reached at p0
   by setting eps1 huge so stop 1 fires before the first solve), the cost after k = 1..K
   iterations (info[1] of runs with itmax = k), the final parameters / info[0..9] of the full
-  solve, and the result of run_sfm() itself.
+  solve, the result of run_sfm() itself, and the truncated solves sba_mot_levmar (points fixed) and
+  sba_str_levmar (cameras fixed).
 """
 import importlib
 import os
@@ -34,13 +35,16 @@ def make(name, trace_len, keep_W, **kw):
     full = ref.run(sc, itmax=150)
     mcon = ref.run(sc, itmax=150, mcon=2)
     sfm = ref.run_sfm(sc)
+    mot = ref.run_partial(sc, 1)      # sba_mot_levmar: cameras only
+    st = ref.run_partial(sc, 2)       # sba_str_levmar: points only
     out = dict(n=sc.n, m=sc.m, cnp=sc.cnp, est_focal=sc.est_focal, undistort=sc.undistort,
                explicit_centers=sc.explicit_centers, proj_sign=sc.proj_sign,
                pt_ptr=sc.pt_ptr, obs_cam=sc.obs_cam, x=sc.x, R0=sc.R0, f_fixed=sc.f_fixed, p0=sc.p0,
                U0=blk["U"], V0=blk["V"], S0=blk["S"], cost0=blk["info"][0],
                cost_trace=costs, p_final=full["p"], info_final=full["info"], ret_final=full["ret"],
                p_mcon2=mcon["p"], info_mcon2=mcon["info"],
-               sfm_R=sfm["R"], sfm_t=sfm["t"], sfm_f=sfm["f"], sfm_pts=sfm["pts"])
+               sfm_R=sfm["R"], sfm_t=sfm["t"], sfm_f=sfm["f"], sfm_pts=sfm["pts"],
+               p_mot=mot["p"], info_mot=mot["info"], p_str=st["p"], info_str=st["info"])
     if keep_W:
         out["W0"] = blk["W"]
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"ref_{name}.npz")

@@ -132,6 +132,26 @@ def test_fixed_cameras(oracle):
     assert np.abs(p - z["p_mcon2"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("name", ["C1", "C1t"])
+def test_motion_only_and_structure_only_modes(oracle, name):
+    """mode 1 = sba_mot_levmar (points fixed), mode 2 = sba_str_levmar (cameras fixed), vs the real reference"""
+    sc, z = scene_from_golden(name)
+    eng = make_engine(sc, mode=1)
+    ret, info = eng.run()
+    p = eng.packed_params()
+    want = z["info_mot"]
+    assert abs(ret - int(want[5])) <= 3 and info[6] in (2, 4)      # rounding-level end game, see test_oracle_golden
+    assert abs(info[1] - want[1]) < 1e-7 * want[1]
+    assert np.abs(p - z["p_mot"]).max() < 1e-5
+    assert np.array_equal(p[sc.m * sc.cnp:], sc.p0[sc.m * sc.cnp:])
+    eng = make_engine(sc, mode=2)
+    ret, info = eng.run()
+    p = eng.packed_params()
+    assert abs(info[1] - z["info_str"][1]) < 1e-9 * z["info_str"][1]
+    assert np.abs(p - z["p_str"]).max() < 1e-5
+    assert np.array_equal(p[:sc.m * sc.cnp], sc.p0[:sc.m * sc.cnp])
+
+
 def test_rotations_unpack_like_run_sfm():
     sc, z = scene_from_golden("C1")
     eng = make_engine(sc)
