@@ -60,3 +60,35 @@ def model_lib():
     L.mi_model_rmse.restype = C.c_double; L.mi_model_rmse.argtypes = [C.c_void_p]
     L.mi_model_optimize.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     return L
+
+
+def ladybug_like_scene(m=1700, n=40000, dmax=120, seed=4, **kw):
+    """BASELINE config C4 shape: many cameras along a closed path, every point seen by a run of neighbouring
+    cameras whose length is heavy-tailed (2 .. dmax), so the reduced camera system is a wide band"""
+    scene = pkg("scene")
+    base = scene.make_scene("x", m=m, n=n, d=dmax, seed=seed, strides=(1,), **kw)
+    rng = np.random.default_rng(seed + 1)
+    L = np.minimum(2 + rng.geometric(0.14, n), dmax)
+    L[rng.random(n) < 0.01] = dmax                       # a few very long tracks (> one wavefront)
+    keep = np.concatenate([np.arange(base.pt_ptr[i], base.pt_ptr[i] + L[i]) for i in range(n)])
+    return scene.Scene(n=n, m=m, cnp=base.cnp, est_focal=base.est_focal, undistort=0, explicit_centers=base.explicit_centers,
+                       proj_sign=base.proj_sign, pt_ptr=np.concatenate([[0], np.cumsum(L)]).astype(np.int32),
+                       obs_cam=base.obs_cam[keep], x=base.x[keep], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0,
+                       p_true=base.p_true, name="ladybug-like")
+
+
+def write_bal(path, sc, p=None, shuffle_seed=None):
+    """BAL / "bundler model" text (util_VSFM.h:448-501) of a Bundler-frame scene holding t (explicit_centers=0)"""
+    assert sc.proj_sign == -1.0 and sc.explicit_centers == 0 and sc.est_focal
+    p = sc.p0 if p is None else p
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    a = p[:m * cnp].reshape(m, cnp); X = p[m * cnp:].reshape(n, 3)
+    R = np.einsum("mij,mjk->mik", rodrigues(a[:, 3:6]), sc.R0.reshape(m, 3, 3))
+    w = pkg("scene").log_so3(R)
+    order = np.arange(sc.nobs) if shuffle_seed is None else np.random.default_rng(shuffle_seed).permutation(sc.nobs)
+    pt = sc.obs_pt()
+    with open(path, "w") as fo:
+        fo.write("%d %d %d\n" % (m, n, sc.nobs))
+        np.savetxt(fo, np.column_stack([sc.obs_cam[order], pt[order], sc.x[order]]), fmt="%d %d %.10g %.10g")
+        np.savetxt(fo, np.column_stack([w, a[:, :3], a[:, 6] / 0.001, np.zeros((m, 2))]), fmt="%.14g")
+        np.savetxt(fo, X, fmt="%.12g")
