@@ -10,6 +10,9 @@
  *   BAL   "bundler model" text: ncam npt nobs / cam pt x y / 9 numbers per camera (w3 t3 f k1 k2) /
  *         X Y Z                                           LoadBundlerModel :448-501, SaveBundlerModel :503-529
  *         (-z camera -> +z: y negated on load, rows 2,3 of R and t2,t3 negated = SetInvertedRT)
+ *   OUT   Bundler "bundle.out" v0.3: ncam npt / per camera  f k1 k2, R (3 rows), t / per point  X Y Z, r g b,
+ *         nview {cam key x y}*   LoadBundlerOut :312-398, SaveBundlerOut :400-446 (-z camera -> +z: SetInvertedR9T,
+ *         y negated); camera names from "<name>-list.txt" when present
  * Camera convention in memory (DataInterface.h:50-52): x^ = f (R X + t).xy / (R X + t).z.
  */
 #ifndef MI_MODEL_H
@@ -24,8 +27,15 @@ typedef struct mi_model mi_model;
 
 mi_model *mi_model_load_nvm(const char *path);     /* NULL on failure, reason in mi_model_last_error() */
 mi_model *mi_model_load_bal(const char *path);
+mi_model *mi_model_load_bundler_out(const char *path);
 int mi_model_save_nvm(const mi_model *mdl, const char *path);
 int mi_model_save_bal(const mi_model *mdl, const char *path);
+int mi_model_save_bundler_out(const mi_model *mdl, const char *path);   /* also writes <name>-list.txt */
+/* RemoveInvisiblePoints (util_VSFM.h:736-866): drops points that lie behind (or closer than 0.1 % of the median
+ * depth to) one of their cameras, then cameras left with < 20 points and points left with < 2 views, and
+ * compacts the indices.  Returns the number of points removed (0 = model untouched) or MI_BA_ERROR.
+ * Unlike the reference (which loses them through a push_back on the wrong vector, :842) colours are kept. */
+int mi_model_remove_invisible_points(mi_model *mdl);
 void mi_model_free(mi_model *mdl);
 const char *mi_model_last_error(void);
 

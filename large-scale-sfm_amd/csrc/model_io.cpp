@@ -1,5 +1,6 @@
 // model_io.cpp -- NVM / BAL text I/O and the optimizer_all process contract (include/mi_model.h).
 // Host code; the numeric work is mi_ba.h's engine.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -191,6 +192,142 @@ int mi_model_save_bal(const mi_model *m, const char *path)
     }
     for (size_t i = 0; i < m->npt(); ++i) out << m->xyz[3 * i] << ' ' << m->xyz[3 * i + 1] << ' ' << m->xyz[3 * i + 2] << '\n';
     return out ? 0 : MI_BA_ERROR;
+}
+
+mi_model *mi_model_load_bundler_out(const char *path)
+{
+    std::ifstream in(path);
+    if (!in) { g_err = std::string("cannot open ") + path; return nullptr; }
+    std::string token;
+    while (in.peek() == '#') std::getline(in, token);
+    long long ncam = 0, npt = 0;
+    in >> ncam >> npt;
+    if (!in || ncam <= 1 || npt <= 1) { g_err = "bundle.out: fewer than 2 cameras or points"; return nullptr; } // util_VSFM.h:339
+    std::string list = path;
+    const size_t ext = list.rfind(".out");
+    std::ifstream listin;
+    if (ext != std::string::npos) { list.replace(ext, std::string::npos, "-list.txt"); listin.open(list); }
+    mi_model *m = new mi_model;
+    m->names.assign(ncam, "unknown"); m->f.resize(ncam); m->R.resize(ncam * 9); m->t.resize(ncam * 3); m->d.resize(ncam * 2);
+    for (long long i = 0; i < ncam; ++i) {
+        double q[9], c[3];
+        in >> m->f[i] >> m->d[2 * i] >> m->d[2 * i + 1];
+        for (int j = 0; j < 9; ++j) in >> q[j];
+        in >> c[0] >> c[1] >> c[2];
+        double *R = &m->R[i * 9], *t = &m->t[i * 3];        // SetInvertedR9T, DataInterface.h:306-314
+        for (int j = 0; j < 3; ++j) R[j] = q[j];
+        for (int j = 3; j < 9; ++j) R[j] = -q[j];
+        t[0] = c[0]; t[1] = -c[1]; t[2] = -c[2];
+        std::string line;
+        if (listin && (listin >> line)) {
+            const size_t sl = line.find_last_of("/\\");
+            m->names[i] = sl == std::string::npos ? line : line.substr(sl + 1);
+            std::getline(listin, line);
+        }
+    }
+    m->xyz.resize(npt * 3); m->rgb.resize(npt * 3);
+    for (long long i = 0; i < npt; ++i) {
+        int npj = 0;
+        in >> m->xyz[3 * i] >> m->xyz[3 * i + 1] >> m->xyz[3 * i + 2] >> m->rgb[3 * i] >> m->rgb[3 * i + 1] >> m->rgb[3 * i + 2] >> npj;
+        if (!in) { g_err = "bundle.out: truncated point record"; delete m; return nullptr; }
+        for (int j = 0; j < npj; ++j) {
+            int cidx; long long fidx; double x, y;
+            in >> cidx >> fidx >> x >> y;
+            if (cidx < 0 || cidx >= ncam) { g_err = "bundle.out: camera index out of range"; delete m; return nullptr; }
+            m->cam_idx.push_back(cidx); m->pt_idx.push_back((int)i); m->feat_id.push_back(fidx);
+            m->xy.push_back(x); m->xy.push_back(-y);        // y negated, util_VSFM.h:390
+        }
+    }
+    if (!in) { g_err = "bundle.out: truncated file"; delete m; return nullptr; }
+    return m;
+}
+
+int mi_model_save_bundler_out(const mi_model *m, const char *path)
+{
+    if (!m) return MI_BA_ERROR;
+    std::string list = path;
+    const size_t ext = list.rfind(".out");
+    if (ext == std::string::npos) { g_err = "bundle.out: file name must end in .out"; return MI_BA_ERROR; } // util_VSFM.h:405
+    list.replace(ext, std::string::npos, "-list.txt");
+    std::ofstream out(path);
+    if (!out) { g_err = std::string("cannot write ") + path; return MI_BA_ERROR; }
+    out << "# Bundle file v0.3\n" << std::setprecision(12) << m->ncam() << ' ' << m->npt() << '\n';
+    for (size_t i = 0; i < m->ncam(); ++i) {
+        out << m->f[i] << ' ' << m->d[2 * i] << ' ' << m->d[2 * i + 1] << '\n';
+        for (int j = 0; j < 9; ++j) out << (j < 3 ? m->R[i * 9 + j] : -m->R[i * 9 + j]) << ((j % 3) == 2 ? '\n' : ' ');
+        out << m->t[3 * i] << ' ' << -m->t[3 * i + 1] << ' ' << -m->t[3 * i + 2] << '\n';
+    }
+    size_t j = 0;
+    for (size_t i = 0; i < m->npt(); ++i) {
+        size_t je = j;
+        while (je < m->nproj() && m->pt_idx[je] == (int)i) ++je;
+        out << m->xyz[3 * i] << ' ' << m->xyz[3 * i + 1] << ' ' << m->xyz[3 * i + 2] << '\n' << m->rgb[3 * i] << ' ' << m->rgb[3 * i + 1] << ' '
+            << m->rgb[3 * i + 2] << '\n' << (je - j) << ' ';
+        for (; j < je; ++j) out << m->cam_idx[j] << ' ' << m->feat_id[j] << ' ' << m->xy[2 * j] << ' ' << -m->xy[2 * j + 1] << ' ';
+        out << '\n';
+    }
+    std::ofstream listout(list);
+    for (auto &nm : m->names) listout << nm << '\n';
+    return out ? 0 : MI_BA_ERROR;
+}
+
+int mi_model_remove_invisible_points(mi_model *m)
+{
+    if (!m) return MI_BA_ERROR;
+    const size_t np = m->nproj(), npt = m->npt(), nc = m->ncam();
+    auto depth = [&](size_t k) {
+        const double *R = &m->R[(size_t)m->cam_idx[k] * 9], *X = &m->xyz[(size_t)m->pt_idx[k] * 3];
+        return R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + m->t[(size_t)m->cam_idx[k] * 3 + 2];
+    };
+    std::vector<double> zz(np);
+    for (size_t k = 0; k < np; ++k) zz[k] = depth(k);
+    std::vector<double> tmp(zz);
+    std::nth_element(tmp.begin(), tmp.begin() + np / 2, tmp.end());
+    const double thr = tmp[np / 2] * 0.001;                                       // util_VSFM.h:749
+    std::vector<char> pmask(npt, 1), cmask(nc, 1);
+    int removed = 0;
+    for (size_t k = 0; k < np; ++k) {
+        const int pid = m->pt_idx[k];
+        if (!pmask[pid]) continue;
+        if (!(zz[k] > thr)) { pmask[pid] = 0; ++removed; }
+    }
+    if (!removed) return 0;
+    const int min_observation = 20;                                               // :771
+    std::vector<int> cv(nc), pv(npt);
+    int again;
+    do {
+        std::fill(cv.begin(), cv.end(), 0);
+        for (size_t k = 0; k < np; ++k) if (pmask[m->pt_idx[k]]) cv[m->cam_idx[k]]++;
+        std::fill(pv.begin(), pv.end(), 0);
+        for (size_t k = 0; k < np; ++k) if (pmask[m->pt_idx[k]] && cv[m->cam_idx[k]] >= min_observation) pv[m->pt_idx[k]]++;
+        again = 0;
+        for (size_t i = 0; i < npt; ++i) if (pmask[i] && pv[i] < 2) { pmask[i] = 0; ++again; ++removed; }
+    } while (again > 0);
+    for (size_t j = 0; j < nc; ++j) cmask[j] = cv[j] >= min_observation;
+    std::vector<int> cidx(nc, -1), pidx(npt, -1);
+    mi_model o;
+    for (size_t j = 0; j < nc; ++j) {
+        if (!cmask[j]) continue;
+        cidx[j] = (int)o.f.size();
+        o.names.push_back(m->names[j]); o.f.push_back(m->f[j]);
+        o.R.insert(o.R.end(), m->R.begin() + j * 9, m->R.begin() + j * 9 + 9);
+        o.t.insert(o.t.end(), m->t.begin() + j * 3, m->t.begin() + j * 3 + 3);
+        o.d.insert(o.d.end(), m->d.begin() + j * 2, m->d.begin() + j * 2 + 2);
+    }
+    for (size_t i = 0; i < npt; ++i) {
+        if (!pmask[i]) continue;
+        pidx[i] = (int)o.npt();
+        o.xyz.insert(o.xyz.end(), m->xyz.begin() + i * 3, m->xyz.begin() + i * 3 + 3);
+        o.rgb.insert(o.rgb.end(), m->rgb.begin() + i * 3, m->rgb.begin() + i * 3 + 3);
+    }
+    for (size_t k = 0; k < np; ++k) {
+        const int pid = m->pt_idx[k], cid = m->cam_idx[k];
+        if (!pmask[pid] || !cmask[cid]) continue;
+        o.pt_idx.push_back(pidx[pid]); o.cam_idx.push_back(cidx[cid]); o.feat_id.push_back(m->feat_id[k]);
+        o.xy.push_back(m->xy[2 * k]); o.xy.push_back(m->xy[2 * k + 1]);
+    }
+    *m = std::move(o);
+    return removed;
 }
 
 int mi_model_counts(const mi_model *m, int64_t c[3])

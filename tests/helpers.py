@@ -53,6 +53,8 @@ def model_lib():
     L = pkg("capi").lib()
     L.mi_model_load_nvm.restype = C.c_void_p; L.mi_model_load_nvm.argtypes = [C.c_char_p]
     L.mi_model_load_bal.restype = C.c_void_p; L.mi_model_load_bal.argtypes = [C.c_char_p]
+    L.mi_model_load_bundler_out.restype = C.c_void_p; L.mi_model_load_bundler_out.argtypes = [C.c_char_p]
+    L.mi_model_save_bundler_out.argtypes = [C.c_void_p, C.c_char_p]; L.mi_model_remove_invisible_points.argtypes = [C.c_void_p]
     L.mi_model_save_nvm.argtypes = [C.c_void_p, C.c_char_p]; L.mi_model_save_bal.argtypes = [C.c_void_p, C.c_char_p]
     L.mi_model_free.argtypes = [C.c_void_p]; L.mi_model_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.mi_model_get.argtypes = [C.c_void_p] * 11

@@ -106,6 +106,42 @@ def test_bal_round_trip_and_convention(tmp_path):
     L.mi_model_free(h); L.mi_model_free(h2)
 
 
+def test_bundler_out_round_trip_and_invisible_points(tmp_path):
+    L = model_lib()
+    sc = vsfm_scene(m=30, n=900, d=6, seed=9)
+    nvm = str(tmp_path / "a.nvm"); out = str(tmp_path / "bundle.out")
+    write_nvm(nvm, sc)
+    h = L.mi_model_load_nvm(nvm.encode())
+    assert L.mi_model_save_bundler_out(h, out.encode()) == 0
+    assert os.path.exists(str(tmp_path / "bundle-list.txt"))
+    h2 = L.mi_model_load_bundler_out(out.encode())
+    assert h2, L.mi_model_last_error()
+    a, b = read_model(L, h), read_model(L, h2)
+    for k in a:
+        assert np.allclose(a[k], b[k], rtol=1e-10, atol=1e-10), k
+    assert abs(L.mi_model_rmse(h) - L.mi_model_rmse(h2)) < 1e-9
+    assert open(out).readline().startswith("# Bundle file v0.3")
+    assert L.mi_model_remove_invisible_points(h) == 0                 # every point is in front of its cameras
+    L.mi_model_free(h); L.mi_model_free(h2)
+    # push 25 points behind their cameras: they, and nothing else, go (every camera keeps > 20 points)
+    bad = sc.p0.copy()
+    X = bad[sc.m * sc.cnp:].reshape(sc.n, 3)
+    X[:25] *= -40.0
+    write_nvm(nvm, sc, bad)
+    h = L.mi_model_load_nvm(nvm.encode())
+    before = read_model(L, h)
+    z = np.einsum("kj,kj->k", before["R"].reshape(-1, 3, 3)[before["cam"]][:, 2, :], before["xyz"][before["pt"]]) + before["t"][before["cam"], 2]
+    gone = np.unique(before["pt"][z <= np.sort(z)[len(z) // 2] * 0.001])       # util_VSFM.h:739-761
+    assert 15 <= len(gone) <= 25 and gone.max() < 25
+    assert L.mi_model_remove_invisible_points(h) == len(gone)
+    c = read_model(L, h)
+    kept = np.setdiff1d(np.arange(sc.n), gone)
+    assert c["xyz"].shape[0] == len(kept) and len(c["pt"]) == sc.nobs - 6 * len(gone) and c["f"].shape[0] == sc.m
+    assert np.array_equal(c["rgb"][:, 0], kept % 256)                          # colours follow their points
+    assert np.all(np.diff(c["pt"]) >= 0) and c["pt"].max() == len(kept) - 1
+    L.mi_model_free(h)
+
+
 def _check_plan(sc, rank=0, world=1, tmb=0):
     capi = pkg("capi")
     pl = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam, rank, world, tmb)
