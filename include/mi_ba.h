@@ -9,10 +9,10 @@
  * include/mi_pba.h, include/mi_sba.h and INTEGRATION.md.
  *
  * Parameterisation = the one Bundler's run_sfm hands to sba (sfm.c:657-709): per camera
- *   a_j = [ C_j or t_j (3) | omega_j (3) | f_j * f_scale (if est_focal) | k1*k_scale, k2*k_scale (if undistort) ]
+ *   a_j = [ C_j or t_j (3) | omega_j (3) | f_j * f_scale (if est_focal) | k1_j * k_scale (if undistort) ]
  * around a fixed initial rotation R0_j (R_j = exp([omega_j]x) R0_j, sfm.c:78-117,545-553), per
  * point b_i = [X Y Z].  Projection (sfm.c:303-374):
- *   q = R_j (X - C_j)   or   R_j X + t_j ;   x^ = proj_sign * f * q.xy / q.z * (1 + k1 r^2 + k2 r^4)
+ *   q = R_j (X - C_j)   or   R_j X + t_j ;   x^ = proj_sign * f * q.xy / q.z * (1 + k1 r^2),  r^2 = |q.xy / q.z|^2
  * proj_sign = -1 is Bundler's camera (sfm.c:333), +1 the VisualSFM / PBA one (+z forward).
  * All arithmetic on the device is IEEE double.
  *
@@ -40,7 +40,8 @@ typedef struct mi_ba_plan mi_ba_plan;
 typedef struct {
     /* model (sfm.c:598-617 arguments of run_sfm) */
     int est_focal;          /* 1: focal length is a parameter (cnp 7), 0: fixed (cnp 6) */
-    int undistort;          /* 1: k1,k2 are parameters (reserved; round 1 supports 0 only) */
+    int undistort;          /* 1: the radial coefficient k1 is a parameter (Bundler's projection distortion,
+                             * sfm.c:360-373, with k2 held at 0 = the one-coefficient model of PBA's CameraT) */
     int explicit_centers;   /* 1: camera params hold the centre C, 0: the translation t */
     int mcon;               /* first mcon cameras are held fixed (sba.h:95 'mcon') */
     double proj_sign;       /* -1 Bundler, +1 VisualSFM/PBA */

@@ -34,8 +34,8 @@ bool Engine::hipok(hipError_t e, const char *what)
 
 Engine::Engine(const mi_ba_config &c) : cfg(c)
 {
-    cnp = 6 + (cfg.est_focal ? 1 : 0);
-    if (cfg.undistort) { err = "undistort (k1,k2 as parameters, cnp 8/9) is not supported yet"; return; }
+    cnp = 6 + (cfg.est_focal ? 1 : 0) + (cfg.undistort ? 1 : 0);
+    if (cfg.undistort != 0 && cfg.undistort != 1) { err = "undistort must be 0 or 1 (Bundler's second coefficient k2 is not supported)"; return; }
     if (cfg.mode < 0 || cfg.mode > 2) { err = "bad bundle mode"; return; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

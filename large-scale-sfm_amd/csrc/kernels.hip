@@ -132,7 +132,17 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
             A[r][t] = cfg.explicit_centers ? -B[r][t] : Pq[r][t];
             A[r][3 + t] = Pq[r][0] * M[0][t] + Pq[r][1] * M[1][t] + Pq[r][2] * M[2][t];
         }
-        if constexpr (CNP >= 7) A[r][6] = s * (r == 0 ? mx : my) * D / cfg.f_scale;
+        // intrinsics columns, in Bundler's order (sfm.c:679-701): focal length (scaled), then k1 (scaled)
+        if constexpr (CNP >= 7) {
+            const double mr = (r == 0) ? mx : my;
+            int idx = 6;
+            if (cfg.est_focal) { A[r][6] = s * mr * D / cfg.f_scale; idx = 7; }
+            if (cfg.undistort) {
+                const double dk = s * f * mr * r2 / cfg.k_scale;
+                if (idx == 6) A[r][6] = dk;
+                if constexpr (CNP >= 8) { if (idx == 7) A[r][7] = dk; }
+            }
+        }
     }
     if (cfg.points_fixed) { // after A (A_C = -B above): no structure block in a motion-only bundle
 #pragma unroll
@@ -185,7 +195,8 @@ __device__ __forceinline__ void cam_record(const ModelCfg &cfg, int cnp, const d
         }
     cl[18] = a[0]; cl[19] = a[1]; cl[20] = a[2];
     cl[21] = cfg.est_focal ? a[6] / cfg.f_scale : f_fix;
-    cl[22] = 0.0; cl[23] = 0.0; // k1, k2: undistort reserved
+    cl[22] = cfg.undistort ? a[cfg.est_focal ? 7 : 6] / cfg.k_scale : 0.0; // k1 (sfm.c:364, TEST_FOCAL scaling)
+    cl[23] = 0.0;                                                          // k2 is not a parameter here
     (void)cnp;
 }
 
@@ -309,7 +320,7 @@ __device__ __forceinline__ void pair_block(const double *sR, const double *sv, i
 #endif
 
 template <int CNP, bool LDS>
-__global__ __launch_bounds__(64, 2) void k_build(const BuildArgs g)
+__global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArgs g) // 8x8 blocks: 128 accumulator VGPRs, one wave per SIMD
 {
 #ifdef MIBA_STAMPS
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
@@ -1229,7 +1240,10 @@ void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const 
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a)
 {
     if (ntiles <= 0) return;
-    if (cnp == 7) {
+    if (cnp == 8) {
+        if (lds_mode) hipLaunchKernelGGL((k_build<8, true>), dim3(ntiles), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_build<8, false>), dim3(ntiles), dim3(64), 0, st, a);
+    } else if (cnp == 7) {
         if (lds_mode) hipLaunchKernelGGL((k_build<7, true>), dim3(ntiles), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_build<7, false>), dim3(ntiles), dim3(64), 0, st, a);
     } else {
@@ -1286,7 +1300,8 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, cons
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
 {
     if (a.nbatch <= 0) return;
-    if (cnp == 7) hipLaunchKernelGGL((k_backsub<7>), dim3(a.ngrid), dim3(64), 0, st, a);
+    if (cnp == 8) hipLaunchKernelGGL((k_backsub<8>), dim3(a.ngrid), dim3(64), 0, st, a);
+    else if (cnp == 7) hipLaunchKernelGGL((k_backsub<7>), dim3(a.ngrid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_backsub<6>), dim3(a.ngrid), dim3(64), 0, st, a);
 }
 
@@ -1294,7 +1309,10 @@ void launch_long_build(hipStream_t st, int cnp, const LongArgs &a)
 {
     if (a.nlong <= 0) return;
     const unsigned gx = (unsigned)((a.max_pairs + 255) / 256);
-    if (cnp == 7) {
+    if (cnp == 8) {
+        hipLaunchKernelGGL((k_long_reduce<8>), dim3(a.nlong), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((k_long_pairs<8>), dim3(gx, a.nlong), dim3(256), 0, st, a);
+    } else if (cnp == 7) {
         hipLaunchKernelGGL((k_long_reduce<7>), dim3(a.nlong), dim3(256), 0, st, a);
         hipLaunchKernelGGL((k_long_pairs<7>), dim3(gx, a.nlong), dim3(256), 0, st, a);
     } else {
@@ -1306,7 +1324,8 @@ void launch_long_build(hipStream_t st, int cnp, const LongArgs &a)
 void launch_long_backsub(hipStream_t st, int cnp, const LongArgs &a)
 {
     if (a.nlong <= 0) return;
-    if (cnp == 7) hipLaunchKernelGGL((k_long_backsub<7>), dim3(a.nlong), dim3(256), 0, st, a);
+    if (cnp == 8) hipLaunchKernelGGL((k_long_backsub<8>), dim3(a.nlong), dim3(256), 0, st, a);
+    else if (cnp == 7) hipLaunchKernelGGL((k_long_backsub<7>), dim3(a.nlong), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_long_backsub<6>), dim3(a.nlong), dim3(256), 0, st, a);
 }
 

@@ -83,14 +83,15 @@ int ParallelBA::RunBundleAdjustment()
     o.abort.store(false); o.iteration.store(0);
     // silent "nothing done" on missing input, SparseBundleCPU.cpp:2587-2590
     if (!o.valid_device || !o.cams || !o.pts || !o.meas || !o.ptidx || !o.camidx || !o.ncam || !o.npt || !o.nproj) return 0;
-    if (c.__use_radial_distortion != 0) {
-        std::fprintf(stderr, "[mi_pba] radial distortion is not supported by this build\n");
+    if (c.__use_radial_distortion < 0) { // PBA_MEASUREMENT_DISTORTION: a different residual (distorts the measurement)
+        std::fprintf(stderr, "[mi_pba] measurement distortion is not supported; use PBA_PROJECTION_DISTORTION\n");
         c.__bundle_return_code = 'E';
         return 0;
     }
     mi_ba_config cfg;
     mi_ba_default_config(&cfg);
     cfg.est_focal = c.__fixed_intrinsics ? 0 : 1;
+    cfg.undistort = (c.__use_radial_distortion > 0 && !c.__fixed_intrinsics) ? 1 : 0; // EnableRadialDistortion(PBA_PROJECTION_DISTORTION)
     cfg.explicit_centers = 0;              // CameraT holds T = -R C (DataInterface.h:51)
     cfg.proj_sign = 1.0;                   // +z forward
     cfg.itmax = c.__lm_max_iteration;
@@ -108,6 +109,7 @@ int ParallelBA::RunBundleAdjustment()
         const CameraT &cam = o.cams[j];
         for (int r = 0; r < 3; ++r) a0[(size_t)j * cnp + r] = cam.t[r];
         if (cfg.est_focal) a0[(size_t)j * cnp + 6] = (double)cam.f * cfg.f_scale;
+        if (cfg.undistort) a0[(size_t)j * cnp + 7] = (double)cam.GetProjectionDistortion() * cfg.k_scale;
         for (int r = 0; r < 9; ++r) R0[(size_t)j * 9 + r] = cam.m[r / 3][r % 3];
         ff[j] = cam.f;
         fixed[j] = cam.constant_camera == 1.0f;
@@ -154,6 +156,7 @@ int ParallelBA::RunBundleAdjustment()
             for (int r = 0; r < 3; ++r) cam.t[r] = (float)a[(size_t)j * cnp + r];
             for (int r = 0; r < 9; ++r) cam.m[r / 3][r % 3] = (float)R[(size_t)j * 9 + r];
             if (cfg.est_focal) cam.f = (float)(a[(size_t)j * cnp + 6] / cfg.f_scale);
+            if (cfg.undistort) cam.SetProjectionDistortion(a[(size_t)j * cnp + 7] / cfg.k_scale);
         }
         for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) o.pts[i].xyz[r] = (float)xyz[(size_t)i * 3 + r];
         ret = c.__num_lm_success;

@@ -48,6 +48,7 @@ class Scene:
     p_true: np.ndarray      # float64, ground truth in the same packing (omega relative to R0)
     name: str = ""
     meta: dict = field(default_factory=dict)
+    nk: int = 2             # distortion parameters when undistort: 2 = k1,k2 (Bundler), 1 = k1 only
 
     @property
     def nobs(self) -> int:
@@ -92,7 +93,8 @@ def project(R: np.ndarray, c: np.ndarray, f: np.ndarray, X: np.ndarray, proj_sig
 def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, d: int | None = None,
                seed: int | None = None, proj_sign: float = -1.0, explicit_centers: int = 1,
                est_focal: int = 1, strides=(1, 2, 3), noise_px: float = 0.25,
-               cam_noise: float = 0.005, f_noise: float = 0.01, pt_noise: float = 0.01) -> Scene:
+               cam_noise: float = 0.005, f_noise: float = 0.01, pt_noise: float = 0.01,
+               undistort: int = 0, nk: int = 2, k_true=(-0.25, 0.12)) -> Scene:
     if name in CONFIGS:
         cm, cn, cd = CONFIGS[name]
         idx = list(CONFIGS).index(name)
@@ -134,7 +136,8 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
     Xo = X_true[obs_pt]
     t_true = -np.einsum("mij,mj->mi", R_true, C)
     c_true = C if explicit_centers else t_true
-    x = project(R_true[obs_cam], c_true[obs_cam], f_true[obs_cam], Xo, proj_sign, explicit_centers)
+    k1t, k2t = (k_true[0], k_true[1] if nk == 2 else 0.0) if undistort else (0.0, 0.0)
+    x = project(R_true[obs_cam], c_true[obs_cam], f_true[obs_cam], Xo, proj_sign, explicit_centers, k1t, k2t)
     x = x + rng.uniform(-noise_px, noise_px, x.shape)
 
     # --- perturbed initial guess
@@ -144,7 +147,7 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
     f_init = f_true * (1 + rng.uniform(-f_noise, f_noise, m))
     X0 = X_true + rng.uniform(-pt_noise, pt_noise, (n, 3))
 
-    cnp = 6 + (1 if est_focal else 0)
+    cnp = 6 + (1 if est_focal else 0) + (nk if undistort else 0)
     a0 = np.zeros((m, cnp))
     a0[:, :3] = c0
     a_true = np.zeros((m, cnp))
@@ -153,9 +156,13 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
     if est_focal:
         a0[:, 6] = f_init * F_SCALE
         a_true[:, 6] = f_true * F_SCALE
+    if undistort:                                  # the initial guess has no distortion
+        a_true[:, 6 + (1 if est_focal else 0)] = k1t * K_SCALE
+        if nk == 2:
+            a_true[:, 7 + (1 if est_focal else 0)] = k2t * K_SCALE
     p0 = np.concatenate([a0.reshape(-1), X0.reshape(-1)])
     p_true = np.concatenate([a_true.reshape(-1), X_true.reshape(-1)])
-    return Scene(n=n, m=m, cnp=cnp, est_focal=int(est_focal), undistort=0,
+    return Scene(n=n, m=m, cnp=cnp, est_focal=int(est_focal), undistort=int(undistort), nk=int(nk),
                  explicit_centers=int(explicit_centers), proj_sign=float(proj_sign),
                  pt_ptr=pt_ptr, obs_cam=obs_cam, x=np.ascontiguousarray(x),
                  R0=np.ascontiguousarray(R0.reshape(m, 9)), f_fixed=np.ascontiguousarray(f_init),

@@ -80,7 +80,7 @@ void ora_project(const ora_problem *pb, int j, const double *aj, const double *b
     double p0 = pb->proj_sign * q[0] * f / q[2];
     double p1 = pb->proj_sign * q[1] * f / q[2];
     if (pb->undistort) {
-        double k1 = k[0] / pb->k_scale, k2 = k[1] / pb->k_scale;
+        double k1 = k[0] / pb->k_scale, k2 = pb->nk == 1 ? 0.0 : k[1] / pb->k_scale;
         double rsq = (p0 * p0 + p1 * p1) / (f * f);
         double factor = 1.0 + k1 * rsq + k2 * rsq * rsq;
         p0 *= factor; p1 *= factor;
@@ -112,7 +112,7 @@ static void jac_analytic(const ora_problem *pb, int j, const double *aj, const d
     const double *k = pb->est_focal ? aj + 7 : aj + 6;
     double f = cam_focal(pb, j, aj);
     double k1 = 0.0, k2 = 0.0;
-    if (pb->undistort) { k1 = k[0] / pb->k_scale; k2 = k[1] / pb->k_scale; }
+    if (pb->undistort) { k1 = k[0] / pb->k_scale; k2 = pb->nk == 1 ? 0.0 : k[1] / pb->k_scale; }
     ora_rot_update(pb->R0 + 9 * j, w, R);
     so3_left_jacobian(w, Jl);
     double qr[3]; /* rotated part, the vector the rotation acts on */
@@ -156,7 +156,7 @@ static void jac_analytic(const ora_problem *pb, int j, const double *aj, const d
         if (pb->est_focal) Ar[cc++] = s * mr * D / pb->f_scale;
         if (pb->undistort) {
             Ar[cc++] = s * f * mr * r2 / pb->k_scale;
-            Ar[cc++] = s * f * mr * r2 * r2 / pb->k_scale;
+            if (pb->nk != 1) Ar[cc++] = s * f * mr * r2 * r2 / pb->k_scale;
         }
     }
 }

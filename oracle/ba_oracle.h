@@ -41,7 +41,7 @@ typedef struct {
     int n;                 /* points */
     int m;                 /* cameras */
     int mcon;              /* first mcon cameras are held fixed (sba_levmar.c:460) */
-    int cnp;               /* 6 (+1 if est_focal) (+2 if undistort)  (sfm.c:643-649) */
+    int cnp;               /* 6 (+1 if est_focal) (+nk if undistort)  (sfm.c:643-649) */
     int est_focal;         /* sfm.c:643 */
     int undistort;         /* sfm.c:648 */
     int explicit_centers;  /* camera params hold C (1) or t (0): sfm.c:319-330 */
@@ -54,6 +54,8 @@ typedef struct {
     const double *x;       /* 2*nobs measurements, same order */
     const double *R0;      /* m*9 row-major initial rotations (fixed during the solve, sfm.c:549) */
     const double *f_fixed; /* m focal lengths used when !est_focal (sfm.c:523) */
+    int nk;                /* distortion parameters when undistort: 2 = Bundler's k1,k2 (sfm.c:648-649), 1 = k1 only
+                            * with k2 held at 0 (the single-coefficient model of PBA's CameraT, DataInterface.h:53) */
 } ora_problem;
 
 typedef struct {

@@ -35,7 +35,7 @@ class _Problem(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("mcon", C.c_int), ("cnp", C.c_int),
                 ("est_focal", C.c_int), ("undistort", C.c_int), ("explicit_centers", C.c_int),
                 ("proj_sign", C.c_double), ("f_scale", C.c_double), ("k_scale", C.c_double),
-                ("pt_ptr", _ip), ("obs_cam", _ip), ("x", _dp), ("R0", _dp), ("f_fixed", _dp)]
+                ("pt_ptr", _ip), ("obs_cam", _ip), ("x", _dp), ("R0", _dp), ("f_fixed", _dp), ("nk", C.c_int)]
 
 
 class _Options(C.Structure):
@@ -85,7 +85,7 @@ class Oracle:
                     f_fixed=np.ascontiguousarray(sc.f_fixed, np.float64))
         pb = _Problem(sc.n, sc.m, mcon, sc.cnp, sc.est_focal, sc.undistort, sc.explicit_centers,
                       sc.proj_sign, 0.001, 5.0, _i(keep["pt_ptr"]), _i(keep["obs_cam"]),
-                      _d(keep["x"]), _d(keep["R0"]), _d(keep["f_fixed"]))
+                      _d(keep["x"]), _d(keep["R0"]), _d(keep["f_fixed"]), getattr(sc, "nk", 2))
         return pb, keep
 
     def run(self, sc, p0=None, itmax=150, fd_jacobian=1, solver=0, pcg_maxit=200, pcg_tol=1e-10,
@@ -148,7 +148,7 @@ class Reference:
         with quiet_stdout():
             ret = self.lib.ref_sba_motstr(n, m, mcon, cnp, _i(pt_ptr), _i(obs_cam), _d(x), _d(p), _d(R0), _d(ff),
                                           sc.est_focal, sc.undistort, sc.explicit_centers, itmax, verbose, o6,
-                                          _d(info), _d(V), _d(S), _d(U), _d(W))
+                                          _d(info), _d(V), _d(S), _d(U), _d(W), getattr(sc, "nk", 2))
         return dict(ret=ret, p=p, info=info, V=V, S=S, U=U, W=W)
 
     def run_partial(self, sc, mode, itmax=150, opts=BUNDLER_OPTS, mcon=0):

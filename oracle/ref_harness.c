@@ -27,6 +27,7 @@
 typedef struct {
     camera_params_t *cams;
     int est_focal, undistort, explicit_centers;
+    int nk; /* 2: k1,k2 are parameters (sfm.c:648-649); 1: only k1 is, k2 is passed to sfm_project_rd as 0 */
 } glue_t;
 
 /* same call sequence as sfm_project_point3 (static in sfm.c:509-558), minus its
@@ -39,7 +40,9 @@ static void glue_project(int j, int i, double *aj, double *bi, double *xij, void
     (void)i;
     if (!g->est_focal) K[0] = K[4] = g->cams[j].f;
     else K[0] = K[4] = aj[6] / g->cams[j].f_scale; /* TEST_FOCAL branch, sfm.c:532 */
+    double k1only[2];
     k = g->est_focal ? aj + 7 : aj + 6;
+    if (g->undistort && g->nk == 1) { k1only[0] = k[0]; k1only[1] = 0.0; k = k1only; }
     rot_update(g->cams[j].R, w, Rnew);
     sfm_project_rd(g->cams + j, K, k, Rnew, dt, bi, xij, g->undistort, g->explicit_centers);
 }
@@ -48,7 +51,7 @@ int ref_sba_motstr(int n, int m, int mcon, int cnp, const int *pt_ptr, const int
                    const double *x, double *p, const double *R0, const double *f_fixed,
                    int est_focal, int undistort, int explicit_centers,
                    int itmax, int verbose, const double *opts6, double *info10,
-                   double *Vout, double *Sout, double *Uout, double *Wout)
+                   double *Vout, double *Sout, double *Uout, double *Wout, int nk)
 {
     int nobs = pt_ptr[n], i, j, o, ret;
     char *vmask = (char *)calloc((size_t)n * m, 1);
@@ -66,7 +69,7 @@ int ref_sba_motstr(int n, int m, int mcon, int cnp, const int *pt_ptr, const int
         cams[j].f_scale = 0.001; /* values run_sfm installs under TEST_FOCAL, sfm.c:640-663 */
         cams[j].k_scale = 5.0;
     }
-    g.cams = cams; g.est_focal = est_focal; g.undistort = undistort; g.explicit_centers = explicit_centers;
+    g.cams = cams; g.est_focal = est_focal; g.undistort = undistort; g.explicit_centers = explicit_centers; g.nk = nk;
     ret = sba_motstr_levmar(n, m, mcon, vmask, p, cnp, 3, xx, NULL, 2, glue_project, NULL, &g,
                             itmax, verbose, opts6, info10, 0, NULL, 0, NULL, Vout, Sout, Uout, Wout);
     free(vmask); free(cams); free(xx);
@@ -111,7 +114,7 @@ int ref_sba_partial(int mode, int n, int m, int mcon, int cnp, const int *pt_ptr
         cams[j].f = f_fixed ? f_fixed[j] : 1.0;
         cams[j].f_scale = 0.001; cams[j].k_scale = 5.0;
     }
-    ms.g.cams = cams; ms.g.est_focal = est_focal; ms.g.undistort = 0; ms.g.explicit_centers = explicit_centers;
+    ms.g.cams = cams; ms.g.est_focal = est_focal; ms.g.undistort = 0; ms.g.explicit_centers = explicit_centers; ms.g.nk = 2;
     ms.cnp = cnp;
     if (mode == 1) {
         ms.pts = fixed_part; ms.cams = NULL;

@@ -36,7 +36,7 @@ def reduced_system(lin, sc, mu, mcon=0):
 def make_engine(sc, **kw):
     capi = pkg("capi")
     eng = capi.Engine(capi.default_config(est_focal=sc.est_focal, explicit_centers=sc.explicit_centers,
-                                          proj_sign=sc.proj_sign, **kw))
+                                          proj_sign=sc.proj_sign, undistort=sc.undistort, **kw))
     eng.load_scene(sc)
     eng.prepare()
     return eng
@@ -172,6 +172,34 @@ def test_fixed_focal_cnp6(oracle):
     assert abs(np.sqrt(info[1] / sc.nobs) - np.sqrt(o["info"][1] / sc.nobs)) < 1e-6
 
 
+@pytest.mark.parametrize("est_focal", [1, 0])
+def test_radial_distortion_k1(oracle, est_focal):
+    """cnp 8 = pose + focal + k1 (and cnp 7 = pose + k1 with the focal length held): Bundler's projection
+    distortion with one coefficient; the oracle's cnp 8 solve is itself pinned to the real sba
+    (test_oracle_golden.py::test_radial_models_match_the_reference)"""
+    sc = pkg("scene").make_scene("x", m=20, n=2000, d=5, seed=3, undistort=1, nk=1, est_focal=est_focal)
+    assert sc.cnp == 7 + est_focal
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    g = eng.debug_linearize(mu)
+    S, E, _ = reduced_system(lin, sc, mu)
+    assert abs(g["cost"] - lin["cost"]) <= 1e-11 * lin["cost"]
+    assert rel(g["ea"], lin["ea"]) < 1e-10 and rel(g["eb"], lin["eb"]) < 1e-10
+    assert np.abs(g["S"] - S).max() < 1e-10 * np.abs(lin["U"]).max()
+    assert rel(g["E"].reshape(-1), E) < 1e-9
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert ret == o["ret"] and info[6] == o["info"][6]
+    assert abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
+    a, _ = eng.params()
+    k1 = a[:, 6 + est_focal] / 5.0
+    assert abs(k1.mean() + 0.25) < 0.05                       # the generator's k1 = -0.25 is recovered
+    # a nonzero distortion in the initial guess goes through the camera record as well
+    eng.set_params(*eng.params())
+    assert abs(eng.debug_linearize(mu)["cost"] - oracle.cost(sc, eng.packed_params())) < 1e-9 * info[1]
+
+
 def test_long_tracks_use_direct_tiles(oracle):
     """points with > 10 views bypass the LDS tile and add straight into S"""
     sc = pkg("scene").make_scene("x", m=40, n=600, d=13, seed=5, strides=(1, 2, 3))
@@ -299,8 +327,8 @@ def test_error_paths():
     eng.set_problem(a0, sc.R0, sc.f_fixed, xyz, sc.x, pt, sc.obs_cam)
     with pytest.raises(RuntimeError, match="sorted by point"):
         eng.prepare()
-    with pytest.raises(RuntimeError, match="not supported"):
-        capi.Engine(capi.default_config(undistort=1))
+    with pytest.raises(RuntimeError, match="k2 is not supported"):
+        capi.Engine(capi.default_config(undistort=2))
 
 
 @pytest.mark.parametrize("name", ["C2", "C3"])

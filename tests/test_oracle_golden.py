@@ -122,6 +122,25 @@ def test_pcg_mode_reaches_same_minimum(oracle, name):
     assert r["info"][5] == z["info_final"][5]
 
 
+@pytest.mark.parametrize("nk", [1, 2])
+def test_radial_models_match_the_reference(oracle, nk):
+    """undistort: k1,k2 as parameters (Bundler, cnp 9, sfm.c:648-649) and k1 alone (cnp 8), live against the
+    real sba when it is built here, and always against the analytic-Jacobian variant of the restatement"""
+    from conftest import pkg
+    sc = pkg("scene").make_scene("x", m=14, n=900, d=5, seed=3, undistort=1, nk=nk)
+    assert sc.cnp == 7 + nk
+    a = oracle.run(sc, itmax=100)
+    b = oracle.run(sc, itmax=100, fd_jacobian=0)
+    assert a["ret"] == b["ret"] and abs(a["info"][1] - b["info"][1]) < 1e-6 * a["info"][1]
+    assert np.sqrt(a["info"][1] / sc.nobs) < 0.19 < 3.0 < np.sqrt(a["info"][0] / sc.nobs)
+    from oracle import Reference
+    if Reference.available():
+        r = Reference().run(sc, itmax=100)
+        assert r["ret"] == a["ret"] and r["info"][6] == a["info"][6] and r["info"][9] == a["info"][9]
+        assert abs(r["info"][1] - a["info"][1]) < 1e-9 * a["info"][1]
+        assert np.abs(r["p"] - a["p"]).max() < 1e-4
+
+
 def test_too_few_measurements_is_an_error(oracle):
     sc, _ = scene_from_golden("micro")
     sc.n = 2   # 2 points -> 2*nobs < unknowns (sba_levmar.c:647-650)
