@@ -87,6 +87,13 @@ int mi_ba_set_points(mi_ba_engine *e, int n, const double *xyz /* n*3 */);
 /* observations sorted by point (pt_idx non-decreasing, like pba's driver.cpp:158-161 requires) */
 int mi_ba_set_observations(mi_ba_engine *e, int64_t nobs, const double *xy /* nobs*2 */,
                            const int *pt_idx, const int *cam_idx);
+/* Bundler's soft constraints (camera_constraints_t / point_constraints_t, sba.h:76-86): penalty
+ *   sum_j,r w_jr (v_jr - a_jr)^2  +  nobs * sum_i w_i |v_i - b_i|^2
+ * added to the cost, U_j / V_i diagonals and gradients as sba_levmar.c:809-842, 952-963, 1017-1029 do -- including
+ * the reference's lag (the penalty of a trial point is evaluated at the old p, :1498).  A weight of 0 leaves the
+ * entry free; NULL clears.  Call after set_cameras / set_points and before prepare. */
+int mi_ba_set_camera_constraints(mi_ba_engine *e, const double *weights /* m*cnp */, const double *values /* m*cnp */);
+int mi_ba_set_point_constraints(mi_ba_engine *e, const double *weight /* n */, const double *values /* n*3 */);
 /* builds the shard plan, uploads everything to HBM */
 int mi_ba_prepare(mi_ba_engine *e);
 

@@ -11,8 +11,8 @@
  * camera_params_t / v3_t are layout-compatible with sfm.h:29-51 and matrix/vector.h:65-67.
  *
  * Supported this round: est_focal_length 0/1, explicit_camera_centers 0/1, ncons >= 0, fix_points
- * (motion-only, sba_mot_levmar).
- * Not yet: use_constraints, use_point_constraints,
+ * (motion-only, sba_mot_levmar), use_constraints, use_point_constraints (Bundler's soft constraints).
+ * Not yet:
  * optimize_for_fisheye, undistort, const_focal_length, the Vout/Sout/Uout/Wout exports -- asking
  * for any of them makes mi_run_sfm return MI_BA_ERROR (run_sfm prints the reason and returns).
  */

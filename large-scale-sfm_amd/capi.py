@@ -68,7 +68,8 @@ def lib() -> C.CDLL:
         sig = {
             "mi_ba_destroy": [vp], "mi_ba_cnp": [vp], "mi_ba_prepare": [vp], "mi_ba_begin": [vp], "mi_ba_step": [vp],
             "mi_ba_reset_timing": [vp], "mi_ba_set_cameras": [vp, i32, dp, dp, dp], "mi_ba_set_points": [vp, i32, dp],
-            "mi_ba_set_observations": [vp, i64, dp, ip, ip], "mi_ba_run": [vp, dp], "mi_ba_get_info": [vp, dp],
+            "mi_ba_set_observations": [vp, i64, dp, ip, ip], "mi_ba_set_camera_constraints": [vp, dp, dp],
+            "mi_ba_set_point_constraints": [vp, dp, dp], "mi_ba_set_fixed_cameras": [vp, C.c_void_p], "mi_ba_run": [vp, dp], "mi_ba_get_info": [vp, dp],
             "mi_ba_get_trace": [vp, dp, i32], "mi_ba_get_params": [vp, dp, dp], "mi_ba_set_params": [vp, dp, dp],
             "mi_ba_get_rotations": [vp, dp], "mi_ba_debug_linearize": [vp, dbl, dp, dp, dp, dp, dp, dp, dp],
             "mi_ba_debug_solve": [vp, dbl, dp, dp, dp], "mi_ba_get_timing": [vp, C.POINTER(Timing)],
@@ -132,6 +133,14 @@ class Engine:
         assert cnp == self.cnp, (cnp, self.cnp)
         self.set_problem(np.ascontiguousarray(p0[:m * cnp]).reshape(m, cnp), sc.R0, sc.f_fixed,
                          np.ascontiguousarray(p0[m * cnp:]).reshape(n, 3), sc.x, sc.obs_pt(), sc.obs_cam)
+        cons = getattr(sc, "constraints", None) or {}
+        self.set_constraints(cons.get("cam_cw"), cons.get("cam_cv"), cons.get("pt_cw"), cons.get("pt_cv"))
+
+    def set_constraints(self, cam_w=None, cam_v=None, pt_w=None, pt_v=None):
+        c = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
+        cam_w, cam_v, pt_w, pt_v = c(cam_w), c(cam_v), c(pt_w), c(pt_v)
+        self._chk(self.L.mi_ba_set_camera_constraints(self.h, _d(cam_w), _d(cam_v)), "set_camera_constraints")
+        self._chk(self.L.mi_ba_set_point_constraints(self.h, _d(pt_w), _d(pt_v)), "set_point_constraints")
 
     def set_problem(self, a0, R0, f_fixed, xyz, xy, pt_idx, cam_idx):
         a0 = np.ascontiguousarray(a0, np.float64); R0 = np.ascontiguousarray(R0, np.float64)

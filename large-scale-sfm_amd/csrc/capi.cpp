@@ -55,6 +55,8 @@ int mi_ba_cnp(const mi_ba_engine *h) { return h ? h->e->cnp : MI_BA_ERROR; }
 int mi_ba_set_cameras(mi_ba_engine *h, int m, const double *a0, const double *R0, const double *f_fixed)
 { return h ? h->e->set_cameras(m, a0, R0, f_fixed) : MI_BA_ERROR; }
 int mi_ba_set_fixed_cameras(mi_ba_engine *h, const unsigned char *mask) { return h ? h->e->set_fixed_cameras(mask) : MI_BA_ERROR; }
+int mi_ba_set_camera_constraints(mi_ba_engine *h, const double *w, const double *v) { return h ? h->e->set_camera_constraints(w, v) : MI_BA_ERROR; }
+int mi_ba_set_point_constraints(mi_ba_engine *h, const double *w, const double *v) { return h ? h->e->set_point_constraints(w, v) : MI_BA_ERROR; }
 int mi_ba_set_points(mi_ba_engine *h, int n, const double *xyz) { return h ? h->e->set_points(n, xyz) : MI_BA_ERROR; }
 int mi_ba_set_observations(mi_ba_engine *h, int64_t nobs, const double *xy, const int *pt_idx, const int *cam_idx)
 { return h ? h->e->set_observations(nobs, xy, pt_idx, cam_idx) : MI_BA_ERROR; }

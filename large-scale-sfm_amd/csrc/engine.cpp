@@ -97,6 +97,26 @@ int Engine::set_fixed_cameras(const unsigned char *mask)
     return 0;
 }
 
+int Engine::set_camera_constraints(const double *weights, const double *values)
+{
+    if (!m_) { err = "set_camera_constraints: set_cameras first"; return MI_BA_ERROR; }
+    if (weights && !values) { err = "set_camera_constraints: values missing"; return MI_BA_ERROR; }
+    if (weights) { h_cam_cw_.assign(weights, weights + (size_t)m_ * cnp); h_cam_cv_.assign(values, values + (size_t)m_ * cnp); }
+    else { h_cam_cw_.clear(); h_cam_cv_.clear(); }
+    prepared_ = begun_ = false;
+    return 0;
+}
+
+int Engine::set_point_constraints(const double *weight, const double *values)
+{
+    if (!n_) { err = "set_point_constraints: set_points first"; return MI_BA_ERROR; }
+    if (weight && !values) { err = "set_point_constraints: values missing"; return MI_BA_ERROR; }
+    if (weight) { h_pt_cw_.assign(weight, weight + n_); h_pt_cv_.assign(values, values + (size_t)n_ * 3); }
+    else { h_pt_cw_.clear(); h_pt_cv_.clear(); }
+    prepared_ = begun_ = false;
+    return 0;
+}
+
 int Engine::set_points(int n, const double *xyz)
 {
     if (n <= 0 || !xyz) { err = "set_points: bad arguments"; return MI_BA_ERROR; }
@@ -175,6 +195,26 @@ int Engine::prepare()
         UP(d_obs_xy_, xy);
     }
     UP(d_R0_, h_R0_); UP(d_ff_, h_ff_);
+    {   // soft constraints: camera side always present (zeros = none), point side only when set
+        if (!h_pt_cw_.empty() && cfg.mode != 0) { err = "prepare: point constraints need the full bundle (mode 0)"; return MI_BA_ERROR; }
+        if (!h_cam_cw_.empty() && cfg.mode == 2) { err = "prepare: camera constraints make no sense in a structure-only bundle"; return MI_BA_ERROR; }
+        std::vector<double> cw((size_t)m_ * kCP, 0.0), cv((size_t)m_ * kCP, 0.0);
+        if (!h_cam_cw_.empty())
+            for (int j = 0; j < m_; ++j)
+                for (int r = 0; r < cnp; ++r) { cw[(size_t)j * kCP + r] = h_cam_cw_[(size_t)j * cnp + r]; cv[(size_t)j * kCP + r] = h_cam_cv_[(size_t)j * cnp + r]; }
+        UP(d_cam_cw_, cw); UP(d_cam_cv_, cv);
+        d_pt_cw_.release(); d_pt_cv_.release();
+        if (!h_pt_cw_.empty()) {
+            const size_t npl_ = (size_t)pl.npts_local();
+            std::vector<double> pw(npl_), pv(npl_ * 3);
+            for (size_t t = 0; t < npl_; ++t) {
+                const size_t i = (size_t)pl.perm[pl.pt_begin + t];
+                pw[t] = h_pt_cw_[i] * (double)nobs_;                 // "nvis * weight", sba_levmar.c:1026
+                for (int r = 0; r < 3; ++r) pv[3 * t + r] = h_pt_cv_[3 * i + r];
+            }
+            UP(d_pt_cw_, pw); UP(d_pt_cv_, pv);
+        }
+    }
     {   // long tracks: scratch rows and the upper pattern for the block lookup
         std::vector<int> scr(pl.long_pts.size() + 1, 0);
         long_max_pairs_ = 0;
@@ -279,6 +319,7 @@ LongArgs Engine::long_args(double mu, bool want_diag, double *dB_dev, int part_r
     a.long_pts = d_long_pts_.p; a.long_scr = d_long_scr_.p; a.pt_obs = d_pt_obs_.p; a.obs_cam = d_obs_cam_.p;
     a.up_row = d_up_row_.p; a.up_col = d_up_col_.p; a.cam_fixed = d_fixed_.p; a.obs_xy = d_obs_xy_.p;
     a.cam_lin = d_cam_lin_[cur_].p; a.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; a.pts = d_pts_[cur_].p; a.dA = d_dA_.p;
+    a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
     a.scratch = d_long_scratch_.p; a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p;
     a.pts_new = d_pts_[cur_ ^ 1].p; a.dB = dB_dev; a.mu = mu; a.eps5 = cfg.opts[5]; a.max_pairs = long_max_pairs_;
     a.nlong = (int)plan_.long_pts.size(); a.m = m_; a.want_diag = want_diag ? 1 : 0; a.part_row0 = part_row0; a.cfg = model();
@@ -301,6 +342,7 @@ bool Engine::linear_phase(double mu, bool want_diag)
     a.m = m_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
     a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc;
     a.dbg = d_dbg_.p; a.want_diag = want_diag ? 1 : 0;
+    a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
     (void)hipEventRecord(ev_[0], st_);
     a.tile0 = 0;
     launch_build(st_, cnp, true, pl.ntile_lds, a);
@@ -311,7 +353,7 @@ bool Engine::linear_phase(double mu, bool want_diag)
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
-                    S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_E_.p, scal_());
+                    S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, d_E_.p, scal_());
     launch_block_inv(st_, m_, d_bsr_diag_.p, d_S_full_.p, d_Minv_.p, scal_());
     return hipok(hipGetLastError(), "launch (linear phase)");
 }
@@ -376,7 +418,8 @@ int Engine::begin()
     trace.clear();
     // probe pass: cost at p0 and the largest diagonal entry of U, V -> mu0 = tau * max (sba_levmar.c:1124-1128)
     if (!linear_phase(1.0, true) || !read_scalars()) return MI_BA_ERROR;
-    p_eL2_ = init_p_eL2_ = h_scal_[SC_COST];
+    c_lag_ = h_scal_[SC_CONS_CAM] + h_scal_[SC_CONS_PTS];       // sba_levmar.c:809-842
+    p_eL2_ = init_p_eL2_ = h_scal_[SC_COST] + c_lag_;
     maxdiag_ = measured_maxdiag();
     eab_inf_ = std::max(h_scal_[SC_EA_INF], h_scal_[SC_EB_INF]);
     mu_ = std::fabs(cfg.opts[0]) * maxdiag_;
@@ -412,7 +455,9 @@ int Engine::step()
     if (hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) { timing.backsub_ms += ms; timing.backsub_launches += 1; }
     const double *s = h_scal_;
     timing.pcg_iters += s[SC_PCG_ITERS];
-    p_eL2_ = s[SC_COST];
+    // cost carried by the reference = residuals at p + the constraint penalty of the previous accepted iterate
+    const double c_cur = s[SC_CONS_CAM] + s[SC_CONS_PTS];
+    p_eL2_ = s[SC_COST] + c_lag_;
     // the truncated drivers' parameter vector is the free block only (sba_levmar.c:2234, 2838)
     p_L2_ = (cfg.mode == 2 ? 0.0 : s[SC_PL2_CAMS]) + (cfg.mode == 1 ? 0.0 : s[SC_PL2_PTS] + pl2_inactive_);
     eab_inf_ = std::max(s[SC_EA_INF], s[SC_EB_INF]);
@@ -441,7 +486,7 @@ int Engine::step()
         }
         ++nfev_;
         {
-            const double pdp_eL2 = s[SC_COST_NEW];
+            const double pdp_eL2 = s[SC_COST_NEW] + c_cur; // QUIRK: penalty at the OLD p (sba_levmar.c:1498, 1514)
             if (!std::isfinite(pdp_eL2)) { stop_ = 7; end_outer(); ret = 2; break; }         // :1479-1485
             const double dL = s[SC_DL_CAMS] + s[SC_DL_PTS], dF = p_eL2_ - pdp_eL2;
             if (dL > 0.0 && dF > 0.0) {                                                       // :1543
@@ -456,7 +501,7 @@ int Engine::step()
                     // QUIRK kept (sba_levmar.c:1569-1572): stop 8 leaves before p <- p + dp
                     if (cfg.mode == 0 && s[SC_MAX_PCT] < eps5 && itno_ >= 4) { stop_ = 8; discard = true; } // motstr only
                 }
-                if (!discard) { accept_trial(); p_eL2_ = pdp_eL2; }
+                if (!discard) { accept_trial(); p_eL2_ = pdp_eL2; c_lag_ = c_cur; }
                 end_outer();
                 ret = stop_ ? 2 : 1;
                 break;

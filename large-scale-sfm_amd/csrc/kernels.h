@@ -32,11 +32,11 @@ struct ModelCfg {
 // accumulation buffer (engine.h) so the SUM part of all-reduce #1 is one contiguous range
 enum Scal {
     // [0,8)  k_build sums over this rank's observations / points      (all-reduce #1, SUM)
-    SC_COST = 0, SC_PL2_PTS = 1,
+    SC_COST = 0, SC_PL2_PTS = 1, SC_CONS_PTS = 2,   // CONS_PTS: soft point-constraint penalty at p
     // [8,16) k_build maxima                                            (all-reduce #1, MAX)
     SC_EB_INF = 8, SC_MAXDIAG_V = 9, SC_SINGULAR = 10,
     // [16,32) camera-side values, replicated on every rank
-    SC_EA_INF = 16, SC_MAXDIAG_U, SC_PL2_CAMS, SC_DL_CAMS, SC_DP2_CAMS, SC_PCG_ITERS, SC_PCG_STATUS, SC_PCG_DONE, SC_NOT_PD,
+    SC_EA_INF = 16, SC_MAXDIAG_U, SC_PL2_CAMS, SC_DL_CAMS, SC_DP2_CAMS, SC_PCG_ITERS, SC_PCG_STATUS, SC_PCG_DONE, SC_NOT_PD, SC_CONS_CAM,
     // [32,40) k_backsub sums                                           (all-reduce #2, SUM)
     SC_COST_NEW = 32, SC_DL_PTS = 33, SC_DP2_PTS = 34,
     // [40,48) k_backsub maxima                                         (all-reduce #2, MAX)
@@ -56,6 +56,7 @@ struct BuildArgs {
     long long pair_gblk_base;
     int tile0, m, want_diag;                // want_diag: also accumulate diag U_j (mu0 and info[4] only)
     const double *cam_lin, *pts;
+    const double *pt_cw, *pt_cv;            // soft point constraints (weight already x nvis), internal order; NULL = none
     double mu;
     unsigned long long *dbg;                // diagnostic stamp sums (MIBA_STAMPS build), else NULL
     double *S_up, *camvec, *ptout, *part;   // part: [ntile][kPartW] cost, |X|^2, -, -, |eb|inf, max diag V, singular
@@ -78,7 +79,7 @@ struct LongArgs {
     const int *long_pts, *long_scr, *pt_obs, *obs_cam, *up_row, *up_col;
     const unsigned char *cam_fixed;
     const double2 *obs_xy;
-    const double *cam_lin, *cam_lin_new, *pts, *dA;
+    const double *cam_lin, *cam_lin_new, *pts, *dA, *pt_cw, *pt_cv;
     double *scratch, *S_up, *camvec, *ptout, *part, *pts_new, *dB;
     double mu, eps5;
     long long max_pairs;
@@ -100,7 +101,7 @@ void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const 
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
-                     const double *camvec, const double *cam_a, double *E, double *scal);
+                     double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, double *E, double *scal);
 void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal);
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // spmv + update for iteration a.it

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
         ncs = g.tile_cslot[tile + 1] - g.tile_cslot[tile];
         for (int i = lane; i < ncs * SC; i += kWave) sC[i] = 0.0;
     }
-    double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0;
+    double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0, ccost = 0.0;
     // register-resident accumulator (LDS tiles): this lane's S block follows the lane for as long as its
     // block does not change
     double acc[LDS ? BLK : 1];
@@ -419,6 +419,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
         double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
         const int j = cur.j, lp = cur.ip - p0, cs = cur.cs;
         bool head = false;
+        double pcw = 0.0, pcd[3] = { 0.0, 0.0, 0.0 };
         // ---- phase 1 (camera records are L2-resident, 192 B x m)
         {
             double cl[kCamLin];
@@ -439,7 +440,14 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
             // point boundaries without touching memory: observations of a point are consecutive lanes
             const int lp_prev = __shfl_up(active ? lp : -2, 1);
             head = active && (lane == 0 || lp != lp_prev);
-            if (head) { sStart[lp] = lane; pl2 += X[0] * X[0] + X[1] * X[1] + X[2] * X[2]; }
+            if (head) {
+                sStart[lp] = lane; pl2 += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+                if (g.pt_cw) { // soft point constraint (sba_levmar.c:1017-1029): needs X, which the prefetch below replaces
+                    pcw = g.pt_cw[cur.ip];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) pcd[t] = g.pt_cv[3 * (size_t)cur.ip + t] - X[t];
+                }
+            }
             if (lane == 0) sStart[npt] = nob;
         }
         // the next batch's points stream from HBM: issue now, consumed in its phase 1
@@ -472,7 +480,12 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
         if (head) {
             double v00 = sV[lp * SV], v01 = sV[lp * SV + 1], v02 = sV[lp * SV + 2];
             double v11 = sV[lp * SV + 3], v12 = sV[lp * SV + 4], v22 = sV[lp * SV + 5];
-            const double eb0 = sV[lp * SV + 6], eb1 = sV[lp * SV + 7], eb2 = sV[lp * SV + 8];
+            double eb0 = sV[lp * SV + 6], eb1 = sV[lp * SV + 7], eb2 = sV[lp * SV + 8];
+            if (pcw != 0.0) {
+                v00 += pcw; v11 += pcw; v22 += pcw;
+                eb0 += pcw * pcd[0]; eb1 += pcw * pcd[1]; eb2 += pcw * pcd[2];
+                ccost += pcw * (pcd[0] * pcd[0] + pcd[1] * pcd[1] + pcd[2] * pcd[2]);
+            }
             maxdv = fmax(maxdv, fmax(v00, fmax(v11, v22)));
             ebinf = fmax(ebinf, fmax(fabs(eb0), fmax(fabs(eb1), fabs(eb2))));
             v00 += g.mu; v11 += g.mu; v22 += g.mu;
@@ -589,11 +602,11 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
     if (lane == 0 && g.dbg)
         for (int i = 0; i < 8; ++i) atomicAdd(&g.dbg[i], stamp_acc[i]);
 #endif
-    cost = wave_sum(cost); pl2 = wave_sum(pl2);
+    cost = wave_sum(cost); pl2 = wave_sum(pl2); ccost = wave_sum(ccost);
     ebinf = wave_max(ebinf); maxdv = wave_max(maxdv); sing = wave_max(sing);
     if (lane == 0) { // one partial row per tile; k_reduce_partials folds them (no same-address atomics)
         double *pr = g.part + (size_t)tile * kPartW;
-        pr[0] = cost; pr[1] = pl2; pr[2] = 0.0; pr[3] = 0.0; pr[4] = ebinf; pr[5] = maxdv; pr[6] = sing; pr[7] = 0.0;
+        pr[0] = cost; pr[1] = pl2; pr[2] = ccost; pr[3] = 0.0; pr[4] = ebinf; pr[5] = maxdv; pr[6] = sing; pr[7] = 0.0;
     }
 }
 
@@ -645,6 +658,15 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
     for (int c = 0; c < 9; ++c) v[c] = block_sum_256(v[c], sh);
     cost = block_sum_256(cost, sh);
     if (tid == 0) {
+        double ccost = 0.0;
+        if (g.pt_cw && g.pt_cw[ip] != 0.0) {
+            const double w = g.pt_cw[ip];
+            for (int t = 0; t < 3; ++t) {
+                const double d = g.pt_cv[3 * (size_t)ip + t] - X[t];
+                v[6 + t] += w * d; ccost += w * d * d;
+            }
+            v[0] += w; v[3] += w; v[5] += w;
+        }
         double v00 = v[0], v01 = v[1], v02 = v[2], v11 = v[3], v12 = v[4], v22 = v[5];
         const double maxdv = fmax(v00, fmax(v11, v22)), ebinf = fmax(fabs(v[6]), fmax(fabs(v[7]), fabs(v[8])));
         v00 += g.mu; v11 += g.mu; v22 += g.mu;
@@ -665,7 +687,7 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
         po[6] = h0; po[7] = h1; po[8] = h2; po[9] = v[6]; po[10] = v[7]; po[11] = v[8];
         sVh[6] = h0; sVh[7] = h1; sVh[8] = h2;
         double *pr = g.part + (size_t)(g.part_row0 + l) * kPartW;
-        pr[0] = cost; pr[1] = X[0] * X[0] + X[1] * X[1] + X[2] * X[2]; pr[2] = 0.0; pr[3] = 0.0;
+        pr[0] = cost; pr[1] = X[0] * X[0] + X[1] * X[1] + X[2] * X[2]; pr[2] = ccost; pr[3] = 0.0;
         pr[4] = ebinf; pr[5] = maxdv; pr[6] = sing; pr[7] = 0.0;
     }
     __syncthreads();
@@ -833,7 +855,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const doubl
 __global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, const unsigned char *__restrict__ fixed, double mu, const int *__restrict__ rowidx,
                                                  const int *__restrict__ col, const int *__restrict__ src,
                                                  const unsigned char *__restrict__ trans, const double *__restrict__ S_up,
-                                                 double *__restrict__ S_full)
+                                                 const double *__restrict__ cam_cw, double *__restrict__ S_full)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int blk = (int)(gid >> 6), el = (int)(gid & 63);
@@ -843,7 +865,7 @@ __global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, const unsigne
     double v;
     if (j == k) {
         v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
-        if (r == c) v = (r < cnp) ? v + mu : 1.0;
+        if (r == c) v = (r < cnp) ? v + mu + cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
         if (fixed[j]) v = (r == c) ? 1.0 : 0.0;
     } else {
         v = trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
@@ -855,25 +877,35 @@ __global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, const unsigne
 
 // right-hand side E_j = ea_j - sum_i Y_ij eb_i (already folded: E = sum A^T (e - B h)), ||ea||_inf,
 // max diag U, ||a||^2   (sba_levmar.c:1085-1088, 1124-1128)
-__global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsigned char *__restrict__ fixed, const double *__restrict__ camvec,
-                                                     const double *__restrict__ cam_a, double *__restrict__ E,
+__global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsigned char *__restrict__ fixed, double *__restrict__ camvec,
+                                                     const double *__restrict__ cam_a, const double *__restrict__ cam_cw,
+                                                     const double *__restrict__ cam_cv, double *__restrict__ E,
                                                      double *__restrict__ scal)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    double eainf = 0.0, maxdu = 0.0, pl2 = 0.0;
+    double eainf = 0.0, maxdu = 0.0, pl2 = 0.0, cc = 0.0;
     if (gid < m * kCP) {
         const int j = gid >> 3, r = gid & 7;
         const bool live = (r < cnp) && !fixed[j];
-        const double ea = camvec[gid], Ev = camvec[(size_t)m * kCP + gid], du = camvec[2 * (size_t)m * kCP + gid];
+        double ea = camvec[gid], Ev = camvec[(size_t)m * kCP + gid], du = camvec[2 * (size_t)m * kCP + gid];
+        if (r < cnp) {
+            const double a = cam_a[gid], w = cam_cw[gid], d = cam_cv[gid] - a;
+            pl2 = a * a;
+            cc = w * d * d;                                   // every camera, fixed ones too (sba_levmar.c:810-825)
+            if (live && w != 0.0) {                           // U_jj += w (k_finalize), ea_j += w diff (:959-960)
+                ea += w * d; Ev += w * d; du += w;
+                camvec[gid] = ea;                             // k_cam_update reads ea for dL
+            }
+        }
         E[gid] = live ? Ev : 0.0;
         if (live) { eainf = fabs(ea); maxdu = du; }
-        if (r < cnp) { const double a = cam_a[gid]; pl2 = a * a; }
     }
-    eainf = wave_max(eainf); maxdu = wave_max(maxdu); pl2 = wave_sum(pl2);
+    eainf = wave_max(eainf); maxdu = wave_max(maxdu); pl2 = wave_sum(pl2); cc = wave_sum(cc);
     if ((threadIdx.x & 63) == 0) {
         atomic_max_pos(&scal[SC_EA_INF], eainf);
         atomic_max_pos(&scal[SC_MAXDIAG_U], maxdu);
         gadd(&scal[SC_PL2_CAMS], pl2);
+        gadd(&scal[SC_CONS_CAM], cc);
     }
 }
 
@@ -1254,12 +1286,12 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
-                     const double *camvec, const double *cam_a, double *E, double *scal)
+                     double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, double *E, double *scal)
 {
     const long long total = (long long)nb * 64;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cnp, nb, fixed, mu, bsr_rowidx,
-                       bsr_col, bsr_src, bsr_trans, S_up, S_full);
-    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, camvec, cam_a, E, scal);
+                       bsr_col, bsr_src, bsr_trans, S_up, cam_cw, S_full);
+    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, camvec, cam_a, cam_cw, cam_cv, E, scal);
 }
 
 void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal)

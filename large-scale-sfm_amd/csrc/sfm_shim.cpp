@@ -10,8 +10,11 @@
 
 namespace {
 
+struct Constraints { const double *cam_w = nullptr, *cam_v = nullptr, *pt_w = nullptr, *pt_v = nullptr; };
+
 int solve(int n, int m, int mcon, const char *vmask, double *p, int cnp, const double *x, const double *R0,
-          const double *f_fixed, int explicit_centers, int itmax, int verbose, const double opts[6], double info[10], int mode = 0)
+          const double *f_fixed, int explicit_centers, int itmax, int verbose, const double opts[6], double info[10], int mode = 0,
+          const Constraints &cons = Constraints())
 {
     if (n <= 0 || m <= 0 || !vmask || !p || !x || !R0 || (cnp != 6 && cnp != 7)) {
         std::fprintf(stderr, "mi_sba_motstr_levmar: bad arguments (cnp must be 6 or 7)\n");
@@ -30,6 +33,7 @@ int solve(int n, int m, int mcon, const char *vmask, double *p, int cnp, const d
     if (!e) { std::fprintf(stderr, "mi_sba_motstr_levmar: %s\n", mi_ba_last_error(nullptr)); return MI_BA_ERROR; }
     int ret = MI_BA_ERROR;
     if (mi_ba_set_cameras(e, m, p, R0, f_fixed) == 0 && mi_ba_set_points(e, n, p + (size_t)m * cnp) == 0 &&
+        mi_ba_set_camera_constraints(e, cons.cam_w, cons.cam_v) == 0 && mi_ba_set_point_constraints(e, cons.pt_w, cons.pt_v) == 0 &&
         mi_ba_set_observations(e, (int64_t)pt.size(), x, pt.data(), cam.data()) == 0 && mi_ba_prepare(e) == 0) {
         ret = mi_ba_run(e, info);
         if (ret != MI_BA_ERROR || true) mi_ba_get_params(e, p, p + (size_t)m * cnp);
@@ -53,13 +57,13 @@ int mi_sba_motstr_levmar(int n, int m, int mcon, const char *vmask, double *p, i
 int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *projections,
                int est_focal_length, int const_focal_length, int undistort, int explicit_camera_centers,
                camera_params_t *cams, v3_t *pts, int use_constraints, int use_point_constraints,
-               v3_t *, double, int fix_points, int optimize_for_fisheye,
+               v3_t *pt_constraints, double pt_constraint_weight, int fix_points, int optimize_for_fisheye,
                double eps2, double *Vout, double *Sout, double *Uout, double *Wout, double info_out[10])
 {
-    if (const_focal_length || undistort || use_constraints || use_point_constraints || optimize_for_fisheye ||
-        Vout || Sout || Uout || Wout) {
-        std::fprintf(stderr, "[run_sfm] this build supports est_focal_length / explicit_camera_centers / ncons / fix_points only "
-                             "(no constraints, distortion, fisheye or Vout/Sout/Uout/Wout)\n");
+    if (const_focal_length || undistort || optimize_for_fisheye || Vout || Sout || Uout || Wout ||
+        (use_point_constraints && (fix_points || !pt_constraints))) {
+        std::fprintf(stderr, "[run_sfm] this build supports est_focal_length / explicit_camera_centers / ncons / fix_points / "
+                             "use_constraints / use_point_constraints (no distortion, fisheye or Vout/Sout/Uout/Wout)\n");
         return MI_BA_ERROR;
     }
     const int m = num_cameras, n = num_pts, cnp = est_focal_length ? 7 : 6;
@@ -74,9 +78,33 @@ int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *pro
     }
     for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) p[(size_t)m * cnp + 3 * (size_t)i + r] = pts[i].p[r]; // :704-709
     const double opts[6] = { 1.0e-3, 1.0e-10, eps2, 1.0e-12, 0.0, 4.0e-2 };                                         // :711-719
+    // soft constraints exactly as run_sfm hands them to sba (sfm.c:727-787), with TEST_FOCAL's rescaling of the focal entry
+    std::vector<double> cw, cv, pw, pv;
+    Constraints cons;
+    if (use_constraints) {
+        cw.assign((size_t)m * cnp, 0.0); cv.assign((size_t)m * cnp, 0.0);
+        for (int j = 0; j < m; ++j)
+            for (int r = 0; r < cnp; ++r) {
+                if (!cams[j].constrained[r]) continue;
+                double w = cams[j].weights[r], v = cams[j].constraints[r];
+                if (r == 6) { v *= f_scale; w *= 1.0 / (f_scale * f_scale); }                                        // :745-749
+                cw[(size_t)j * cnp + r] = w; cv[(size_t)j * cnp + r] = v;
+            }
+        cons.cam_w = cw.data(); cons.cam_v = cv.data();
+    }
+    if (use_point_constraints) {
+        pw.assign(n, 0.0); pv.assign((size_t)n * 3, 0.0);
+        for (int i = 0; i < n; ++i) {
+            const double *c = pt_constraints[i].p;
+            if (c[0] == 0.0 && c[1] == 0.0 && c[2] == 0.0) continue;                                                 // :769-777
+            pw[i] = pt_constraint_weight;
+            for (int r = 0; r < 3; ++r) pv[(size_t)i * 3 + r] = c[r];
+        }
+        cons.pt_w = pw.data(); cons.pt_v = pv.data();
+    }
     double info[10] = { 0 };
     const int ret = solve(n, m, ncons, vmask, p.data(), cnp, projections, R0.data(), ff.data(), explicit_camera_centers,
-                          150 /* MAX_ITERS, sfm.c:820 */, 0, opts, info, fix_points ? 1 : 0 /* sba_mot_levmar, sfm.c:845-852 */);
+                          150 /* MAX_ITERS, sfm.c:820 */, 0, opts, info, fix_points ? 1 : 0 /* sba_mot_levmar, sfm.c:845-852 */, cons);
     if (info_out) std::memcpy(info_out, info, sizeof(info));
     if (ret == MI_BA_ERROR) return ret;
     std::printf("[run_sfm] Number of iterations: %d\n", (int)info[5]);

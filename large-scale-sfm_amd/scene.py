@@ -49,6 +49,7 @@ class Scene:
     name: str = ""
     meta: dict = field(default_factory=dict)
     nk: int = 2             # distortion parameters when undistort: 2 = k1,k2 (Bundler), 1 = k1 only
+    constraints: dict | None = None   # soft constraints: cam_cw / cam_cv [m, cnp], pt_cw [n] / pt_cv [n, 3]
 
     @property
     def nobs(self) -> int:

@@ -420,6 +420,42 @@ static void build_blocks(const ora_problem *pb, const double *jac, const double 
     }
 }
 
+/* soft-constraint penalty at p: sum w (c - p)^2 over camera parameters (all cameras, sba_levmar.c:809-826) plus
+ * nvis * w * |c - b|^2 over constrained points (:829-842) */
+static double constraint_cost(const ora_problem *pb, const double *p)
+{
+    const int cnp = pb->cnp, m = pb->m, n = pb->n;
+    const double nvis = (double)pb->pt_ptr[n];
+    double c = 0.0;
+    if (pb->cam_cw)
+        for (size_t i = 0; i < (size_t)m * cnp; ++i) { double d = pb->cam_cv[i] - p[i]; c += pb->cam_cw[i] * d * d; }
+    if (pb->pt_cw)
+        for (int i = 0; i < n; ++i)
+            for (int r = 0; r < 3; ++r) { double d = pb->pt_cv[3 * i + r] - p[(size_t)m * cnp + 3 * i + r]; c += nvis * pb->pt_cw[i] * d * d; }
+    return c;
+}
+
+/* the same constraints in the normal equations: U_jj, ea_j (:952-963), V_ii, eb_i (:1017-1029) */
+static void add_constraints(const ora_problem *pb, const double *p, ora_blocks *bk)
+{
+    const int cnp = pb->cnp, m = pb->m, n = pb->n, mcon = pb->mcon;
+    const double nvis = (double)pb->pt_ptr[n];
+    if (pb->cam_cw)
+        for (int j = mcon; j < m; ++j)
+            for (int r = 0; r < cnp; ++r) {
+                const double w = pb->cam_cw[(size_t)j * cnp + r], d = pb->cam_cv[(size_t)j * cnp + r] - p[(size_t)j * cnp + r];
+                bk->U[(size_t)j * cnp * cnp + r * cnp + r] += w;
+                bk->ea[(size_t)j * cnp + r] += w * d;
+            }
+    if (pb->pt_cw)
+        for (int i = 0; i < n; ++i)
+            for (int r = 0; r < 3; ++r) {
+                const double w = nvis * pb->pt_cw[i], d = pb->pt_cv[3 * i + r] - p[(size_t)m * cnp + 3 * i + r];
+                bk->V[9 * (size_t)i + 4 * r] += w;
+                bk->eb[3 * (size_t)i + r] += w * d;
+            }
+}
+
 /* S_jk = delta_jk U*_j - sum_i Y_ij W_ik^T, E_j = ea_j - sum_i Y_ij eb_i with
  * Y_ij = W_ij Vinv_i (sba_levmar.c:1182-1339).  S row-major, dimension (m-mcon)*cnp. */
 static void build_schur(const ora_problem *pb, const ora_blocks *bk, const double *Vinv,
@@ -540,6 +576,7 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
 
     predict(pb, p, hx); nfev = 1;
     p_eL2 = sub_norm(e, pb->x, hx, nobs2);
+    p_eL2 += constraint_cost(pb, p);
     init_p_eL2 = p_eL2;
     if (!isfinite(p_eL2)) stop = 7;
 
@@ -556,6 +593,7 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
         if (mode == 1) for (size_t o = 0; o < nobs; ++o) memset(jac + o * ABsz_ + 2 * cnp, 0, 6 * sizeof(double));
         if (mode == 2) for (size_t o = 0; o < nobs; ++o) memset(jac + o * ABsz_, 0, 2 * cnp * sizeof(double));
         build_blocks(pb, jac, e, &bk);
+        if (mode == 0) add_constraints(pb, p, &bk);
         /* ||J^T e||_inf and ||p||^2, sba_levmar.c:1085-1088 */
         p_L2 = eab_inf = 0.0;
         for (size_t i = v0; i < v1; ++i) {
@@ -624,8 +662,11 @@ int ora_motstr_levmar(const ora_problem *pb, const ora_options *op, double *p,
                 }
                 predict(pb, pdp, hx); ++nfev;
                 pdp_eL2 = sub_norm(hx, pb->x, hx, nobs2); /* hx now holds the trial residuals */
-                cost_trial = pdp_eL2;
                 if (!isfinite(pdp_eL2)) { stop = 7; break; }
+                /* QUIRK (sba_levmar.c:1498, 1514): the constraint penalty of the TRIAL point is evaluated with the
+                 * OLD p, so the carried cost lags the constraints by one accepted step */
+                if (mode == 0) pdp_eL2 += constraint_cost(pb, p);
+                cost_trial = pdp_eL2;
                 double dL = 0.0;
                 for (size_t i = v0; i < v1; ++i) dL += dp[i] * (mu * dp[i] + eab[i]);
                 double dF = p_eL2 - pdp_eL2;

@@ -54,6 +54,11 @@ typedef struct {
     const double *x;       /* 2*nobs measurements, same order */
     const double *R0;      /* m*9 row-major initial rotations (fixed during the solve, sfm.c:549) */
     const double *f_fixed; /* m focal lengths used when !est_focal (sfm.c:523) */
+    /* Bundler's soft constraints (sba.h:76-86; sba_levmar.c:809-842, 952-963, 1017-1029, 1488-1522); weight 0 = none */
+    const double *cam_cw;  /* m*cnp weights or NULL   */
+    const double *cam_cv;  /* m*cnp target values     */
+    const double *pt_cw;   /* n weights or NULL (the reference multiplies them by the observation count) */
+    const double *pt_cv;   /* n*3 target positions    */
     int nk;                /* distortion parameters when undistort: 2 = Bundler's k1,k2 (sfm.c:648-649), 1 = k1 only
                             * with k2 held at 0 (the single-coefficient model of PBA's CameraT, DataInterface.h:53) */
 } ora_problem;

@@ -35,7 +35,8 @@ class _Problem(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("mcon", C.c_int), ("cnp", C.c_int),
                 ("est_focal", C.c_int), ("undistort", C.c_int), ("explicit_centers", C.c_int),
                 ("proj_sign", C.c_double), ("f_scale", C.c_double), ("k_scale", C.c_double),
-                ("pt_ptr", _ip), ("obs_cam", _ip), ("x", _dp), ("R0", _dp), ("f_fixed", _dp), ("nk", C.c_int)]
+                ("pt_ptr", _ip), ("obs_cam", _ip), ("x", _dp), ("R0", _dp), ("f_fixed", _dp),
+                ("cam_cw", _dp), ("cam_cv", _dp), ("pt_cw", _dp), ("pt_cv", _dp), ("nk", C.c_int)]
 
 
 class _Options(C.Structure):
@@ -83,9 +84,13 @@ class Oracle:
         keep = dict(pt_ptr=np.ascontiguousarray(sc.pt_ptr, np.int32), obs_cam=np.ascontiguousarray(sc.obs_cam, np.int32),
                     x=np.ascontiguousarray(sc.x, np.float64), R0=np.ascontiguousarray(sc.R0, np.float64),
                     f_fixed=np.ascontiguousarray(sc.f_fixed, np.float64))
+        for k in ("cam_cw", "cam_cv", "pt_cw", "pt_cv"):     # optional soft constraints (Scene.constraints dict)
+            v = (getattr(sc, "constraints", None) or {}).get(k)
+            keep[k] = None if v is None else np.ascontiguousarray(v, np.float64)
         pb = _Problem(sc.n, sc.m, mcon, sc.cnp, sc.est_focal, sc.undistort, sc.explicit_centers,
                       sc.proj_sign, 0.001, 5.0, _i(keep["pt_ptr"]), _i(keep["obs_cam"]),
-                      _d(keep["x"]), _d(keep["R0"]), _d(keep["f_fixed"]), getattr(sc, "nk", 2))
+                      _d(keep["x"]), _d(keep["R0"]), _d(keep["f_fixed"]),
+                      _d(keep["cam_cw"]), _d(keep["cam_cv"]), _d(keep["pt_cw"]), _d(keep["pt_cv"]), getattr(sc, "nk", 2))
         return pb, keep
 
     def run(self, sc, p0=None, itmax=150, fd_jacobian=1, solver=0, pcg_maxit=200, pcg_tol=1e-10,
@@ -148,7 +153,10 @@ class Reference:
         with quiet_stdout():
             ret = self.lib.ref_sba_motstr(n, m, mcon, cnp, _i(pt_ptr), _i(obs_cam), _d(x), _d(p), _d(R0), _d(ff),
                                           sc.est_focal, sc.undistort, sc.explicit_centers, itmax, verbose, o6,
-                                          _d(info), _d(V), _d(S), _d(U), _d(W), getattr(sc, "nk", 2))
+                                          _d(info), _d(V), _d(S), _d(U), _d(W), getattr(sc, "nk", 2),
+                                          *[_d(None if (getattr(sc, "constraints", None) or {}).get(k) is None
+                                               else np.ascontiguousarray(sc.constraints[k], np.float64))
+                                            for k in ("cam_cw", "cam_cv", "pt_cw", "pt_cv")])
         return dict(ret=ret, p=p, info=info, V=V, S=S, U=U, W=W)
 
     def run_partial(self, sc, mode, itmax=150, opts=BUNDLER_OPTS, mcon=0):

@@ -51,8 +51,11 @@ int ref_sba_motstr(int n, int m, int mcon, int cnp, const int *pt_ptr, const int
                    const double *x, double *p, const double *R0, const double *f_fixed,
                    int est_focal, int undistort, int explicit_centers,
                    int itmax, int verbose, const double *opts6, double *info10,
-                   double *Vout, double *Sout, double *Uout, double *Wout, int nk)
+                   double *Vout, double *Sout, double *Uout, double *Wout, int nk,
+                   const double *cam_cw, const double *cam_cv, const double *pt_cw, const double *pt_cv)
 {
+    camera_constraints_t *cc = NULL;
+    point_constraints_t *pc = NULL;
     int nobs = pt_ptr[n], i, j, o, ret;
     char *vmask = (char *)calloc((size_t)n * m, 1);
     camera_params_t *cams = (camera_params_t *)calloc(m, sizeof(camera_params_t));
@@ -70,8 +73,32 @@ int ref_sba_motstr(int n, int m, int mcon, int cnp, const int *pt_ptr, const int
         cams[j].k_scale = 5.0;
     }
     g.cams = cams; g.est_focal = est_focal; g.undistort = undistort; g.explicit_centers = explicit_centers; g.nk = nk;
+    if (cam_cw) { /* camera_constraints_t as run_sfm builds them, sfm.c:727-760 */
+        cc = (camera_constraints_t *)malloc(m * sizeof(camera_constraints_t));
+        for (j = 0; j < m; ++j) {
+            int r;
+            cc[j].constrained = (char *)malloc(cnp);
+            cc[j].constraints = (double *)malloc(sizeof(double) * cnp);
+            cc[j].weights = (double *)malloc(sizeof(double) * cnp);
+            for (r = 0; r < cnp; ++r) {
+                cc[j].constrained[r] = cam_cw[(size_t)j * cnp + r] != 0.0;
+                cc[j].constraints[r] = cam_cv[(size_t)j * cnp + r];
+                cc[j].weights[r] = cam_cw[(size_t)j * cnp + r];
+            }
+        }
+    }
+    if (pt_cw) { /* point_constraints_t, sfm.c:763-787 */
+        pc = (point_constraints_t *)malloc(n * sizeof(point_constraints_t));
+        for (i = 0; i < n; ++i) {
+            pc[i].constrained = pt_cw[i] != 0.0;
+            pc[i].weight = pt_cw[i];
+            pc[i].constraints[0] = pt_cv[3 * i]; pc[i].constraints[1] = pt_cv[3 * i + 1]; pc[i].constraints[2] = pt_cv[3 * i + 2];
+        }
+    }
     ret = sba_motstr_levmar(n, m, mcon, vmask, p, cnp, 3, xx, NULL, 2, glue_project, NULL, &g,
-                            itmax, verbose, opts6, info10, 0, NULL, 0, NULL, Vout, Sout, Uout, Wout);
+                            itmax, verbose, opts6, info10, cc != NULL, cc, pc != NULL, pc, Vout, Sout, Uout, Wout);
+    if (cc) { for (j = 0; j < m; ++j) { free(cc[j].constrained); free(cc[j].constraints); free(cc[j].weights); } free(cc); }
+    free(pc);
     free(vmask); free(cams); free(xx);
     return ret;
 }

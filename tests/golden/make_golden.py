@@ -37,6 +37,18 @@ def make(name, trace_len, keep_W, **kw):
     sfm = ref.run_sfm(sc)
     mot = ref.run_partial(sc, 1)      # sba_mot_levmar: cameras only
     st = ref.run_partial(sc, 2)       # sba_str_levmar: points only
+    # Bundler's soft constraints: a focal prior on every camera, position priors on every third camera,
+    # position priors on every tenth point
+    rng = np.random.default_rng(12345)
+    m_, n_, cnp_ = sc.m, sc.n, sc.cnp
+    a0 = sc.p0[:m_ * cnp_].reshape(m_, cnp_); X0 = sc.p0[m_ * cnp_:].reshape(n_, 3)
+    cw = np.zeros((m_, cnp_)); cv = np.zeros((m_, cnp_))
+    cw[:, 6] = 3e4; cv[:, 6] = 0.8
+    cw[::3, :3] = 50.0; cv[::3, :3] = a0[::3, :3] + rng.normal(0, 0.01, a0[::3, :3].shape)
+    pw = np.zeros(n_); pv = np.zeros((n_, 3)); pw[::10] = 2e-3; pv[::10] = X0[::10] + 0.02
+    sc.constraints = dict(cam_cw=cw, cam_cv=cv, pt_cw=pw, pt_cv=pv)
+    cons = ref.run(sc, itmax=150)
+    sc.constraints = None
     out = dict(n=sc.n, m=sc.m, cnp=sc.cnp, est_focal=sc.est_focal, undistort=sc.undistort,
                explicit_centers=sc.explicit_centers, proj_sign=sc.proj_sign,
                pt_ptr=sc.pt_ptr, obs_cam=sc.obs_cam, x=sc.x, R0=sc.R0, f_fixed=sc.f_fixed, p0=sc.p0,
@@ -44,7 +56,8 @@ def make(name, trace_len, keep_W, **kw):
                cost_trace=costs, p_final=full["p"], info_final=full["info"], ret_final=full["ret"],
                p_mcon2=mcon["p"], info_mcon2=mcon["info"],
                sfm_R=sfm["R"], sfm_t=sfm["t"], sfm_f=sfm["f"], sfm_pts=sfm["pts"],
-               p_mot=mot["p"], info_mot=mot["info"], p_str=st["p"], info_str=st["info"])
+               p_mot=mot["p"], info_mot=mot["info"], p_str=st["p"], info_str=st["info"],
+               cons_cam_cw=cw, cons_cam_cv=cv, cons_pt_cw=pw, cons_pt_cv=pv, p_cons=cons["p"], info_cons=cons["info"])
     if keep_W:
         out["W0"] = blk["W"]
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"ref_{name}.npz")

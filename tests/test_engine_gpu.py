@@ -172,6 +172,20 @@ def test_fixed_focal_cnp6(oracle):
     assert abs(np.sqrt(info[1] / sc.nobs) - np.sqrt(o["info"][1] / sc.nobs)) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["micro", "C1", "C1t"])
+def test_soft_constraints_match_the_reference(oracle, name):
+    """Bundler's camera and point constraints (sba.h:76-86), incl. the one-step lag of the penalty, vs the real sba"""
+    sc, z = scene_from_golden(name)
+    sc.constraints = dict(cam_cw=z["cons_cam_cw"], cam_cv=z["cons_cam_cv"], pt_cw=z["cons_pt_cw"], pt_cv=z["cons_pt_cv"])
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    ret, info = eng.run()
+    want = z["info_cons"]
+    assert ret == int(want[5]) and info[6] == want[6] and info[9] == want[9]
+    assert abs(info[0] - want[0]) < 1e-11 * want[0] and abs(info[1] - want[1]) < 1e-6 * want[1]
+    assert np.abs(eng.packed_params() - z["p_cons"]).max() < 1e-5     # the constraints pin the gauge
+
+
 @pytest.mark.parametrize("est_focal", [1, 0])
 def test_radial_distortion_k1(oracle, est_focal):
     """cnp 8 = pose + focal + k1 (and cnp 7 = pose + k1 with the focal length held): Bundler's projection

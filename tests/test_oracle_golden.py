@@ -122,6 +122,24 @@ def test_pcg_mode_reaches_same_minimum(oracle, name):
     assert r["info"][5] == z["info_final"][5]
 
 
+def with_constraints(sc, z):
+    sc.constraints = dict(cam_cw=z["cons_cam_cw"], cam_cv=z["cons_cam_cv"], pt_cw=z["cons_pt_cw"], pt_cv=z["cons_pt_cv"])
+    return sc
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_soft_constraints(oracle, name):
+    """Bundler's camera / point constraints incl. the one-step lag of the penalty (sba_levmar.c:1498, 1514)"""
+    sc, z = scene_from_golden(name)
+    r = oracle.run(with_constraints(sc, z), itmax=150)
+    want = z["info_cons"]
+    for k in (5, 6, 9):
+        assert r["info"][k] == want[k], k
+    assert abs(r["info"][0] - want[0]) < 1e-12 * want[0] and abs(r["info"][1] - want[1]) < 1e-9 * want[1]
+    assert np.abs(r["p"] - z["p_cons"]).max() < 1e-7
+    assert want[0] > z["info_final"][0]            # the penalty is part of the reported cost
+
+
 @pytest.mark.parametrize("nk", [1, 2])
 def test_radial_models_match_the_reference(oracle, nk):
     """undistort: k1,k2 as parameters (Bundler, cnp 9, sfm.c:648-649) and k1 alone (cnp 8), live against the
