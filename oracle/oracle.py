@@ -174,8 +174,9 @@ class Reference:
                                            sc.est_focal, sc.explicit_centers, itmax, (C.c_double * 6)(*opts), _d(info))
         return dict(ret=ret, p=np.concatenate([cams, pts]), info=info)
 
-    def run_sfm(self, sc, eps2=1e-12):
-        """Bundler's run_sfm end to end (MAX_ITERS 150 hard-coded, sfm.c:820)."""
+    def run_sfm(self, sc, eps2=1e-12, cam_w=None, cam_v=None, pt_v=None, pt_weight=0.0):
+        """Bundler's run_sfm end to end (MAX_ITERS 150 hard-coded, sfm.c:820); cam_w / cam_v (m, 9) and pt_v (n, 3)
+        are run_sfm's own soft constraints in camera_params_t units."""
         m, n, cnp = sc.m, sc.n, sc.cnp
         a = sc.p0[:m * cnp].reshape(m, cnp)
         R = np.ascontiguousarray(sc.R0, np.float64).copy()
@@ -186,6 +187,8 @@ class Reference:
         pt_ptr = np.ascontiguousarray(sc.pt_ptr, np.int32); obs_cam = np.ascontiguousarray(sc.obs_cam, np.int32)
         x = np.ascontiguousarray(sc.x, np.float64)
         with quiet_stdout():
-            self.lib.ref_run_sfm(n, m, 0, _i(pt_ptr), _i(obs_cam), _d(x), sc.est_focal, sc.undistort,
-                                 sc.explicit_centers, _d(R), _d(t), _d(f), _d(k), _d(pts), C.c_double(eps2))
+            opt = [None if v is None else np.ascontiguousarray(v, np.float64) for v in (cam_w, cam_v, pt_v)]
+            self.lib.ref_run_sfm_cons(n, m, 0, _i(pt_ptr), _i(obs_cam), _d(x), sc.est_focal, sc.undistort,
+                                      sc.explicit_centers, _d(R), _d(t), _d(f), _d(k), _d(pts), C.c_double(eps2),
+                                      *[None if v is None else _d(v) for v in opt], C.c_double(pt_weight))
         return dict(R=R.reshape(m, 3, 3), t=t, f=f, k=k, pts=pts.reshape(n, 3))

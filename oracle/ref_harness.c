@@ -156,15 +156,31 @@ int ref_sba_partial(int mode, int n, int m, int mcon, int cnp, const int *pt_ptr
 
 /* Bundler's driver as is.  cams_R m*9, cams_t m*3 (t or C), cams_f m, cams_k m*2 are read
  * and written back; pts n*3 likewise. */
+void ref_run_sfm_cons(int n, int m, int ncons, const int *pt_ptr, const int *obs_cam, const double *x,
+                      int est_focal, int undistort, int explicit_centers,
+                      double *cams_R, double *cams_t, double *cams_f, double *cams_k, double *pts, double eps2,
+                      const double *cam_w, const double *cam_v, const double *pt_v, double pt_weight);
+
 void ref_run_sfm(int n, int m, int ncons, const int *pt_ptr, const int *obs_cam, const double *x,
                  int est_focal, int undistort, int explicit_centers,
                  double *cams_R, double *cams_t, double *cams_f, double *cams_k, double *pts, double eps2)
+{
+    ref_run_sfm_cons(n, m, ncons, pt_ptr, obs_cam, x, est_focal, undistort, explicit_centers, cams_R, cams_t, cams_f, cams_k,
+                     pts, eps2, NULL, NULL, NULL, 0.0);
+}
+
+/* the same with run_sfm's own constraint arguments: cam_w / cam_v are m*9 weights / targets in the units of
+ * camera_params_t (weight 0 = unconstrained; sfm.h:37-39), pt_v n*3 targets ((0,0,0) = unconstrained, sfm.c:769) */
+void ref_run_sfm_cons(int n, int m, int ncons, const int *pt_ptr, const int *obs_cam, const double *x,
+                      int est_focal, int undistort, int explicit_centers,
+                      double *cams_R, double *cams_t, double *cams_f, double *cams_k, double *pts, double eps2,
+                      const double *cam_w, const double *cam_v, const double *pt_v, double pt_weight)
 {
     int nobs = pt_ptr[n], i, j, o;
     char *vmask = (char *)calloc((size_t)n * m, 1);
     camera_params_t *cams = (camera_params_t *)calloc(m, sizeof(camera_params_t));
     double *xx = (double *)malloc(sizeof(double) * 2 * nobs);
-    v3_t *P = (v3_t *)malloc(sizeof(v3_t) * n);
+    v3_t *P = (v3_t *)malloc(sizeof(v3_t) * n), *PC = NULL;
     for (i = 0; i < n; ++i) {
         for (o = pt_ptr[i]; o < pt_ptr[i + 1]; ++o) vmask[(size_t)i * m + obs_cam[o]] = 1;
         Vx(P[i]) = pts[3 * i]; Vy(P[i]) = pts[3 * i + 1]; Vz(P[i]) = pts[3 * i + 2];
@@ -174,9 +190,22 @@ void ref_run_sfm(int n, int m, int ncons, const int *pt_ptr, const int *obs_cam,
         memcpy(cams[j].R, cams_R + 9 * j, 9 * sizeof(double));
         memcpy(cams[j].t, cams_t + 3 * j, 3 * sizeof(double));
         cams[j].f = cams_f[j]; cams[j].k[0] = cams_k[2 * j]; cams[j].k[1] = cams_k[2 * j + 1];
+        if (cam_w) {
+            int r;
+            for (r = 0; r < 9; ++r) {
+                cams[j].constrained[r] = cam_w[9 * j + r] != 0.0;
+                cams[j].weights[r] = cam_w[9 * j + r];
+                cams[j].constraints[r] = cam_v[9 * j + r];
+            }
+        }
+    }
+    if (pt_v) {
+        PC = (v3_t *)malloc(sizeof(v3_t) * n);
+        for (i = 0; i < n; ++i) { Vx(PC[i]) = pt_v[3 * i]; Vy(PC[i]) = pt_v[3 * i + 1]; Vz(PC[i]) = pt_v[3 * i + 2]; }
     }
     run_sfm(n, m, ncons, vmask, xx, est_focal, 0, undistort, explicit_centers, cams, P,
-            0, 0, NULL, 0.0, 0, 0, eps2, NULL, NULL, NULL, NULL);
+            cam_w != NULL, pt_v != NULL, PC, pt_weight, 0, 0, eps2, NULL, NULL, NULL, NULL);
+    free(PC);
     for (j = 0; j < m; ++j) {
         memcpy(cams_R + 9 * j, cams[j].R, 9 * sizeof(double));
         memcpy(cams_t + 3 * j, cams[j].t, 3 * sizeof(double));

@@ -49,6 +49,12 @@ def make(name, trace_len, keep_W, **kw):
     sc.constraints = dict(cam_cw=cw, cam_cv=cv, pt_cw=pw, pt_cv=pv)
     cons = ref.run(sc, itmax=150)
     sc.constraints = None
+    # the same kind of priors through run_sfm's own arguments (raw focal units; TEST_FOCAL rescales them, sfm.c:745-749)
+    sw = np.zeros((m_, 9)); sv = np.zeros((m_, 9))
+    sw[:, 6] = 0.03; sv[:, 6] = 800.0
+    sw[::3, :3] = 50.0; sv[::3, :3] = cv[::3, :3]
+    spv = np.zeros((n_, 3)); spv[::10] = pv[::10]
+    sfmc = ref.run_sfm(sc, cam_w=sw, cam_v=sv, pt_v=spv, pt_weight=2e-3)
     out = dict(n=sc.n, m=sc.m, cnp=sc.cnp, est_focal=sc.est_focal, undistort=sc.undistort,
                explicit_centers=sc.explicit_centers, proj_sign=sc.proj_sign,
                pt_ptr=sc.pt_ptr, obs_cam=sc.obs_cam, x=sc.x, R0=sc.R0, f_fixed=sc.f_fixed, p0=sc.p0,
@@ -57,7 +63,9 @@ def make(name, trace_len, keep_W, **kw):
                p_mcon2=mcon["p"], info_mcon2=mcon["info"],
                sfm_R=sfm["R"], sfm_t=sfm["t"], sfm_f=sfm["f"], sfm_pts=sfm["pts"],
                p_mot=mot["p"], info_mot=mot["info"], p_str=st["p"], info_str=st["info"],
-               cons_cam_cw=cw, cons_cam_cv=cv, cons_pt_cw=pw, cons_pt_cv=pv, p_cons=cons["p"], info_cons=cons["info"])
+               cons_cam_cw=cw, cons_cam_cv=cv, cons_pt_cw=pw, cons_pt_cv=pv, p_cons=cons["p"], info_cons=cons["info"],
+               sfmc_cam_w=sw, sfmc_cam_v=sv, sfmc_pt_v=spv, sfmc_pt_weight=2e-3,
+               sfmc_R=sfmc["R"], sfmc_t=sfmc["t"], sfmc_f=sfmc["f"], sfmc_pts=sfmc["pts"])
     if keep_W:
         out["W0"] = blk["W"]
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"ref_{name}.npz")

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 class CameraParams(C.Structure):      # sfm.h:29-51 / include/mi_sfm.h
     _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("f", C.c_double), ("k", C.c_double * 2),
-                ("k_inv", C.c_double * 6), ("constrained", C.c_char * 9), ("constraints", C.c_double * 9),
+                ("k_inv", C.c_double * 6), ("constrained", C.c_ubyte * 9), ("constraints", C.c_double * 9),
                 ("weights", C.c_double * 9), ("K_known", C.c_double * 9), ("k_known", C.c_double * 5),
                 ("fisheye", C.c_char), ("known_intrinsics", C.c_char), ("f_cx", C.c_double), ("f_cy", C.c_double),
                 ("f_rad", C.c_double), ("f_angle", C.c_double), ("f_focal", C.c_double), ("f_scale", C.c_double),
@@ -56,6 +56,37 @@ def test_run_sfm_matches_the_references_run_sfm(name):
     # unsupported options are refused, not silently ignored
     assert L.mi_run_sfm(n, m, 0, vmask.ctypes.data, x.ctypes.data, 1, 0, 1, 1, C.addressof(cams), pts.ctypes.data,
                         0, 0, None, 0.0, 0, 0, 1e-12, None, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("name", ["C1", "C1t"])
+def test_run_sfm_with_soft_constraints(name):
+    """use_constraints / use_point_constraints (sfm.c:727-787) against the reference's run_sfm with the same priors"""
+    sc, z = scene_from_golden(name)
+    L = pkg("capi").lib()
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    a = sc.p0[:m * cnp].reshape(m, cnp)
+    cams = (CameraParams * m)()
+    for j in range(m):
+        cams[j].R[:] = list(sc.R0[j]); cams[j].t[:] = list(a[j, :3]); cams[j].f = a[j, 6] / 0.001
+        cams[j].constrained[:] = [int(w != 0) for w in z["sfmc_cam_w"][j]]
+        cams[j].weights[:] = list(z["sfmc_cam_w"][j]); cams[j].constraints[:] = list(z["sfmc_cam_v"][j])
+    pts = np.ascontiguousarray(sc.p0[m * cnp:]).copy()
+    ptc = np.ascontiguousarray(z["sfmc_pt_v"])
+    vmask, x = _dense_inputs(sc)
+    info = np.zeros(10)
+    L.mi_run_sfm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    ret = L.mi_run_sfm(n, m, 0, vmask.ctypes.data, x.ctypes.data, 1, 0, 0, sc.explicit_centers, C.addressof(cams),
+                       pts.ctypes.data, 1, 1, ptc.ctypes.data, float(z["sfmc_pt_weight"]), 0, 0, 1e-12,
+                       None, None, None, None, info.ctypes.data)
+    assert ret >= 0
+    R = np.array([list(c.R) for c in cams]).reshape(m, 3, 3)
+    t = np.array([list(c.t) for c in cams]); f = np.array([c.f for c in cams])
+    # soft priors pin the gauge only weakly and the shim solves with the default PCG tolerance: same bars as above
+    assert np.abs(R - z["sfmc_R"]).max() < 1e-3 and np.abs(t - z["sfmc_t"]).max() < 5e-3
+    assert np.abs(f - z["sfmc_f"]).max() < 0.5 and np.abs(pts.reshape(n, 3) - z["sfmc_pts"]).max() < 5e-3
+    assert np.abs(f - z["sfm_f"]).max() > 1.0        # and they did change the answer
 
 
 def test_sba_motstr_levmar_shape():
