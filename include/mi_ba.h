@@ -41,7 +41,9 @@ typedef struct {
     /* model (sfm.c:598-617 arguments of run_sfm) */
     int est_focal;          /* 1: focal length is a parameter (cnp 7), 0: fixed (cnp 6) */
     int undistort;          /* 1: the radial coefficient k1 is a parameter (Bundler's projection distortion,
-                             * sfm.c:360-373, with k2 held at 0 = the one-coefficient model of PBA's CameraT) */
+                             * sfm.c:360-373, with k2 held at 0 = the one-coefficient model of PBA's CameraT);
+                             * 2: PBA's measurement distortion, residual x (1 + k |x|^2) - f q.xy / q.z
+                             * (SparseBundleCPU.cpp:1188-1193), k in the same parameter slot */
     int explicit_centers;   /* 1: camera params hold the centre C, 0: the translation t */
     int mcon;               /* first mcon cameras are held fixed (sba.h:95 'mcon') */
     double proj_sign;       /* -1 Bundler, +1 VisualSFM/PBA */

@@ -38,9 +38,12 @@ struct CameraT_ {
     { for (int j = 0; j < 3; ++j) t[j] = -(float_t)(m[j][0] * c[0] + m[j][1] * c[1] + m[j][2] * c[2]); }
     template <class F> void GetCameraCenter(F c[3]) const
     { for (int j = 0; j < 3; ++j) c[j] = -(F)(m[0][j] * t[0] + m[1][j] * t[1] + m[2][j] * t[2]); }
-    /* radial = r / f^2 stored as measurement distortion (DataInterface.h:81-86) */
-    template <class F> void SetNormalizedMeasurementDistortion(F r) { radial = (float_t)(r / (f * f)); distortion_type = -1; }
-    float_t GetNormalizedMeasurementDistortion() const { return distortion_type == -1 ? radial * (f * f) : 0; }
+    /* measurement distortion x (1 + r |x|^2) = projection; the reference's spelling is kept (DataInterface.h:81-86) */
+    template <class F> void SetMeasumentDistortion(F r) { radial = (float_t)r; distortion_type = -1; }
+    float_t GetMeasurementDistortion() const { return distortion_type == -1 ? radial : 0; }
+    /* the normalised form stored in NVM files: r * f^2 */
+    template <class F> void SetNormalizedMeasurementDistortion(F r) { SetMeasumentDistortion(r / (f * f)); }
+    float_t GetNormalizedMeasurementDistortion() const { return GetMeasurementDistortion() * (f * f); }
     template <class F> void SetProjectionDistortion(F r) { radial = (float_t)r; distortion_type = 1; }
     float_t GetProjectionDistortion() const { return distortion_type == 1 ? radial : 0; }
     /* Rodrigues vector -> R (DataInterface.h:93-107) */

@@ -22,14 +22,19 @@
 /* the slice of the reference's ConfigBA (ConfigBA.h:27-202) that callers of the plugin touch */
 class ConfigBA {
 public:
-    int __lm_max_iteration;         /* ConfigBA.h "-lmi": LM iteration cap (engine itmax)              */
+    int __lm_max_iteration;         /* ConfigBA.h "-lmi": LM iteration cap (engine itmax), default 50  */
+    float __lm_mse_threshold;       /* "-lme": stop ('M') once an accepted step's mean squared error is
+                                     * at or below this; 0.25 px^2 like the reference (ConfigBA.cpp:48)    */
+    int __bundle_time_budget;       /* "-budg" / SetNextTimeBudget: seconds, 0 = none ('T')            */
+    int __bundle_mode_next;         /* "-moti" 1 / "-stru" 2 (ConfigBA.cpp:528-533)                     */
     int __cg_max_iteration;         /* "-cgi": PCG iteration cap                                        */
     float __cg_norm_threshold;      /* "-cgn": PCG stop, sqrt(r'z/r0'z0)                                */
     bool __fixed_intrinsics;        /* SetFixedIntrinsics                                               */
-    int __use_radial_distortion;    /* EnableRadialDistortion: only 0 is supported this round           */
+    int __use_radial_distortion;    /* EnableRadialDistortion / "-pd" 1 / "-md", "-radi" -1              */
     int __verbose_level;
     int __selected_device;
-    char __bundle_return_code;      /* 'E' numeric error, 'S' small step, 'G' small gradient, 'M' itmax, 0 */
+    char __bundle_return_code;      /* 'E' numeric error, 'S' small step, 'G' small gradient, 'M' MSE threshold,
+                                     * 'T' time budget, 0 iteration cap (SparseBundleCPU.cpp:3851-3935)  */
     int __num_lm_success, __num_lm_iteration;
     float __initial_mse, __final_mse;
     ConfigBA();

@@ -35,7 +35,7 @@ bool Engine::hipok(hipError_t e, const char *what)
 Engine::Engine(const mi_ba_config &c) : cfg(c)
 {
     cnp = 6 + (cfg.est_focal ? 1 : 0) + (cfg.undistort ? 1 : 0);
-    if (cfg.undistort != 0 && cfg.undistort != 1) { err = "undistort must be 0 or 1 (Bundler's second coefficient k2 is not supported)"; return; }
+    if (cfg.undistort < 0 || cfg.undistort > 2) { err = "undistort must be 0, 1 (projection distortion k1) or 2 (measurement distortion)"; return; }
     if (cfg.mode < 0 || cfg.mode > 2) { err = "bad bundle mode"; return; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

@@ -51,8 +51,10 @@ __device__ __forceinline__ void ladd(double *p, double v)                       
 // differences, sba_levmar_wrap.c:163-259; the analytic form agrees to ~1e-6 relative, see
 // tests/test_oracle_golden.py::test_analytic_jacobian_close_to_fd)
 // ------------------------------------------------------------------------------------------
+// undistort == 2 is PBA's measurement distortion (ComputeProjection with radial == -1, SparseBundleCPU.cpp:1188-1193):
+// residual x (1 + k |x|^2) - f q.xy / q.z, written as x - xhat with xhat = f q.xy / q.z - k |x|^2 x
 __device__ __forceinline__ void project_obs(const ModelCfg &cfg, const double *__restrict__ cl, const double X[3],
-                                            double &u, double &v)
+                                            double2 xy, double &u, double &v)
 {
     double q[3];
     if (cfg.explicit_centers) {
@@ -63,10 +65,12 @@ __device__ __forceinline__ void project_obs(const ModelCfg &cfg, const double *_
 #pragma unroll
         for (int r = 0; r < 3; ++r) q[r] = cl[3 * r] * X[0] + cl[3 * r + 1] * X[1] + cl[3 * r + 2] * X[2] + cl[18 + r];
     }
+    const bool md = cfg.undistort == 2;
     double f = cl[21], k1 = cl[22], k2 = cl[23];
     double iz = 1.0 / q[2], mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
-    double g = cfg.proj_sign * f * (1.0 + k1 * r2 + k2 * r2 * r2);
+    double g = cfg.proj_sign * f * (md ? 1.0 : 1.0 + k1 * r2 + k2 * r2 * r2);
     u = g * mx; v = g * my;
+    if (md) { const double kk = k1 * (xy.x * xy.x + xy.y * xy.y); u -= kk * xy.x; v -= kk * xy.y; }
 }
 
 template <int CNP>
@@ -76,7 +80,9 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
     double R[9], q[3], qr[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = cl[i];
-    const double c0 = cl[18], c1 = cl[19], c2 = cl[20], f = cl[21], k1 = cl[22], k2 = cl[23];
+    const bool md = cfg.undistort == 2;
+    const double m2k = md ? (xy.x * xy.x + xy.y * xy.y) : 0.0;
+    const double c0 = cl[18], c1 = cl[19], c2 = cl[20], f = cl[21], k1 = md ? 0.0 : cl[22], k2 = cl[23];
     if (cfg.explicit_centers) {
         double d0 = X[0] - c0, d1 = X[1] - c1, d2 = X[2] - c2;
 #pragma unroll
@@ -91,6 +97,7 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
     const double D = 1.0 + k1 * r2 + k2 * r2 * r2, Dp = k1 + 2.0 * k2 * r2;
     e[0] = xy.x - s * f * mx * D;
     e[1] = xy.y - s * f * my * D;
+    if (md) { const double kk = cl[22] * m2k; e[0] = fma(kk, xy.x, e[0]); e[1] = fma(kk, xy.y, e[1]); }
     const double dmx[3] = { iz, 0.0, -mx * iz }, dmy[3] = { 0.0, iz, -my * iz };
     double Pq[2][3];
 #pragma unroll
@@ -138,7 +145,8 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
             int idx = 6;
             if (cfg.est_focal) { A[r][6] = s * mr * D / cfg.f_scale; idx = 7; }
             if (cfg.undistort) {
-                const double dk = s * f * mr * r2 / cfg.k_scale;
+                const double dk = md ? -m2k * (r == 0 ? xy.x : xy.y) / cfg.k_scale     // JacobianOne, SparseBundleCPU.cpp:1427-1432
+                                     : s * f * mr * r2 / cfg.k_scale;
                 if (idx == 6) A[r][6] = dk;
                 if constexpr (CNP >= 8) { if (idx == 7) A[r][7] = dk; }
             }
@@ -789,7 +797,7 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
         const double *row = scr + (size_t)(o - os) * kLongRow;
         const double2 xy = g.obs_xy[o];
         double u, v;
-        project_obs(g.cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, u, v);
+        project_obs(g.cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, xy, u, v);
         const double en0 = xy.x - u, en1 = xy.y - v, e0 = row[22], e1 = row[23];
         cn += en0 * en0 + en1 * en1;
         double pc = 0.0;
@@ -1236,8 +1244,10 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
                 for (int r = 0; r < 3; ++r) q[r] = cln[3 * r] * Xn[0] + cln[3 * r + 1] * Xn[1] + cln[3 * r + 2] * Xn[2] + cln[10 + r];
             }
             const double iz = 1.0 / q[2], mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
-            const double gg = cfg.proj_sign * cln[13] * (1.0 + cln[14] * r2 + cln[15] * r2 * r2);
-            const double en0 = xy.x - gg * mx, en1 = xy.y - gg * my;
+            const bool md = cfg.undistort == 2;
+            const double gg = cfg.proj_sign * cln[13] * (md ? 1.0 : 1.0 + cln[14] * r2 + cln[15] * r2 * r2);
+            double en0 = xy.x - gg * mx, en1 = xy.y - gg * my;
+            if (md) { const double kk = cln[14] * (xy.x * xy.x + xy.y * xy.y); en0 = fma(kk, xy.x, en0); en1 = fma(kk, xy.y, en1); }
             cn += en0 * en0 + en1 * en1;
             // QUIRK kept from sba_levmar.c:1554: signed comparison against eps5
             double pc = 0.0;

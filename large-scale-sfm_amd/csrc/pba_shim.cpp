@@ -2,6 +2,7 @@
 // Mirrors the call sequence of the reference plugin (pba.cpp:27-154 forwarding to
 // SparseBundleCPU.cpp:2541-2674); the numbers come from the HIP engine.
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,7 +13,7 @@
 #include "../../include/mi_pba.h"
 
 ConfigBA::ConfigBA()
-    : __lm_max_iteration(50), __cg_max_iteration(100), __cg_norm_threshold(1e-3f), __fixed_intrinsics(false),
+    : __lm_max_iteration(50), __lm_mse_threshold(0.25f), __bundle_time_budget(0), __bundle_mode_next(0), __cg_max_iteration(100), __cg_norm_threshold(1e-3f), __fixed_intrinsics(false),
       __use_radial_distortion(0), __verbose_level(0), __selected_device(0), __bundle_return_code(0), __num_lm_success(0),
       __num_lm_iteration(0), __initial_mse(0), __final_mse(0)
 {
@@ -27,6 +28,13 @@ void ConfigBA::ParseParam(int argc, char **argv)
         if (!a || a[0] != '-') continue;
         const char *v = (i + 1 < argc) ? argv[i + 1] : nullptr;
         if (!std::strcmp(a, "-lmi") && v) { __lm_max_iteration = std::atoi(v); ++i; }
+        else if (!std::strcmp(a, "-lme") && v) { if (std::atof(v) >= 0) __lm_mse_threshold = (float)std::atof(v); ++i; }
+        else if (!std::strcmp(a, "-budg") && v) { if (std::atoi(v) >= 0) __bundle_time_budget = std::atoi(v); ++i; }
+        else if (!std::strcmp(a, "-md") || !std::strcmp(a, "-radi")) __use_radial_distortion = -1;
+        else if (!std::strcmp(a, "-pd")) __use_radial_distortion = 1;
+        else if (!std::strcmp(a, "-vari")) __fixed_intrinsics = false;
+        else if (!std::strcmp(a, "-moti")) __bundle_mode_next = 1;
+        else if (!std::strcmp(a, "-stru")) __bundle_mode_next = 2;
         else if (!std::strcmp(a, "-cgi") && v) { __cg_max_iteration = std::atoi(v); ++i; }
         else if (!std::strcmp(a, "-cgn") && v) { __cg_norm_threshold = (float)std::atof(v); ++i; }
         else if (!std::strcmp(a, "-dev") && v) { __selected_device = std::atoi(v); ++i; }
@@ -43,7 +51,6 @@ struct ParallelBA::Impl {
     CameraT *cams = nullptr; size_t ncam = 0;
     Point3D *pts = nullptr; size_t npt = 0;
     const Point2D *meas = nullptr; const int *ptidx = nullptr, *camidx = nullptr; size_t nproj = 0;
-    BundleModeT mode = BUNDLE_FULL;
     std::atomic<float> mse{0.0f};
     std::atomic<int> iteration{0};
     std::atomic<bool> abort{false};
@@ -63,13 +70,13 @@ void ParallelBA::ParseParam(int narg, char **argv) { _optimizer->cfg.ParseParam(
 ConfigBA *ParallelBA::GetInternalConfig() { return &_optimizer->cfg; }
 void ParallelBA::SetFixedIntrinsics(bool fixed) { _optimizer->cfg.__fixed_intrinsics = fixed; }
 void ParallelBA::EnableRadialDistortion(DistortionT type) { _optimizer->cfg.__use_radial_distortion = (int)type; }
-void ParallelBA::SetNextTimeBudget(int) {}
+void ParallelBA::SetNextTimeBudget(int seconds) { _optimizer->cfg.__bundle_time_budget = seconds; }
 void ParallelBA::ReserveStorage(size_t, size_t, size_t) {}
 void ParallelBA::SetCameraData(size_t ncam, CameraT *cams) { _optimizer->ncam = ncam; _optimizer->cams = cams; }
 void ParallelBA::SetPointData(size_t npoint, Point3D *pts) { _optimizer->npt = npoint; _optimizer->pts = pts; }
 void ParallelBA::SetProjection(size_t nproj, const Point2D *imgpts, const int *point_idx, const int *cam_idx)
 { _optimizer->nproj = nproj; _optimizer->meas = imgpts; _optimizer->ptidx = point_idx; _optimizer->camidx = cam_idx; }
-void ParallelBA::SetNextBundleMode(BundleModeT mode) { _optimizer->mode = mode; }
+void ParallelBA::SetNextBundleMode(BundleModeT mode) { _optimizer->cfg.__bundle_mode_next = (int)mode; }
 float ParallelBA::GetMeanSquaredError() { return _optimizer->mse.load(); }
 void ParallelBA::AbortBundleAdjustment() { _optimizer->abort.store(true); }
 int ParallelBA::GetCurrentIteration() { return _optimizer->iteration.load(); }
@@ -83,22 +90,28 @@ int ParallelBA::RunBundleAdjustment()
     o.abort.store(false); o.iteration.store(0);
     // silent "nothing done" on missing input, SparseBundleCPU.cpp:2587-2590
     if (!o.valid_device || !o.cams || !o.pts || !o.meas || !o.ptidx || !o.camidx || !o.ncam || !o.npt || !o.nproj) return 0;
-    if (c.__use_radial_distortion < 0) { // PBA_MEASUREMENT_DISTORTION: a different residual (distorts the measurement)
-        std::fprintf(stderr, "[mi_pba] measurement distortion is not supported; use PBA_PROJECTION_DISTORTION\n");
-        c.__bundle_return_code = 'E';
-        return 0;
+    // EnableRadialDistortion: +1 distorts the projection, -1 the measurement (pba.h:73-84); with fixed intrinsics the
+    // coefficient is applied but not estimated (JacobianOne, SparseBundleCPU.cpp:1362-1363, 1427)
+    const int dist = c.__use_radial_distortion;
+    if (dist > 0 && c.__fixed_intrinsics) {
+        for (size_t j = 0; j < o.ncam; ++j)
+            if (o.cams[j].radial != 0) {
+                std::fprintf(stderr, "[mi_pba] fixed non-zero projection distortion is not supported\n");
+                c.__bundle_return_code = 'E';
+                return 0;
+            }
     }
     mi_ba_config cfg;
     mi_ba_default_config(&cfg);
     cfg.est_focal = c.__fixed_intrinsics ? 0 : 1;
-    cfg.undistort = (c.__use_radial_distortion > 0 && !c.__fixed_intrinsics) ? 1 : 0; // EnableRadialDistortion(PBA_PROJECTION_DISTORTION)
+    cfg.undistort = (dist != 0 && !c.__fixed_intrinsics) ? (dist > 0 ? 1 : 2) : 0;
     cfg.explicit_centers = 0;              // CameraT holds T = -R C (DataInterface.h:51)
     cfg.proj_sign = 1.0;                   // +z forward
     cfg.itmax = c.__lm_max_iteration;
     cfg.pcg_maxit = c.__cg_max_iteration; cfg.pcg_tol = c.__cg_norm_threshold;
     cfg.device = o.device; cfg.verbose = c.__verbose_level;
-    cfg.mode = o.mode == BUNDLE_ONLY_MOTION ? 1 : o.mode == BUNDLE_ONLY_STRUCTURE ? 2 : 0; // SetNextBundleMode, pba.h:103
-    o.mode = BUNDLE_FULL;                                                                 // "next" = one run
+    cfg.mode = c.__bundle_mode_next == 1 ? 1 : c.__bundle_mode_next == 2 ? 2 : 0;        // SetNextBundleMode, pba.h:103
+    c.__bundle_mode_next = 0;                                                             // ResetTemporarySetting, ConfigBA.cpp:149-157
     mi_ba_engine *e = mi_ba_create(&cfg);
     if (!e) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(nullptr)); c.__bundle_return_code = 'E'; return 0; }
     const int m = (int)o.ncam, n = (int)o.npt, cnp = mi_ba_cnp(e);
@@ -109,7 +122,7 @@ int ParallelBA::RunBundleAdjustment()
         const CameraT &cam = o.cams[j];
         for (int r = 0; r < 3; ++r) a0[(size_t)j * cnp + r] = cam.t[r];
         if (cfg.est_focal) a0[(size_t)j * cnp + 6] = (double)cam.f * cfg.f_scale;
-        if (cfg.undistort) a0[(size_t)j * cnp + 7] = (double)cam.GetProjectionDistortion() * cfg.k_scale;
+        if (cfg.undistort) a0[(size_t)j * cnp + 7] = (double)cam.radial * cfg.k_scale;   // PBA reads c[13] whatever its type tag
         for (int r = 0; r < 9; ++r) R0[(size_t)j * 9 + r] = cam.m[r / 3][r % 3];
         ff[j] = cam.f;
         fixed[j] = cam.constant_camera == 1.0f;
@@ -119,6 +132,13 @@ int ParallelBA::RunBundleAdjustment()
         std::fprintf(stderr, "[mi_pba] per-camera SetFixedIntrinsic() is ignored; use SetFixedIntrinsics(true) for all cameras\n");
     for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) xyz[(size_t)i * 3 + r] = o.pts[i].xyz[r];
     for (size_t k = 0; k < o.nproj; ++k) { xy[2 * k] = o.meas[k].x; xy[2 * k + 1] = o.meas[k].y; }
+    if (dist < 0 && c.__fixed_intrinsics) // a fixed measurement distortion only rescales the measurements
+        for (size_t k = 0; k < o.nproj; ++k) {
+            const int j = o.camidx[k];
+            if (j < 0 || j >= m) continue;      // reported by mi_ba_prepare
+            const double g = 1.0 + (double)o.cams[j].radial * (xy[2 * k] * xy[2 * k] + xy[2 * k + 1] * xy[2 * k + 1]);
+            xy[2 * k] *= g; xy[2 * k + 1] *= g;
+        }
     int ret = 0;
     double info[MI_BA_INFOSZ] = { 0 };
     if (mi_ba_set_cameras(e, m, a0.data(), R0.data(), ff.data()) || mi_ba_set_fixed_cameras(e, fixed.data()) ||
@@ -133,6 +153,8 @@ int ParallelBA::RunBundleAdjustment()
     c.__initial_mse = (float)(info[0] / (double)o.nproj);
     o.mse.store(c.__initial_mse);
     int st = 0;
+    char early = 0;
+    const auto t_start = std::chrono::steady_clock::now();
     while (!o.abort.load()) {
         st = mi_ba_step(e);
         if (st == MI_BA_ERROR) break;
@@ -140,13 +162,21 @@ int ParallelBA::RunBundleAdjustment()
         o.mse.store((float)(info[1] / (double)o.nproj));
         o.iteration.store((int)info[5]);
         c.__num_lm_iteration = (int)info[9];
-        if (st == 1) c.__num_lm_success++;
+        if (st == 1) {
+            c.__num_lm_success++;
+            // the reference's tests after every successful step (SparseBundleCPU.cpp:3919-3935)
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+            if (c.__bundle_time_budget > 0 && secs > c.__bundle_time_budget) { early = 'T'; break; }
+            if (o.mse.load() <= c.__lm_mse_threshold) { early = 'M'; break; }
+        }
         if (st == 2) break;
     }
+    c.__bundle_time_budget = 0;          // ResetTemporarySetting, ConfigBA.cpp:149-157
     if (st == MI_BA_ERROR) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(e)); c.__bundle_return_code = 'E'; }
+    else if (early) c.__bundle_return_code = early;
     else {
         const int stop = (int)info[6];   // sba stop reasons -> PBA return codes (SparseBundleCPU.cpp:3851-3935)
-        c.__bundle_return_code = stop == 7 ? 'E' : stop == 2 ? 'S' : stop == 1 ? 'G' : stop == 3 ? 'M' : 0;
+        c.__bundle_return_code = stop == 7 ? 'E' : (stop == 2 || stop == 8) ? 'S' : stop == 1 ? 'G' : 0;
     }
     // write the result back into the caller's arrays (TransferDataToHost, SparseBundleCPU.cpp:2660-2674)
     std::vector<double> a((size_t)m * cnp), R((size_t)m * 9);
@@ -156,7 +186,8 @@ int ParallelBA::RunBundleAdjustment()
             for (int r = 0; r < 3; ++r) cam.t[r] = (float)a[(size_t)j * cnp + r];
             for (int r = 0; r < 9; ++r) cam.m[r / 3][r % 3] = (float)R[(size_t)j * 9 + r];
             if (cfg.est_focal) cam.f = (float)(a[(size_t)j * cnp + 6] / cfg.f_scale);
-            if (cfg.undistort) cam.SetProjectionDistortion(a[(size_t)j * cnp + 7] / cfg.k_scale);
+            if (cfg.undistort == 1) cam.SetProjectionDistortion(a[(size_t)j * cnp + 7] / cfg.k_scale);
+            if (cfg.undistort == 2) cam.SetMeasumentDistortion(a[(size_t)j * cnp + 7] / cfg.k_scale);
         }
         for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) o.pts[i].xyz[r] = (float)xyz[(size_t)i * 3 + r];
         ret = c.__num_lm_success;

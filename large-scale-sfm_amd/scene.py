@@ -95,7 +95,9 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
                seed: int | None = None, proj_sign: float = -1.0, explicit_centers: int = 1,
                est_focal: int = 1, strides=(1, 2, 3), noise_px: float = 0.25,
                cam_noise: float = 0.005, f_noise: float = 0.01, pt_noise: float = 0.01,
-               undistort: int = 0, nk: int = 2, k_true=(-0.25, 0.12)) -> Scene:
+               undistort: int = 0, nk: int = 2, k_true=(-0.25, 0.12), md_k: float = -1.25e-7) -> Scene:
+    """undistort 1: Bundler's projection distortion with nk coefficients k_true; undistort 2: PBA's measurement
+    distortion x (1 + md_k |x|^2) = projection (SparseBundleCPU.cpp:1188-1193), one coefficient"""
     if name in CONFIGS:
         cm, cn, cd = CONFIGS[name]
         idx = list(CONFIGS).index(name)
@@ -137,8 +139,15 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
     Xo = X_true[obs_pt]
     t_true = -np.einsum("mij,mj->mi", R_true, C)
     c_true = C if explicit_centers else t_true
-    k1t, k2t = (k_true[0], k_true[1] if nk == 2 else 0.0) if undistort else (0.0, 0.0)
+    if undistort == 2:
+        nk = 1
+    k1t, k2t = (k_true[0], k_true[1] if nk == 2 else 0.0) if undistort == 1 else (0.0, 0.0)
     x = project(R_true[obs_cam], c_true[obs_cam], f_true[obs_cam], Xo, proj_sign, explicit_centers, k1t, k2t)
+    if undistort == 2:                             # invert x (1 + k |x|^2) = u by fixed-point iteration
+        u = x
+        for _ in range(50):
+            x = u / (1 + md_k * (x ** 2).sum(1))[:, None]
+        k1t = md_k
     x = x + rng.uniform(-noise_px, noise_px, x.shape)
 
     # --- perturbed initial guess

@@ -61,8 +61,10 @@ static inline double cam_focal(const ora_problem *pb, int j, const double *aj)
     return pb->est_focal ? aj[6] / pb->f_scale : pb->f_fixed[j];
 }
 
-/* sfm.c:509-558 -> sfm.c:303-374 */
-void ora_project(const ora_problem *pb, int j, const double *aj, const double *bi, double *xij)
+/* sfm.c:509-558 -> sfm.c:303-374.  o = observation index, only needed by the measurement-distortion model
+ * (undistort == 2, PBA's ComputeProjection with radial == -1, SparseBundleCPU.cpp:1188-1193): its residual is
+ * x (1 + k |x|^2) - f q.xy / q.z, restated here as x - xhat with xhat = f q.xy / q.z - k |x|^2 x. */
+static void project_obs(const ora_problem *pb, int j, int o, const double *aj, const double *bi, double *xij)
 {
     double R[9], q[3];
     const double *dt = aj, *w = aj + 3;
@@ -79,13 +81,24 @@ void ora_project(const ora_problem *pb, int j, const double *aj, const double *b
     }
     double p0 = pb->proj_sign * q[0] * f / q[2];
     double p1 = pb->proj_sign * q[1] * f / q[2];
-    if (pb->undistort) {
+    if (pb->undistort == 2) {
+        if (o >= 0) {
+            const double *xm = pb->x + 2 * (size_t)o;
+            double kk = k[0] / pb->k_scale * (xm[0] * xm[0] + xm[1] * xm[1]);
+            p0 -= kk * xm[0]; p1 -= kk * xm[1];
+        }
+    } else if (pb->undistort) {
         double k1 = k[0] / pb->k_scale, k2 = pb->nk == 1 ? 0.0 : k[1] / pb->k_scale;
         double rsq = (p0 * p0 + p1 * p1) / (f * f);
         double factor = 1.0 + k1 * rsq + k2 * rsq * rsq;
         p0 *= factor; p1 *= factor;
     }
     xij[0] = p0; xij[1] = p1;
+}
+
+void ora_project(const ora_problem *pb, int j, const double *aj, const double *bi, double *xij)
+{
+    project_obs(pb, j, -1, aj, bi, xij);
 }
 
 /* left Jacobian of SO(3): exp((w+d)^) ~= exp((Jl d)^) exp(w^) */
@@ -103,7 +116,7 @@ static void so3_left_jacobian(const double *w, double *Jl)
 }
 
 /* analytic A (2 x cnp) and B (2 x 3) of the model above; also returns the projection */
-static void jac_analytic(const ora_problem *pb, int j, const double *aj, const double *bi,
+static void jac_analytic(const ora_problem *pb, int j, int o, const double *aj, const double *bi,
                          double *A, double *B, double *xij)
 {
     const int cnp = pb->cnp;
@@ -112,7 +125,8 @@ static void jac_analytic(const ora_problem *pb, int j, const double *aj, const d
     const double *k = pb->est_focal ? aj + 7 : aj + 6;
     double f = cam_focal(pb, j, aj);
     double k1 = 0.0, k2 = 0.0;
-    if (pb->undistort) { k1 = k[0] / pb->k_scale; k2 = pb->nk == 1 ? 0.0 : k[1] / pb->k_scale; }
+    const int md = pb->undistort == 2; /* measurement distortion: the projection itself is undistorted */
+    if (pb->undistort && !md) { k1 = k[0] / pb->k_scale; k2 = pb->nk == 1 ? 0.0 : k[1] / pb->k_scale; }
     ora_rot_update(pb->R0 + 9 * j, w, R);
     so3_left_jacobian(w, Jl);
     double qr[3]; /* rotated part, the vector the rotation acts on */
@@ -136,6 +150,9 @@ static void jac_analytic(const ora_problem *pb, int j, const double *aj, const d
         Pq[3 + t] = s * f * (D * dmy[t] + my * Dp * dr2);
     }
     if (xij) { xij[0] = s * f * mx * D; xij[1] = s * f * my * D; }
+    const double *xm = pb->x + 2 * (size_t)(o < 0 ? 0 : o);
+    const double m2 = md ? xm[0] * xm[0] + xm[1] * xm[1] : 0.0;
+    if (xij && md) { xij[0] -= k[0] / pb->k_scale * m2 * xm[0]; xij[1] -= k[0] / pb->k_scale * m2 * xm[1]; }
     /* B = Pq R */
     for (int r = 0; r < 2; ++r)
         for (int t = 0; t < 3; ++t)
@@ -154,40 +171,13 @@ static void jac_analytic(const ora_problem *pb, int j, const double *aj, const d
         double mr = (r == 0) ? mx : my;
         int cc = 6;
         if (pb->est_focal) Ar[cc++] = s * mr * D / pb->f_scale;
-        if (pb->undistort) {
+        if (md) Ar[cc++] = -m2 * xm[r] / pb->k_scale; /* JacobianOne, SparseBundleCPU.cpp:1427-1432 */
+        else if (pb->undistort) {
             Ar[cc++] = s * f * mr * r2 / pb->k_scale;
             if (pb->nk != 1) Ar[cc++] = s * f * mr * r2 * r2 / pb->k_scale;
         }
     }
 }
-
-/* ------------------------------------------------------------------ index helpers */
-
-typedef struct {
-    int nobs;
-    int *obs_pt;    /* nobs: point of each observation */
-    int *cam_ptr;   /* m+1 */
-    int *cam_obs;   /* nobs: observation ids grouped by camera, points ascending */
-} ora_index;
-
-static void index_build(const ora_problem *pb, ora_index *ix)
-{
-    int n = pb->n, m = pb->m, nobs = pb->pt_ptr[n];
-    ix->nobs = nobs;
-    ix->obs_pt = (int *)xmalloc(sizeof(int) * nobs);
-    ix->cam_ptr = (int *)xmalloc(sizeof(int) * (m + 1));
-    ix->cam_obs = (int *)xmalloc(sizeof(int) * nobs);
-    memset(ix->cam_ptr, 0, sizeof(int) * (m + 1));
-    for (int i = 0; i < n; ++i)
-        for (int o = pb->pt_ptr[i]; o < pb->pt_ptr[i + 1]; ++o) { ix->obs_pt[o] = i; ix->cam_ptr[pb->obs_cam[o] + 1]++; }
-    for (int j = 0; j < m; ++j) ix->cam_ptr[j + 1] += ix->cam_ptr[j];
-    int *fill = (int *)xmalloc(sizeof(int) * m);
-    memcpy(fill, ix->cam_ptr, sizeof(int) * m);
-    for (int o = 0; o < nobs; ++o) ix->cam_obs[fill[pb->obs_cam[o]]++] = o;
-    free(fill);
-}
-
-static void index_free(ora_index *ix) { free(ix->obs_pt); free(ix->cam_ptr); free(ix->cam_obs); }
 
 /* ------------------------------------------------------------------ residuals & Jacobian */
 
@@ -199,7 +189,7 @@ static void predict(const ora_problem *pb, const double *p, double *hx)
     for (int i = 0; i < pb->n; ++i)
         for (int o = pb->pt_ptr[i]; o < pb->pt_ptr[i + 1]; ++o) {
             int j = pb->obs_cam[o];
-            ora_project(pb, j, pa + (size_t)j * cnp, pbb + 3 * (size_t)i, hx + 2 * (size_t)o);
+            project_obs(pb, j, o, pa + (size_t)j * cnp, pbb + 3 * (size_t)i, hx + 2 * (size_t)o);
         }
 }
 
@@ -239,7 +229,7 @@ static void jacobian(const ora_problem *pb, int fd, double *p, double *jac)
             for (int o = pb->pt_ptr[i]; o < pb->pt_ptr[i + 1]; ++o) {
                 int j = pb->obs_cam[o];
                 double *AB = jac + (size_t)o * ABsz;
-                jac_analytic(pb, j, pa + (size_t)j * cnp, pbb + 3 * (size_t)i, AB, AB + 2 * cnp, NULL);
+                jac_analytic(pb, j, o, pa + (size_t)j * cnp, pbb + 3 * (size_t)i, AB, AB + 2 * cnp, NULL);
             }
         return;
     }
@@ -252,14 +242,14 @@ static void jacobian(const ora_problem *pb, int fd, double *p, double *jac)
             int j = pb->obs_cam[o];
             double *aj = pa + (size_t)j * cnp;
             double *A = jac + (size_t)o * ABsz, *B = A + 2 * cnp;
-            ora_project(pb, j, aj, bi, hx);
+            project_obs(pb, j, o, aj, bi, hx);
             for (int jj = 0; jj < cnp; ++jj) {
                 double d = ORA_DELTA_SCALE * aj[jj];
                 d = fabs(d);
                 if (d < ORA_MIN_DELTA) d = ORA_MIN_DELTA;
                 double d1 = 1.0 / d, tmp = aj[jj];
                 aj[jj] += d;
-                ora_project(pb, j, aj, bi, hxx);
+                project_obs(pb, j, o, aj, bi, hxx);
                 aj[jj] = tmp;
                 A[jj] = (hxx[0] - hx[0]) * d1;
                 A[cnp + jj] = (hxx[1] - hx[1]) * d1;
@@ -270,7 +260,7 @@ static void jacobian(const ora_problem *pb, int fd, double *p, double *jac)
                 if (d < ORA_MIN_DELTA) d = ORA_MIN_DELTA;
                 double d1 = 1.0 / d, tmp = bi[jj];
                 bi[jj] += d;
-                ora_project(pb, j, aj, bi, hxx);
+                project_obs(pb, j, o, aj, bi, hxx);
                 bi[jj] = tmp;
                 B[jj] = (hxx[0] - hx[0]) * d1;
                 B[3 + jj] = (hxx[1] - hx[1]) * d1;

@@ -26,9 +26,9 @@ int main(int argc, char **argv)
     for (int64_t k = 0; k < cnt[2]; ++k) meas[k].SetPoint2D(xy[2 * k], xy[2 * k + 1]);
 
     ParallelBA pba(ParallelBA::PBA_CUDA_DEVICE_DEFAULT);        // on the stack, like driver.cpp:130
-    char a0[] = "-lmi", a1[] = "150";
-    char *args[] = { a0, a1 };
-    pba.ParseParam(2, args);
+    char a0[] = "-lmi", a1[] = "150", a2[] = "-lme", a3[] = "0";   // run to convergence, not to the default 0.25 px^2
+    char *args[] = { a0, a1, a2, a3 };
+    pba.ParseParam(4, args);
     pba.SetCameraData(cams.size(), &cams[0]);
     pba.SetPointData(pts.size(), &pts[0]);
     pba.SetProjection(meas.size(), &meas[0], &ptidx[0], &camidx[0]);

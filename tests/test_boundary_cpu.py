@@ -36,6 +36,24 @@ def test_parallelba_has_the_reference_cxx_abi():
     assert want <= have, sorted(want - have)
 
 
+def test_the_references_own_parallelba_runs_behind_our_header(tmp_path):
+    """tests/native/pba_plain_client.cpp compiled against include/mi_pba.h and linked to the REFERENCE's PBA (CPU
+    build, oracle/_ref/libpba_ref.so): the header is binary compatible (vtable order, CameraT / Point3D / Point2D
+    layouts), and the committed golden vectors are what that library produces"""
+    from helpers import build_pba_client, pba_case, run_pba_client, write_pba_problem
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpba_ref.so")):
+        pytest.skip("oracle/_ref/libpba_ref.so not built (needs /root/reference)")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_pba.npz"))
+    exe = build_pba_client(tmp_path, "ref")
+    for name in ("meas_dist", "motion_only"):
+        sc, kw = pba_case(name)
+        prob = str(tmp_path / (name + ".txt"))
+        write_pba_problem(prob, sc, **kw)
+        r = run_pba_client(exe, prob, tmp_path, -3, sc.m, sc.n)
+        assert r["iters"] == int(z[name + "_iters"]) and abs(r["mse"] - float(z[name + "_mse"])) < 1e-6 * r["mse"]
+        assert np.abs(r["f"] - z[name + "_f"]).max() < 1e-3 and np.abs(r["pts"] - z[name + "_pts"]).max() < 1e-6
+
+
 def test_no_gpu_is_a_loud_error():
     import torch
     if torch.cuda.is_available():

@@ -158,6 +158,49 @@ def test_parallelba_plugin_client(tmp_path, oracle):
     assert np.allclose(vals[:2, 1:4], sc.p0[:2 * sc.cnp].reshape(2, sc.cnp)[:, :3], atol=1e-5)   # constant cameras untouched
 
 
+@pytest.fixture(scope="module")
+def pba_mi_client(tmp_path_factory):
+    from helpers import build_pba_client
+    wd = tmp_path_factory.mktemp("pba_mi")
+    return build_pba_client(wd, "mi"), wd
+
+
+@pytest.mark.parametrize("name", __import__("helpers").PBA_CASES)
+def test_parallelba_against_the_references_own_parallelba(name, pba_mi_client):
+    """the same client binary source, linked to libmi_ba.so here and to the reference's PBA (CPU double) when
+    tests/golden/ref_pba.npz was made: final error and parameters of both solvers on the same input"""
+    from helpers import pba_case, run_pba_client, write_pba_problem
+    exe, wd = pba_mi_client
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_pba.npz"))
+    sc, kw = pba_case(name)
+    assert abs(np.abs(sc.x).sum() - float(z[name + "_xsum"])) < 1e-6 * float(z[name + "_xsum"])    # same input as the golden run
+    prob = os.path.join(str(wd), name + ".txt")
+    write_pba_problem(prob, sc, **kw)
+    r = run_pba_client(exe, prob, wd, -1, sc.m, sc.n)
+    ref = {k: z[name + "_" + k] for k in ("iters", "mse", "f", "t", "R", "radial", "pts")}
+    print(name, "iters", r["iters"], int(ref["iters"]), "mse", r["mse"], float(ref["mse"]),
+          "df", np.abs(r["f"] - ref["f"]).max(), "dt", np.abs(r["t"] - ref["t"]).max(), "dR", np.abs(r["R"] - ref["R"]).max(),
+          "dX", np.abs(r["pts"] - ref["pts"]).max(), "drad", np.abs(r["radial"] - ref["radial"]).max())
+    if name == "early_stop":
+        # "-lme 0.25": both stop at the first successful step whose MSE is at or below the threshold
+        assert r["iters"] <= 3 and r["mse"] <= 0.25
+        return
+    rm, rw = np.sqrt(r["mse"]), np.sqrt(float(ref["mse"]))
+    assert abs(rm - rw) <= 1e-4 * rw                   # measured: 7 digits of the MSE agree
+    nc = kw["nconst"]
+    if nc:                                             # constant cameras are untouched
+        assert np.array_equal(r["f"][:nc], ref["f"][:nc]) and np.array_equal(r["t"][:nc], ref["t"][:nc])
+    if kw.get("mode", 0) != 2:
+        assert np.abs(r["R"] - ref["R"]).max() < 1e-4 and np.abs(r["t"] - ref["t"]).max() < 5e-3
+        if not kw.get("fixed_intr"):
+            assert np.abs(r["f"] - ref["f"]).max() < 0.5
+    if kw.get("mode", 0) != 1:
+        assert np.abs(r["pts"] - ref["pts"]).max() < 5e-4
+    if kw.get("distortion") and not kw.get("fixed_intr"):
+        scale = np.abs(ref["radial"]).max()
+        assert np.abs(r["radial"] - ref["radial"])[nc:].max() < 0.03 * scale
+
+
 def test_config_c4_ladybug_like_through_the_bal_loader(tmp_path, oracle):
     """BASELINE config C4: a BAL-style problem (1.7k cameras along a path, heavy-tailed track lengths incl.
     tracks longer than a wavefront, observations not grouped by point in the file) loaded through the

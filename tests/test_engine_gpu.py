@@ -214,6 +214,29 @@ def test_radial_distortion_k1(oracle, est_focal):
     assert abs(eng.debug_linearize(mu)["cost"] - oracle.cost(sc, eng.packed_params())) < 1e-9 * info[1]
 
 
+@pytest.mark.parametrize("d", [5, 13])
+def test_measurement_distortion(oracle, d):
+    """undistort 2 = PBA's measurement distortion x (1 + k |x|^2) = projection (SparseBundleCPU.cpp:1188-1193, 1427-1432);
+    LDS tiles (d 5) and direct tiles (d 13); the model is pinned to the reference's own PBA by
+    test_boundary_gpu.py::test_parallelba_against_the_references_own_parallelba[meas_dist]"""
+    sc = pkg("scene").make_scene("x", m=40, n=1200, d=d, seed=8, undistort=2, proj_sign=1.0, explicit_centers=0)
+    assert sc.cnp == 8 and sc.undistort == 2
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, mcon=2)
+    lin = oracle.linearize(sc, fd_jacobian=0, mcon=2)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    g = eng.debug_linearize(mu)
+    assert abs(g["cost"] - lin["cost"]) <= 1e-11 * lin["cost"]
+    assert rel(g["ea"], lin["ea"]) < 1e-10 and rel(g["eb"], lin["eb"]) < 1e-10
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0, mcon=2)
+    assert ret == o["ret"] and info[6] == o["info"][6]
+    assert abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
+    assert np.abs(eng.packed_params() - o["p"]).max() < 1e-6
+    a, _ = eng.params()
+    assert abs(np.median(a[2:, 7]) / 5.0 + 1.25e-7) < 0.6e-7      # the generator's coefficient is recovered (150 obs / camera)
+    assert abs(oracle.cost(sc, eng.packed_params()) - info[1]) < 1e-9 * info[1]
+
+
 def test_long_tracks_use_direct_tiles(oracle):
     """points with > 10 views bypass the LDS tile and add straight into S"""
     sc = pkg("scene").make_scene("x", m=40, n=600, d=13, seed=5, strides=(1, 2, 3))
@@ -341,8 +364,8 @@ def test_error_paths():
     eng.set_problem(a0, sc.R0, sc.f_fixed, xyz, sc.x, pt, sc.obs_cam)
     with pytest.raises(RuntimeError, match="sorted by point"):
         eng.prepare()
-    with pytest.raises(RuntimeError, match="k2 is not supported"):
-        capi.Engine(capi.default_config(undistort=2))
+    with pytest.raises(RuntimeError, match="undistort must be"):
+        capi.Engine(capi.default_config(undistort=3))
 
 
 @pytest.mark.parametrize("name", ["C2", "C3"])
