@@ -96,6 +96,13 @@ int mi_ba_set_observations(mi_ba_engine *e, int64_t nobs, const double *xy /* no
  * entry free; NULL clears.  Call after set_cameras / set_points and before prepare. */
 int mi_ba_set_camera_constraints(mi_ba_engine *e, const double *weights /* m*cnp */, const double *values /* m*cnp */);
 int mi_ba_set_point_constraints(mi_ba_engine *e, const double *weight /* n */, const double *values /* n*3 */);
+/* quadratic couplings between the parameters of two cameras: penalty  sum_q,r w_qr (a_{A(q),r} - a_{B(q),r})^2.
+ * PBA's shared-intrinsics "Q" constraints (ParallelBA::SetFocalMask, pba.h:124; SparseBundleCPU.cpp:1262-1329,
+ * 2781-2892) are links on the focal-length (and distortion) entries around a ring of cameras.  The couplings
+ * enter U (diagonal and the (A,B) off-diagonal block, which the plan adds to the pattern of S), the gradient and
+ * the cost exactly; weights are in the units of the internal parameters a_j.  nlink = 0 clears.  Call after
+ * set_cameras and before prepare. */
+int mi_ba_set_camera_links(mi_ba_engine *e, int nlink, const int *cam_a, const int *cam_b, const double *weights /* nlink*cnp */);
 /* builds the shard plan, uploads everything to HBM */
 int mi_ba_prepare(mi_ba_engine *e);
 

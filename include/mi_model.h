@@ -46,6 +46,11 @@ int mi_model_counts(const mi_model *mdl, int64_t counts[3]);
 int mi_model_get(const mi_model *mdl, double *f, double *R, double *t, double *d, double *xyz, int *rgb,
                  double *xy, int *pt_idx, int *cam_idx, int64_t *feat_id);
 
+/* shared intrinsics for the next mi_model_optimize: mask[j] = first camera of j's group (mask of that camera = itself),
+ * -1 = on its own; soft equality of the focal lengths of a group exactly as ParallelBA::SetFocalMask (pba.h:124;
+ * the BAL / Ladybug configuration C4).  NULL or weight <= 0 clears. */
+int mi_model_set_focal_mask(mi_model *mdl, const int *mask /* ncam */, double weight);
+
 /* bundle adjust in place.  cfg: only itmax, opts, pcg_*, est_focal, mcon, device, verbose are read (the
  * camera convention of the file fixes the rest).  Returns LM iterations or MI_BA_ERROR. */
 int mi_model_optimize(mi_model *mdl, const mi_ba_config *cfg, double info[MI_BA_INFOSZ]);

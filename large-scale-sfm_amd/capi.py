@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
             "mi_ba_destroy": [vp], "mi_ba_cnp": [vp], "mi_ba_prepare": [vp], "mi_ba_begin": [vp], "mi_ba_step": [vp],
             "mi_ba_reset_timing": [vp], "mi_ba_set_cameras": [vp, i32, dp, dp, dp], "mi_ba_set_points": [vp, i32, dp],
             "mi_ba_set_observations": [vp, i64, dp, ip, ip], "mi_ba_set_camera_constraints": [vp, dp, dp],
+            "mi_ba_set_camera_links": [vp, C.c_int, ip, ip, dp],
             "mi_ba_set_point_constraints": [vp, dp, dp], "mi_ba_set_fixed_cameras": [vp, C.c_void_p], "mi_ba_run": [vp, dp], "mi_ba_get_info": [vp, dp],
             "mi_ba_get_trace": [vp, dp, i32], "mi_ba_get_params": [vp, dp, dp], "mi_ba_set_params": [vp, dp, dp],
             "mi_ba_get_rotations": [vp, dp], "mi_ba_debug_linearize": [vp, dbl, dp, dp, dp, dp, dp, dp, dp],
@@ -135,6 +136,13 @@ class Engine:
                          np.ascontiguousarray(p0[m * cnp:]).reshape(n, 3), sc.x, sc.obs_pt(), sc.obs_cam)
         cons = getattr(sc, "constraints", None) or {}
         self.set_constraints(cons.get("cam_cw"), cons.get("cam_cv"), cons.get("pt_cw"), cons.get("pt_cv"))
+
+    def set_camera_links(self, cam_a, cam_b, weights):
+        """quadratic couplings w[q, r] (a[cam_a[q], r] - a[cam_b[q], r])^2 (PBA's shared-intrinsics constraints)"""
+        a = np.ascontiguousarray(cam_a, np.int32); b = np.ascontiguousarray(cam_b, np.int32)
+        w = np.ascontiguousarray(weights, np.float64)
+        self._keep_links = (a, b, w)
+        self._chk(self.L.mi_ba_set_camera_links(self.h, len(a), a.ctypes.data_as(_ip), b.ctypes.data_as(_ip), _d(w)), "set_camera_links")
 
     def set_constraints(self, cam_w=None, cam_v=None, pt_w=None, pt_v=None):
         c = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)

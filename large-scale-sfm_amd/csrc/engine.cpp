@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 namespace miba {
 
@@ -107,6 +108,24 @@ int Engine::set_camera_constraints(const double *weights, const double *values)
     return 0;
 }
 
+int Engine::set_camera_links(int nlink, const int *cam_a, const int *cam_b, const double *weights)
+{
+    if (!m_) { err = "set_camera_links: set_cameras first"; return MI_BA_ERROR; }
+    h_link_cam_.clear(); h_link_w_.clear();
+    prepared_ = begun_ = false;
+    if (nlink <= 0) return 0;
+    if (!cam_a || !cam_b || !weights) { err = "set_camera_links: null argument"; return MI_BA_ERROR; }
+    for (int q = 0; q < nlink; ++q) {
+        if (cam_a[q] < 0 || cam_a[q] >= m_ || cam_b[q] < 0 || cam_b[q] >= m_ || cam_a[q] == cam_b[q]) {
+            h_link_cam_.clear(); h_link_w_.clear();
+            err = "set_camera_links: bad camera index"; return MI_BA_ERROR;
+        }
+        h_link_cam_.push_back(cam_a[q]); h_link_cam_.push_back(cam_b[q]);
+    }
+    h_link_w_.assign(weights, weights + (size_t)nlink * cnp);
+    return 0;
+}
+
 int Engine::set_point_constraints(const double *weight, const double *values)
 {
     if (!n_) { err = "set_point_constraints: set_points first"; return MI_BA_ERROR; }
@@ -172,7 +191,9 @@ int Engine::prepare()
         err = "cannot solve a problem with fewer measurements than unknowns";
         return MI_BA_ERROR;
     }
-    std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches);
+    if (!h_link_cam_.empty() && cfg.mode == 2) { err = "prepare: camera links make no sense in a structure-only bundle"; return MI_BA_ERROR; }
+    std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches,
+                                  h_link_cam_.empty() ? nullptr : &h_link_cam_);
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
     const Plan &pl = plan_;
 #define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
@@ -215,6 +236,41 @@ int Engine::prepare()
             UP(d_pt_cw_, pw); UP(d_pt_cv_, pv);
         }
     }
+    links_ = CamLinks{};
+    if (!h_link_cam_.empty()) { // camera links: CSR over cameras (each link at both ends), summed weight per linked pair
+        const int nl = (int)h_link_cam_.size() / 2;
+        std::vector<int> row(m_ + 1, 0), other(2 * (size_t)nl), fill;
+        std::vector<double> w(2 * (size_t)nl * kCP, 0.0), pw;
+        for (int q = 0; q < 2 * nl; ++q) row[h_link_cam_[q] + 1]++;
+        for (int j = 0; j < m_; ++j) row[j + 1] += row[j];
+        fill.assign(row.begin(), row.end() - 1);
+        std::unordered_map<uint64_t, int> pairs;
+        for (int q = 0; q < nl; ++q) {
+            const int a = h_link_cam_[2 * q], b = h_link_cam_[2 * q + 1];
+            const int ea = fill[a]++, eb = fill[b]++;
+            other[ea] = b; other[eb] = a;
+            const uint64_t key = ((uint64_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b);
+            auto it = pairs.find(key);
+            if (it == pairs.end()) { it = pairs.emplace(key, (int)pairs.size()).first; pw.resize(pairs.size() * kCP, 0.0); }
+            for (int r = 0; r < cnp; ++r) {
+                const double wr = h_link_w_[(size_t)q * cnp + r];
+                if (!(wr >= 0.0)) { err = "prepare: camera link weights must be >= 0"; return MI_BA_ERROR; }
+                w[(size_t)ea * kCP + r] = wr; w[(size_t)eb * kCP + r] = wr;
+                pw[(size_t)it->second * kCP + r] += wr;
+            }
+        }
+        std::vector<int> blk(pl.nb_full(), -1);
+        for (int j = 0; j < m_; ++j)
+            for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) {
+                const int k = pl.bsr_col[q];
+                if (k == j) continue;
+                auto it = pairs.find(((uint64_t)std::min(j, k) << 32) | (uint32_t)std::max(j, k));
+                if (it != pairs.end()) blk[q] = it->second;
+            }
+        UP(d_link_row_, row); UP(d_link_other_, other); UP(d_link_w_, w); UP(d_link_blk_, blk); UP(d_link_pair_w_, pw);
+        links_.row = d_link_row_.p; links_.other = d_link_other_.p; links_.w = d_link_w_.p;
+        links_.blk_pair = d_link_blk_.p; links_.pair_w = d_link_pair_w_.p;
+    }
     {   // long tracks: scratch rows and the upper pattern for the block lookup
         std::vector<int> scr(pl.long_pts.size() + 1, 0);
         long_max_pairs_ = 0;
@@ -250,7 +306,8 @@ int Engine::prepare()
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)m_ * kCP * 7), "alloc pcg") ||
         !hipok(d_rzpq_.alloc((size_t)(cfg.pcg_maxit + 4) + 2 * (size_t)((m_ + 7) / 8) + (size_t)m_), "alloc rz/pq") ||
         !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGrid) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
-        !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage"))
+        !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage") ||
+        !hipok(d_cam_part_.alloc((size_t)((m_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
@@ -353,7 +410,8 @@ bool Engine::linear_phase(double mu, bool want_diag)
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
-                    S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, d_E_.p, scal_());
+                    S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
+                    d_cam_part_.p, d_stage_.p, scal_());
     launch_block_inv(st_, m_, d_bsr_diag_.p, d_S_full_.p, d_Minv_.p, scal_());
     return hipok(hipGetLastError(), "launch (linear phase)");
 }
@@ -389,8 +447,8 @@ bool Engine::solve_phase(double mu, double *dB_dev)
         if (h_scal_[SC_PCG_STATUS] != 0.0 || h_scal_[SC_PCG_DONE] != 0.0) break;
     }
     (void)hipEventRecord(ev_[3], st_);
-    launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, d_cam_a_[cur_ ^ 1].p,
-                      d_cam_lin_[cur_ ^ 1].p, scal_());
+    launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, links_,
+                      d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part_.p, d_stage_.p, scal_());
     BacksubArgs b{};
     b.batch_obs = d_batch_obs_.p; b.batch_pt = d_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
@@ -419,7 +477,7 @@ int Engine::begin()
     // probe pass: cost at p0 and the largest diagonal entry of U, V -> mu0 = tau * max (sba_levmar.c:1124-1128)
     if (!linear_phase(1.0, true) || !read_scalars()) return MI_BA_ERROR;
     c_lag_ = h_scal_[SC_CONS_CAM] + h_scal_[SC_CONS_PTS];       // sba_levmar.c:809-842
-    p_eL2_ = init_p_eL2_ = h_scal_[SC_COST] + c_lag_;
+    p_eL2_ = init_p_eL2_ = h_scal_[SC_COST] + c_lag_ + h_scal_[SC_LINK];
     maxdiag_ = measured_maxdiag();
     eab_inf_ = std::max(h_scal_[SC_EA_INF], h_scal_[SC_EB_INF]);
     mu_ = std::fabs(cfg.opts[0]) * maxdiag_;
@@ -457,7 +515,7 @@ int Engine::step()
     timing.pcg_iters += s[SC_PCG_ITERS];
     // cost carried by the reference = residuals at p + the constraint penalty of the previous accepted iterate
     const double c_cur = s[SC_CONS_CAM] + s[SC_CONS_PTS];
-    p_eL2_ = s[SC_COST] + c_lag_;
+    p_eL2_ = s[SC_COST] + c_lag_ + s[SC_LINK];           // links: exact at p, no lag (they are not Bundler's)
     // the truncated drivers' parameter vector is the free block only (sba_levmar.c:2234, 2838)
     p_L2_ = (cfg.mode == 2 ? 0.0 : s[SC_PL2_CAMS]) + (cfg.mode == 1 ? 0.0 : s[SC_PL2_PTS] + pl2_inactive_);
     eab_inf_ = std::max(s[SC_EA_INF], s[SC_EB_INF]);
@@ -486,7 +544,7 @@ int Engine::step()
         }
         ++nfev_;
         {
-            const double pdp_eL2 = s[SC_COST_NEW] + c_cur; // QUIRK: penalty at the OLD p (sba_levmar.c:1498, 1514)
+            const double pdp_eL2 = s[SC_COST_NEW] + c_cur + s[SC_LINK_NEW]; // QUIRK: Bundler's penalty at the OLD p (sba_levmar.c:1498, 1514)
             if (!std::isfinite(pdp_eL2)) { stop_ = 7; end_outer(); ret = 2; break; }         // :1479-1485
             const double dL = s[SC_DL_CAMS] + s[SC_DL_PTS], dF = p_eL2_ - pdp_eL2;
             if (dL > 0.0 && dF > 0.0) {                                                       // :1543

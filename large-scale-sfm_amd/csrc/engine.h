@@ -46,6 +46,7 @@ public:
     int set_cameras(int m, const double *a0, const double *R0, const double *f_fixed);
     int set_fixed_cameras(const unsigned char *mask);
     int set_camera_constraints(const double *weights, const double *values);
+    int set_camera_links(int nlink, const int *cam_a, const int *cam_b, const double *weights);
     int set_point_constraints(const double *weight, const double *values);
     int set_points(int n, const double *xyz);
     int set_observations(int64_t nobs, const double *xy, const int *pt_idx, const int *cam_idx);
@@ -91,6 +92,9 @@ private:
     std::vector<int> h_pt_, h_cam_;
     std::vector<unsigned char> h_fixed_, h_fixed_eff_;
     std::vector<double> h_cam_cw_, h_cam_cv_, h_pt_cw_, h_pt_cv_; // soft constraints (empty = none)
+    std::vector<int> h_link_cam_;                                 // camera links: 2 ints per link
+    std::vector<double> h_link_w_;                                // cnp weights per link
+    CamLinks links_{};                                            // device view (row == nullptr: none)
     double c_lag_ = 0.0; // constraint penalty carried with the cost: the one of the PREVIOUS accepted iterate (QUIRK, sba_levmar.c:1498)
     bool have_ff_ = false;
     double pl2_inactive_ = 0.0;
@@ -105,6 +109,8 @@ private:
     DevBuf<unsigned long long> d_dbg_;
     DevBuf<int> d_long_pts_, d_long_scr_, d_up_row_, d_up_col_;
     DevBuf<double> d_long_scratch_, d_cam_cw_, d_cam_cv_, d_pt_cw_, d_pt_cv_;
+    DevBuf<int> d_link_row_, d_link_other_, d_link_blk_;
+    DevBuf<double> d_link_w_, d_link_pair_w_, d_cam_part_;
     long long long_max_pairs_ = 0;
     LongArgs long_args(double mu, bool want_diag, double *dB_dev, int part_row0);
     DevBuf<double2> d_obs_xy_;

@@ -35,13 +35,27 @@ enum Scal {
     SC_COST = 0, SC_PL2_PTS = 1, SC_CONS_PTS = 2,   // CONS_PTS: soft point-constraint penalty at p
     // [8,16) k_build maxima                                            (all-reduce #1, MAX)
     SC_EB_INF = 8, SC_MAXDIAG_V = 9, SC_SINGULAR = 10,
-    // [16,32) camera-side values, replicated on every rank
-    SC_EA_INF = 16, SC_MAXDIAG_U, SC_PL2_CAMS, SC_DL_CAMS, SC_DP2_CAMS, SC_PCG_ITERS, SC_PCG_STATUS, SC_PCG_DONE, SC_NOT_PD, SC_CONS_CAM,
+    // [16,32) camera-side values, computed redundantly on every rank: every sum is folded in a FIXED order
+    // (per-wave partial rows + k_reduce_partials), so all ranks hold the same bits and take the same LM decisions
+    SC_PL2_CAMS = 16, SC_CONS_CAM = 17, SC_LINK = 18,   // k_finalize_vec sums  [16,20)
+    SC_EA_INF = 20, SC_MAXDIAG_U = 21,                  // k_finalize_vec maxima [20,24)
+    SC_DL_CAMS = 24, SC_DP2_CAMS = 25, SC_LINK_NEW = 26, // k_cam_update sums    [24,28)
+    SC_PCG_ITERS = 28, SC_PCG_STATUS, SC_PCG_DONE, SC_NOT_PD,
     // [32,40) k_backsub sums                                           (all-reduce #2, SUM)
     SC_COST_NEW = 32, SC_DL_PTS = 33, SC_DP2_PTS = 34,
     // [40,48) k_backsub maxima                                         (all-reduce #2, MAX)
-    SC_MAX_PCT = 40,
+    SC_MAX_PCT = 40, SC_SPARE_MAX = 44,                 // [44,48): dump for unused maxima columns
     SC_COUNT = 48
+};
+
+// quadratic couplings between parameters of two cameras, cost += w_r (a_j[r] - a_k[r])^2: PBA's shared-intrinsics
+// "Q" constraints (SetFocalMask, SparseBundleCPU.cpp:1262-1329, 2781-2892).  Every link is listed at both ends.
+struct CamLinks {
+    const int *row;        // m + 1, CSR over cameras; nullptr = no links
+    const int *other;      // linked camera of each entry
+    const double *w;       // kCP weights per entry (internal parameter units), 0 = uncoupled
+    const int *blk_pair;   // per block of the full BSR pattern: index into pair_w, or -1
+    const double *pair_w;  // kCP summed weights per linked camera pair
 };
 
 struct BuildArgs {
@@ -101,15 +115,16 @@ void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const 
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
-                     double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, double *E, double *scal);
+                     double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
+                     double *E, double *cam_part, double *stage, double *scal);
 void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal);
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // spmv + update for iteration a.it
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . z_it
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max);
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
-                       const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
-                       double *cam_lin_new, double *scal);
+                       const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
+                       double *cam_lin_new, double *cam_part, double *stage, double *scal);
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a);
 void launch_long_build(hipStream_t st, int cnp, const LongArgs &a);   // k_long_reduce + k_long_pairs
 void launch_long_backsub(hipStream_t st, int cnp, const LongArgs &a);

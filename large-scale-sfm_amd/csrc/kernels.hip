@@ -863,7 +863,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const doubl
 __global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, const unsigned char *__restrict__ fixed, double mu, const int *__restrict__ rowidx,
                                                  const int *__restrict__ col, const int *__restrict__ src,
                                                  const unsigned char *__restrict__ trans, const double *__restrict__ S_up,
-                                                 const double *__restrict__ cam_cw, double *__restrict__ S_full)
+                                                 const double *__restrict__ cam_cw, const CamLinks lk, double *__restrict__ S_full)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int blk = (int)(gid >> 6), el = (int)(gid & 63);
@@ -873,10 +873,13 @@ __global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, const unsigne
     double v;
     if (j == k) {
         v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
+        if (r == c && r < cnp && lk.row)                               // shared-intrinsics links: U_jj += sum w
+            for (int q = lk.row[j]; q < lk.row[j + 1]; ++q) v += lk.w[(size_t)q * kCP + r];
         if (r == c) v = (r < cnp) ? v + mu + cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
         if (fixed[j]) v = (r == c) ? 1.0 : 0.0;
     } else {
         v = trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
+        if (r == c && lk.row) { const int pq = lk.blk_pair[blk]; if (pq >= 0) v -= lk.pair_w[(size_t)pq * kCP + r]; } // U_jk = -w
         if (fixed[j] || fixed[k]) v = 0.0;
     }
     if (r >= cnp || c >= cnp) v = (j == k && r == c) ? 1.0 : 0.0;
@@ -887,11 +890,11 @@ __global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, const unsigne
 // max diag U, ||a||^2   (sba_levmar.c:1085-1088, 1124-1128)
 __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsigned char *__restrict__ fixed, double *__restrict__ camvec,
                                                      const double *__restrict__ cam_a, const double *__restrict__ cam_cw,
-                                                     const double *__restrict__ cam_cv, double *__restrict__ E,
-                                                     double *__restrict__ scal)
+                                                     const double *__restrict__ cam_cv, const CamLinks lk, double *__restrict__ E,
+                                                     double *__restrict__ part)
 {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    double eainf = 0.0, maxdu = 0.0, pl2 = 0.0, cc = 0.0;
+    double eainf = 0.0, maxdu = 0.0, pl2 = 0.0, cc = 0.0, lc = 0.0;
     if (gid < m * kCP) {
         const int j = gid >> 3, r = gid & 7;
         const bool live = (r < cnp) && !fixed[j];
@@ -900,20 +903,26 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
             const double a = cam_a[gid], w = cam_cw[gid], d = cam_cv[gid] - a;
             pl2 = a * a;
             cc = w * d * d;                                   // every camera, fixed ones too (sba_levmar.c:810-825)
-            if (live && w != 0.0) {                           // U_jj += w (k_finalize), ea_j += w diff (:959-960)
-                ea += w * d; Ev += w * d; du += w;
+            double add = 0.0, dadd = 0.0;
+            if (w != 0.0) { add = w * d; dadd = w; }          // U_jj += w (k_finalize), ea_j += w diff (:959-960)
+            if (lk.row)                                       // links: residual -(a_j - a_k), each link seen from both ends
+                for (int q = lk.row[j]; q < lk.row[j + 1]; ++q) {
+                    const double wq = lk.w[(size_t)q * kCP + r], dq = cam_a[(size_t)lk.other[q] * kCP + r] - a;
+                    add = fma(wq, dq, add); dadd += wq;
+                    lc = fma(0.5 * wq, dq * dq, lc);
+                }
+            if (live && (add != 0.0 || dadd != 0.0)) {
+                ea += add; Ev += add; du += dadd;
                 camvec[gid] = ea;                             // k_cam_update reads ea for dL
             }
         }
         E[gid] = live ? Ev : 0.0;
         if (live) { eainf = fabs(ea); maxdu = du; }
     }
-    eainf = wave_max(eainf); maxdu = wave_max(maxdu); pl2 = wave_sum(pl2); cc = wave_sum(cc);
-    if ((threadIdx.x & 63) == 0) {
-        atomic_max_pos(&scal[SC_EA_INF], eainf);
-        atomic_max_pos(&scal[SC_MAXDIAG_U], maxdu);
-        gadd(&scal[SC_PL2_CAMS], pl2);
-        gadd(&scal[SC_CONS_CAM], cc);
+    eainf = wave_max(eainf); maxdu = wave_max(maxdu); pl2 = wave_sum(pl2); cc = wave_sum(cc); lc = wave_sum(lc);
+    if ((threadIdx.x & 63) == 0) { // one partial row per wave, folded in a fixed order by k_reduce_partials
+        double *pr = part + (size_t)(gid >> 6) * kPartW;
+        pr[0] = pl2; pr[1] = cc; pr[2] = lc; pr[3] = 0.0; pr[4] = eainf; pr[5] = maxdu; pr[6] = 0.0; pr[7] = 0.0;
     }
 }
 
@@ -1118,11 +1127,11 @@ __global__ __launch_bounds__(64) void k_pcg_update(const PcgArgs a)
 // ------------------------------------------------------------------------------------------
 __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *__restrict__ fixed, double mu, const double *__restrict__ cam_a,
                              const double *__restrict__ dA, const double *__restrict__ camvec,
-                             const double *__restrict__ R0, const double *__restrict__ f_fixed,
-                             double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ scal)
+                             const double *__restrict__ R0, const double *__restrict__ f_fixed, const CamLinks lk,
+                             double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ part)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    double dl = 0.0, dp2 = 0.0;
+    double dl = 0.0, dp2 = 0.0, lc = 0.0;
     if (j < m) {
         double an[kCP];
 #pragma unroll
@@ -1134,9 +1143,20 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
             dp2 += d * d;
         }
         cam_record(cfg, cnp, an, R0 + (size_t)j * 9, f_fixed ? f_fixed[j] : 1.0, cam_lin_new + (size_t)j * kCamLin);
+        if (lk.row)                                            // link penalty at the trial point
+            for (int q = lk.row[j]; q < lk.row[j + 1]; ++q) {
+                const int k = lk.other[q];
+                for (int r = 0; r < cnp; ++r) {
+                    const double ak = cam_a[k * kCP + r] + (fixed[k] ? 0.0 : dA[k * kCP + r]), dq = ak - an[r];
+                    lc = fma(0.5 * lk.w[(size_t)q * kCP + r], dq * dq, lc);
+                }
+            }
     }
-    dl = wave_sum(dl); dp2 = wave_sum(dp2);
-    if ((threadIdx.x & 63) == 0) { gadd(&scal[SC_DL_CAMS], dl); gadd(&scal[SC_DP2_CAMS], dp2); }
+    dl = wave_sum(dl); dp2 = wave_sum(dp2); lc = wave_sum(lc);
+    if ((threadIdx.x & 63) == 0) {
+        double *pr = part + (size_t)blockIdx.x * kPartW;
+        pr[0] = dl; pr[1] = dp2; pr[2] = lc; pr[3] = 0.0; pr[4] = 0.0; pr[5] = 0.0; pr[6] = 0.0; pr[7] = 0.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1296,12 +1316,15 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
-                     double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, double *E, double *scal)
+                     double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
+                     double *E, double *cam_part, double *stage, double *scal)
 {
     const long long total = (long long)nb * 64;
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cnp, nb, fixed, mu, bsr_rowidx,
-                       bsr_col, bsr_src, bsr_trans, S_up, cam_cw, S_full);
-    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, camvec, cam_a, cam_cw, cam_cv, E, scal);
+                       bsr_col, bsr_src, bsr_trans, S_up, cam_cw, links, S_full);
+    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, camvec, cam_a, cam_cw, cam_cv,
+                       links, E, cam_part);
+    launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);
 }
 
 void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal)
@@ -1332,11 +1355,12 @@ void launch_reduce_partials(hipStream_t st, int nrows, const double *part, doubl
 }
 
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
-                       const double *camvec, const double *R0, const double *f_fixed, double *cam_a_new,
-                       double *cam_lin_new, double *scal)
+                       const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
+                       double *cam_lin_new, double *cam_part, double *stage, double *scal)
 {
     hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, dA, camvec, R0, f_fixed,
-                       cam_a_new, cam_lin_new, scal);
+                       links, cam_a_new, cam_lin_new, cam_part);
+    launch_reduce_partials(st, (m + 63) / 64, cam_part, stage, scal + SC_DL_CAMS, scal + SC_SPARE_MAX);
 }
 
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)

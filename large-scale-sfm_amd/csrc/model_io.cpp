@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include "focal_links.h"
+
 #include "../../include/mi_model.h"
 
 struct mi_model {
@@ -21,6 +23,8 @@ struct mi_model {
     std::vector<double> xy;              // per projection 2
     std::vector<int> pt_idx, cam_idx;
     std::vector<long long> feat_id;
+    std::vector<int> focal_mask;         // shared-intrinsics groups (SetFocalMask semantics), empty = none
+    double focal_weight = 0.0;
     size_t ncam() const { return f.size(); }
     size_t npt() const { return xyz.size() / 3; }
     size_t nproj() const { return pt_idx.size(); }
@@ -363,6 +367,16 @@ double mi_model_rmse(const mi_model *m)
     return std::sqrt(s / (double)m->nproj());
 }
 
+int mi_model_set_focal_mask(mi_model *m, const int *mask, double weight)
+{
+    if (!m) return MI_BA_ERROR;
+    m->focal_mask.clear(); m->focal_weight = 0.0;
+    if (!mask || weight <= 0) return 0;
+    m->focal_mask.assign(mask, mask + m->ncam());
+    m->focal_weight = weight;
+    return 0;
+}
+
 int mi_model_optimize(mi_model *m, const mi_ba_config *user, double info[MI_BA_INFOSZ])
 {
     if (!m) return MI_BA_ERROR;
@@ -376,6 +390,15 @@ int mi_model_optimize(mi_model *m, const mi_ba_config *user, double info[MI_BA_I
     mi_ba_engine *e = mi_ba_create(&cfg);
     if (!e) { g_err = mi_ba_last_error(nullptr); return MI_BA_ERROR; }
     const int ncam = (int)m->ncam(), npt = (int)m->npt(), cnp = mi_ba_cnp(e);
+    miba::FocalLinks fl;
+    if (!m->focal_mask.empty() && cfg.est_focal) { // shared intrinsics, as ParallelBA::SetFocalMask (pba.h:124)
+        if (!miba::focal_mask_links(ncam, m->focal_mask.data(), m->nproj(), m->cam_idx.data(), m->focal_weight, fl)) {
+            g_err = "incorrect focal mask"; mi_ba_destroy(e); return MI_BA_ERROR;
+        }
+        miba::focal_mask_average(ncam, m->focal_mask.data(), m->f.data(), 1);
+    }
+    std::vector<double> link_w(fl.a.size() * (size_t)cnp, 0.0);
+    for (size_t q = 0; q < fl.a.size(); ++q) link_w[q * cnp + 6] = fl.w[q] * fl.w[q] / (cfg.f_scale * cfg.f_scale);
     std::vector<double> a0((size_t)ncam * cnp, 0.0);
     for (int j = 0; j < ncam; ++j) {
         for (int r = 0; r < 3; ++r) a0[(size_t)j * cnp + r] = m->t[(size_t)j * 3 + r];
@@ -383,6 +406,7 @@ int mi_model_optimize(mi_model *m, const mi_ba_config *user, double info[MI_BA_I
     }
     int ret = MI_BA_ERROR;
     if (mi_ba_set_cameras(e, ncam, a0.data(), m->R.data(), m->f.data()) == 0 && mi_ba_set_points(e, npt, m->xyz.data()) == 0 &&
+        mi_ba_set_camera_links(e, (int)fl.a.size(), fl.a.data(), fl.b.data(), link_w.data()) == 0 &&
         mi_ba_set_observations(e, (int64_t)m->nproj(), m->xy.data(), m->pt_idx.data(), m->cam_idx.data()) == 0 && mi_ba_prepare(e) == 0) {
         ret = mi_ba_run(e, info);
         std::vector<double> a((size_t)ncam * cnp), R((size_t)ncam * 9);

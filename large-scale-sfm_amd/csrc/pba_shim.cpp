@@ -1,8 +1,10 @@
 // pba_shim.cpp -- class ParallelBA (include/mi_pba.h) over the C ABI of include/mi_ba.h.
 // Mirrors the call sequence of the reference plugin (pba.cpp:27-154 forwarding to
 // SparseBundleCPU.cpp:2541-2674); the numbers come from the HIP engine.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +13,7 @@
 
 #include "../../include/mi_ba.h"
 #include "../../include/mi_pba.h"
+#include "focal_links.h"
 
 ConfigBA::ConfigBA()
     : __lm_max_iteration(50), __lm_mse_threshold(0.25f), __bundle_time_budget(0), __bundle_mode_next(0), __cg_max_iteration(100), __cg_norm_threshold(1e-3f), __fixed_intrinsics(false),
@@ -51,6 +54,7 @@ struct ParallelBA::Impl {
     CameraT *cams = nullptr; size_t ncam = 0;
     Point3D *pts = nullptr; size_t npt = 0;
     const Point2D *meas = nullptr; const int *ptidx = nullptr, *camidx = nullptr; size_t nproj = 0;
+    const int *fmask = nullptr; float fweight = 0.0f;
     std::atomic<float> mse{0.0f};
     std::atomic<int> iteration{0};
     std::atomic<bool> abort{false};
@@ -80,7 +84,9 @@ void ParallelBA::SetNextBundleMode(BundleModeT mode) { _optimizer->cfg.__bundle_
 float ParallelBA::GetMeanSquaredError() { return _optimizer->mse.load(); }
 void ParallelBA::AbortBundleAdjustment() { _optimizer->abort.store(true); }
 int ParallelBA::GetCurrentIteration() { return _optimizer->iteration.load(); }
-void ParallelBA::SetFocalMask(const int *, float) {} // shared-focal "Q" constraints: SURVEY 8f rank 2, not in this round
+// shared-intrinsics groups: fmask[i] = index of the group's first camera (fmask[iq] == iq), -1 = on its own
+// (pba.h:124, SparseBundleCPU.cpp:2550-2554); the pointer is kept like every other input array
+void ParallelBA::SetFocalMask(const int *fmask, float weight) { _optimizer->fmask = fmask; _optimizer->fweight = weight; }
 
 int ParallelBA::RunBundleAdjustment()
 {
@@ -105,13 +111,36 @@ int ParallelBA::RunBundleAdjustment()
     mi_ba_default_config(&cfg);
     cfg.est_focal = c.__fixed_intrinsics ? 0 : 1;
     cfg.undistort = (dist != 0 && !c.__fixed_intrinsics) ? (dist > 0 ? 1 : 2) : 0;
+    if (cfg.undistort == 2) { // the coefficient of |x|^2 (pixels^2) is ~1e-7: scale its parameter by f^2 so that the additive damping sees a balanced column
+        std::vector<float> fv(o.ncam);
+        for (size_t j = 0; j < o.ncam; ++j) fv[j] = o.cams[j].f;
+        std::nth_element(fv.begin(), fv.begin() + fv.size() / 2, fv.end());
+        const double fm = fv[fv.size() / 2];
+        if (fm > 0) cfg.k_scale = 5.0 * fm * fm;
+    }
     cfg.explicit_centers = 0;              // CameraT holds T = -R C (DataInterface.h:51)
     cfg.proj_sign = 1.0;                   // +z forward
     cfg.itmax = c.__lm_max_iteration;
+    cfg.opts[5] = 0.0;                     // Bundler's "residuals changed by < 4 %" exit (stop 8) is not a PBA rule
     cfg.pcg_maxit = c.__cg_max_iteration; cfg.pcg_tol = c.__cg_norm_threshold;
     cfg.device = o.device; cfg.verbose = c.__verbose_level;
     cfg.mode = c.__bundle_mode_next == 1 ? 1 : c.__bundle_mode_next == 2 ? 2 : 0;        // SetNextBundleMode, pba.h:103
     c.__bundle_mode_next = 0;                                                             // ResetTemporarySetting, ConfigBA.cpp:149-157
+    // SetFocalMask: soft equality of focal length (and distortion) inside a group, as a ring of links between its
+    // cameras (ProcessIndexCameraQ, SparseBundleCPU.cpp:2781-2851), the group's values first set to their means and
+    // the weight sqrt(projections per camera of the group) * weight (ProcessWeightCameraQ, :2854-2892)
+    miba::FocalLinks fl;
+    std::vector<double> link_wr;
+    if (o.fmask && o.fweight > 0 && cfg.est_focal && cfg.mode != 2) {
+        const int mm = (int)o.ncam;
+        if (!miba::focal_mask_links(mm, o.fmask, o.nproj, o.camidx, o.fweight, fl))
+            std::fprintf(stderr, "[mi_pba] Error: incorrect constraints\n");   // the reference drops the mask and goes on
+        else {
+            miba::focal_mask_average(mm, o.fmask, &o.cams[0].f, sizeof(CameraT) / sizeof(float));
+            miba::focal_mask_average(mm, o.fmask, &o.cams[0].radial, sizeof(CameraT) / sizeof(float));
+            for (size_t q = 0; q < fl.a.size(); ++q) link_wr.push_back(dist != 0 ? fl.w[q] * o.cams[fl.rep[q]].f : 0.0);
+        }
+    }
     mi_ba_engine *e = mi_ba_create(&cfg);
     if (!e) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(nullptr)); c.__bundle_return_code = 'E'; return 0; }
     const int m = (int)o.ncam, n = (int)o.npt, cnp = mi_ba_cnp(e);
@@ -141,7 +170,13 @@ int ParallelBA::RunBundleAdjustment()
         }
     int ret = 0;
     double info[MI_BA_INFOSZ] = { 0 };
+    std::vector<double> link_w(fl.a.size() * (size_t)cnp, 0.0);
+    for (size_t q = 0; q < fl.a.size(); ++q) {   // internal units: a6 = f * f_scale, a7 = k * k_scale
+        link_w[q * cnp + 6] = fl.w[q] * fl.w[q] / (cfg.f_scale * cfg.f_scale);
+        if (cfg.undistort) link_w[q * cnp + 7] = link_wr[q] * link_wr[q] / (cfg.k_scale * cfg.k_scale);
+    }
     if (mi_ba_set_cameras(e, m, a0.data(), R0.data(), ff.data()) || mi_ba_set_fixed_cameras(e, fixed.data()) ||
+        mi_ba_set_camera_links(e, (int)fl.a.size(), fl.a.data(), fl.b.data(), link_w.data()) ||
         mi_ba_set_points(e, n, xyz.data()) || mi_ba_set_observations(e, (int64_t)o.nproj, xy.data(), o.ptidx, o.camidx) ||
         mi_ba_prepare(e) || mi_ba_begin(e)) {
         std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(e));

@@ -31,7 +31,7 @@ inline double point_weight(int d) { return (double)d + 0.5 * (double)d * (d + 1)
 } // namespace
 
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
-                       int rank, int world, int tile_max_batches)
+                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs)
 {
     if (n <= 0 || m <= 0 || nobs < 0) return "empty problem";
     if (world < 1 || rank < 0 || rank >= world) return "bad rank/world";
@@ -126,6 +126,12 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                 for (int b = a + 1; b < d; ++b) row[c[b] >> 6] |= 1ull << (c[b] & 63);
             }
         }
+        if (extra_pairs)
+            for (size_t q = 0; q + 1 < extra_pairs->size(); q += 2) {
+                const int a = std::min((*extra_pairs)[q], (*extra_pairs)[q + 1]), b = std::max((*extra_pairs)[q], (*extra_pairs)[q + 1]);
+                if (a < 0 || b >= m) return "camera link out of range";
+                bits[(size_t)a * words + (b >> 6)] |= 1ull << (b & 63);
+            }
         pl.up_row.assign(m + 1, 0);
         for (int j = 0; j < m; ++j) {
             int cnt = 0;

@@ -72,7 +72,9 @@ struct Plan {
 };
 
 // pt_idx must be non-decreasing.  Returns "" or an error message.
+// extra_pairs: camera pairs (2 ints each) whose block of S must exist although no point links them
+// (parameter couplings between cameras, kernels.h CamLinks)
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
-                       int rank, int world, int tile_max_batches);
+                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs = nullptr);
 
 } // namespace miba

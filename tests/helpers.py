@@ -153,7 +153,8 @@ def run_pba_client(exe, problem, workdir, device, m, n):
                 radial=cams[:, 13], pts=pts, stdout=out.stdout)
 
 
-PBA_CASES = ("plain", "early_stop", "proj_dist", "meas_dist", "fixed_intr_md", "motion_only", "structure_only")
+PBA_CASES = ("plain", "early_stop", "proj_dist", "meas_dist", "fixed_intr_md", "motion_only", "structure_only",
+             "shared_focal", "shared_focal_groups_pd")
 
 
 def pba_case(name):
@@ -178,6 +179,13 @@ def pba_case(name):
         sc = vsfm_scene(m=16, n=1500, d=5, seed=35, pt_noise=0.0); kw.update(mode=1, nconst=0)
     elif name == "structure_only":
         sc = vsfm_scene(m=16, n=1500, d=5, seed=36, cam_noise=0.0, f_noise=0.0); kw.update(mode=2, nconst=0)
+    elif name == "shared_focal":                     # SetFocalMask: one group holding every camera
+        # (no constant cameras: the reference's Q term also drags the focal length of a constant camera along,
+        #  SparseBundleCPU.cpp:1301-1329 has no constant-camera test; here a constant camera stays constant)
+        sc = vsfm_scene(m=16, n=1500, d=5, seed=37); kw.update(mask=np.zeros(16, int), nconst=0)
+    elif name == "shared_focal_groups_pd":           # two groups, a pair, cameras on their own; with projection distortion
+        sc = vsfm_scene(m=16, n=1500, d=5, seed=38, undistort=1, nk=1, k_true=(-0.12, 0.0))
+        kw.update(distortion=1, mask=np.array([0, 0, 2, 2, 2, -1, 6, 0, 2, -1, 6, 11, 11, 0, 2, -1]), nconst=0)
     else:
         raise KeyError(name)
     return sc, kw

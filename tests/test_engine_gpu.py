@@ -214,6 +214,50 @@ def test_radial_distortion_k1(oracle, est_focal):
     assert abs(eng.debug_linearize(mu)["cost"] - oracle.cost(sc, eng.packed_params())) < 1e-9 * info[1]
 
 
+def test_camera_links(oracle):
+    """quadratic couplings between cameras (the engine side of ParallelBA::SetFocalMask): U gets diagonal and
+    off-diagonal entries, the gradient and the cost the matching terms; checked against numpy on the oracle's blocks"""
+    sc, z = scene_from_golden("C1")
+    m, cnp = sc.m, sc.cnp
+    la = np.array([0, 1, 2, 3, 7, 9, 7]); lb = np.array([1, 2, 3, 0, 9, 7, 15])     # a ring, a doubled pair, a far pair
+    w = np.zeros((len(la), cnp)); w[:, 6] = 3e6; w[4:, 6] = 5e5; w[6, 0] = 40.0     # focal entries + one centre coordinate
+    capi = pkg("capi")
+    eng = capi.Engine(capi.default_config(est_focal=sc.est_focal, explicit_centers=sc.explicit_centers, proj_sign=sc.proj_sign,
+                                          pcg_tol=1e-12, pcg_maxit=400))
+    eng.load_scene(sc)
+    eng.set_camera_links(la, lb, w)
+    eng.prepare()
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    g = eng.debug_linearize(mu)
+    S, E, _ = reduced_system(lin, sc, mu)
+    a = sc.p0[:m * cnp].reshape(m, cnp)
+    pen = 0.0
+    for q in range(len(la)):
+        ja, jb = la[q], lb[q]
+        for r in range(cnp):
+            S[ja * cnp + r, ja * cnp + r] += w[q, r]; S[jb * cnp + r, jb * cnp + r] += w[q, r]
+            S[ja * cnp + r, jb * cnp + r] -= w[q, r]; S[jb * cnp + r, ja * cnp + r] -= w[q, r]
+            d = a[ja, r] - a[jb, r]
+            E[ja * cnp + r] -= w[q, r] * d; E[jb * cnp + r] += w[q, r] * d
+            pen += w[q, r] * d * d
+    scale = np.abs(lin["U"]).max()
+    assert np.abs(g["S"] - S).max() < 1e-10 * max(scale, w.max())
+    assert rel(g["E"].reshape(-1), E) < 1e-9
+    # the solve: cost reported = residuals + penalty, linked focal lengths pulled together
+    ret, info = eng.run()
+    assert abs(info[0] - (lin["cost"] + pen)) < 1e-10 * info[0]
+    p = eng.packed_params()
+    af = p[:m * cnp].reshape(m, cnp)
+    penf = sum(w[q, r] * (af[la[q], r] - af[lb[q], r]) ** 2 for q in range(len(la)) for r in range(cnp))
+    assert abs(info[1] - (oracle.cost(sc, p) + penf)) < 1e-9 * info[1]
+    assert np.ptp(af[:4, 6]) < 0.02 * np.ptp(a[:4, 6]) and abs(af[7, 6] - af[9, 6]) < 0.05 * abs(a[7, 6] - a[9, 6])
+    # the reduced gradient of the penalised objective has collapsed (Bundler's 4 % exit leaves it short of zero)
+    eng.set_params(*eng.params())
+    g2 = eng.debug_linearize(mu)
+    assert np.abs(g2["E"]).max() < 1e-2 * np.abs(g["E"]).max()
+
+
 @pytest.mark.parametrize("d", [5, 13])
 def test_measurement_distortion(oracle, d):
     """undistort 2 = PBA's measurement distortion x (1 + k |x|^2) = projection (SparseBundleCPU.cpp:1188-1193, 1427-1432);
