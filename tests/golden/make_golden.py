@@ -74,7 +74,24 @@ def make(name, trace_len, keep_W, **kw):
           "rmse", np.sqrt(full["info"][1] / sc.nobs))
 
 
+def make_edge():
+    """edge cases: tests/helpers.py::degenerate_scene (points seen once or twice, a camera nobody observes);
+    the inputs are regenerated from the seed, only the reference's answer is stored"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest  # noqa: F401
+    import helpers
+    sc = helpers.degenerate_scene()
+    ref = Reference()
+    full = ref.run(sc, itmax=150)
+    mcon = ref.run(sc, itmax=150, mcon=1)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_edge.npz")
+    np.savez_compressed(path, xsum=np.abs(sc.x).sum(), p_final=full["p"], info_final=full["info"], ret_final=full["ret"],
+                        p_mcon1=mcon["p"], info_mcon1=mcon["info"])
+    print("edge ->", path, "iters", full["ret"], "stop", full["info"][6])
+
+
 if __name__ == "__main__":
+    make_edge()
     make("micro", 8, True)
     make("C1", 12, False)
     # camera params hold t instead of C (the other branch of sfm.c:319-330)

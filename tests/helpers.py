@@ -189,3 +189,22 @@ def pba_case(name):
     else:
         raise KeyError(name)
     return sc, kw
+
+
+def degenerate_scene(seed=5):
+    """edge cases in one scene: points seen once (V_i has rank 2, only the damping makes it invertible), points seen
+    twice, a camera nobody observes (U_j = 0), on top of ordinary tracks"""
+    scene = pkg("scene")
+    rng = np.random.default_rng(seed)
+    base = scene.make_scene("x", m=13, n=700, d=6, seed=seed + 100, strides=(1, 2))
+    keep = []
+    for i in range(base.n):
+        idx = np.arange(base.pt_ptr[i], base.pt_ptr[i + 1])
+        idx = idx[base.obs_cam[idx] != 12]                     # camera 12 sees nothing
+        d = 1 if i % 7 == 0 else 2 if i % 7 == 1 else len(idx)
+        keep.append(idx[:d])
+    sel = np.concatenate(keep)
+    cnt = np.array([len(k) for k in keep])
+    return scene.Scene(n=base.n, m=base.m, cnp=base.cnp, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0,
+                       pt_ptr=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), obs_cam=base.obs_cam[sel],
+                       x=base.x[sel], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true, name="degenerate")

@@ -382,6 +382,26 @@ def test_mixed_track_lengths_and_unsorted_cameras(oracle):
     assert np.array_equal(p[m * cnp:].reshape(n, 3)[unobserved], sc.p0[m * cnp:].reshape(n, 3)[unobserved])
 
 
+def test_degenerate_points_and_an_unobserved_camera(oracle):
+    """points seen once / twice and a camera without observations, vs the real reference's answer (golden)"""
+    import os
+    from conftest import GOLDEN
+    from helpers import degenerate_scene
+    sc = degenerate_scene()
+    z = np.load(os.path.join(GOLDEN, "ref_edge.npz"))
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    ret, info = eng.run()
+    want = z["info_final"]
+    assert ret == int(z["ret_final"]) and info[6] == want[6] and info[9] == want[9]
+    assert abs(info[1] - want[1]) < 1e-6 * want[1]
+    p = eng.packed_params()
+    assert abs(oracle.cost(sc, p) - info[1]) < 1e-9 * info[1]
+    assert np.array_equal(p[12 * sc.cnp:13 * sc.cnp], sc.p0[12 * sc.cnp:13 * sc.cnp])       # nobody observes camera 12
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, mcon=1)                                 # gauge pinned: compare parameters
+    eng.run()
+    assert np.abs(eng.packed_params() - z["p_mcon1"]).max() < 1e-4
+
+
 def test_rccl_exchange_on_a_one_rank_communicator(oracle, monkeypatch):
     """the all-reduce calls of the multi-GPU path (same buffers, counts and stream) on this single GPU"""
     monkeypatch.setenv("MI_BA_FORCE_COMM", "1")

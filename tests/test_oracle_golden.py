@@ -167,6 +167,22 @@ def test_too_few_measurements_is_an_error(oracle):
     assert oracle.run(sc, itmax=5)["ret"] == -1
 
 
+def test_edge_cases_match_the_reference(oracle):
+    """points seen once (V_i rank 2: only the damping makes it invertible) or twice, a camera nobody observes"""
+    from conftest import GOLDEN
+    from helpers import degenerate_scene
+    import os
+    sc = degenerate_scene()
+    z = np.load(os.path.join(GOLDEN, "ref_edge.npz"))
+    assert abs(np.abs(sc.x).sum() - float(z["xsum"])) < 1e-9 * float(z["xsum"])
+    r = oracle.run(sc, itmax=150)
+    assert r["ret"] == int(z["ret_final"]) and np.array_equal(r["info"][[5, 6, 9]], z["info_final"][[5, 6, 9]])
+    assert np.abs(r["p"] - z["p_final"]).max() < 1e-6 and abs(r["info"][1] - z["info_final"][1]) < 1e-8 * r["info"][1]
+    r = oracle.run(sc, itmax=150, mcon=1)
+    assert np.abs(r["p"] - z["p_mcon1"]).max() < 1e-6
+    assert np.array_equal(r["p"][12 * sc.cnp:13 * sc.cnp], sc.p0[12 * sc.cnp:13 * sc.cnp])   # the unobserved camera never moves
+
+
 def test_live_reference_if_present(oracle):
     from oracle import Reference
     if not Reference.available():
