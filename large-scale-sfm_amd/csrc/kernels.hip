@@ -53,6 +53,9 @@ __device__ __forceinline__ void ladd(double *p, double v)                       
 // ------------------------------------------------------------------------------------------
 // undistort == 2 is PBA's measurement distortion (ComputeProjection with radial == -1, SparseBundleCPU.cpp:1188-1193):
 // residual x (1 + k |x|^2) - f q.xy / q.z, written as x - xhat with xhat = f q.xy / q.z - k |x|^2 x
+// FULL = false is the lean instantiation of the common case (no measurement distortion): the hot kernels are register
+// bound, and carrying the rarely used model through them costs occupancy
+template <bool FULL>
 __device__ __forceinline__ void project_obs(const ModelCfg &cfg, const double *__restrict__ cl, const double X[3],
                                             double2 xy, double &u, double &v)
 {
@@ -65,24 +68,29 @@ __device__ __forceinline__ void project_obs(const ModelCfg &cfg, const double *_
 #pragma unroll
         for (int r = 0; r < 3; ++r) q[r] = cl[3 * r] * X[0] + cl[3 * r + 1] * X[1] + cl[3 * r + 2] * X[2] + cl[18 + r];
     }
-    const bool md = cfg.undistort == 2;
-    double f = cl[21], k1 = cl[22], k2 = cl[23];
-    double iz = 1.0 / q[2], mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
-    double g = cfg.proj_sign * f * (md ? 1.0 : 1.0 + k1 * r2 + k2 * r2 * r2);
+    const bool md = FULL && cfg.undistort == 2;
+    double f = cl[21];
+    double iz = 1.0 / q[2], mx = q[0] * iz, my = q[1] * iz;
+    double g = cfg.proj_sign * f;
+    if constexpr (FULL) {
+        const double k1 = cl[22], k2 = cl[23], r2 = mx * mx + my * my;
+        if (!md) g *= 1.0 + k1 * r2 + k2 * r2 * r2;
+    }
     u = g * mx; v = g * my;
-    if (md) { const double kk = k1 * (xy.x * xy.x + xy.y * xy.y); u -= kk * xy.x; v -= kk * xy.y; }
+    if (md) { const double kk = cl[22] * (xy.x * xy.x + xy.y * xy.y); u -= kk * xy.x; v -= kk * xy.y; }
 }
 
-template <int CNP>
+template <int CNP, bool FULL>
 __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double *__restrict__ cl, const double X[3],
                                               double2 xy, bool fixed_cam, double e[2], double A[2][CNP], double B[2][3])
 {
     double R[9], q[3], qr[3];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = cl[i];
-    const bool md = cfg.undistort == 2;
+    const bool md = FULL && cfg.undistort == 2;
     const double m2k = md ? (xy.x * xy.x + xy.y * xy.y) : 0.0;
-    const double c0 = cl[18], c1 = cl[19], c2 = cl[20], f = cl[21], k1 = md ? 0.0 : cl[22], k2 = cl[23];
+    const double c0 = cl[18], c1 = cl[19], c2 = cl[20], f = cl[21];
+    const double k1 = (FULL && !md) ? cl[22] : 0.0, k2 = FULL ? cl[23] : 0.0;   // lean: no distortion terms at all
     if (cfg.explicit_centers) {
         double d0 = X[0] - c0, d1 = X[1] - c1, d2 = X[2] - c2;
 #pragma unroll
@@ -94,7 +102,7 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
     }
     const double s = cfg.proj_sign, iz = 1.0 / q[2];
     const double mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
-    const double D = 1.0 + k1 * r2 + k2 * r2 * r2, Dp = k1 + 2.0 * k2 * r2;
+    const double D = FULL ? 1.0 + k1 * r2 + k2 * r2 * r2 : 1.0, Dp = FULL ? k1 + 2.0 * k2 * r2 : 0.0;
     e[0] = xy.x - s * f * mx * D;
     e[1] = xy.y - s * f * my * D;
     if (md) { const double kk = cl[22] * m2k; e[0] = fma(kk, xy.x, e[0]); e[1] = fma(kk, xy.y, e[1]); }
@@ -143,8 +151,8 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
         if constexpr (CNP >= 7) {
             const double mr = (r == 0) ? mx : my;
             int idx = 6;
-            if (cfg.est_focal) { A[r][6] = s * mr * D / cfg.f_scale; idx = 7; }
-            if (cfg.undistort) {
+            if (!FULL || cfg.est_focal) { A[r][6] = s * mr * D / cfg.f_scale; idx = 7; }   // lean: cnp 7 = pose + focal
+            if (FULL && cfg.undistort) {
                 const double dk = md ? -m2k * (r == 0 ? xy.x : xy.y) / cfg.k_scale     // JacobianOne, SparseBundleCPU.cpp:1427-1432
                                      : s * f * mr * r2 / cfg.k_scale;
                 if (idx == 6) A[r][6] = dk;
@@ -327,7 +335,7 @@ __device__ __forceinline__ void pair_block(const double *sR, const double *sv, i
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int CNP, bool LDS>
+template <int CNP, bool LDS, bool FULL>
 __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArgs g) // 8x8 blocks: 128 accumulator VGPRs, one wave per SIMD
 {
 #ifdef MIBA_STAMPS
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
             if (have_next) load_batch_level1<LDS>(g, td, b + 1 - b_begin, lane, nxt);   // streams + pair entries of the next batch
             STAMP(7);
             if (active) {
-                linearize_obs<CNP>(cfg, cl, X, cur.xy, g.cam_fixed[j] != 0, e, A, B);
+                linearize_obs<CNP, FULL>(cfg, cl, X, cur.xy, g.cam_fixed[j] != 0, e, A, B);
                 cost += e[0] * e[0] + e[1] * e[1];
                 double *row = sR + lane * SR;
 #pragma unroll
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
             head = active && (lane == 0 || lp != lp_prev);
             if (head) {
                 sStart[lp] = lane; pl2 += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
-                if (g.pt_cw) { // soft point constraint (sba_levmar.c:1017-1029): needs X, which the prefetch below replaces
+                if (FULL && g.pt_cw) { // soft point constraint (sba_levmar.c:1017-1029): needs X, which the prefetch below replaces
                     pcw = g.pt_cw[cur.ip];
 #pragma unroll
                     for (int t = 0; t < 3; ++t) pcd[t] = g.pt_cv[3 * (size_t)cur.ip + t] - X[t];
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
             double v00 = sV[lp * SV], v01 = sV[lp * SV + 1], v02 = sV[lp * SV + 2];
             double v11 = sV[lp * SV + 3], v12 = sV[lp * SV + 4], v22 = sV[lp * SV + 5];
             double eb0 = sV[lp * SV + 6], eb1 = sV[lp * SV + 7], eb2 = sV[lp * SV + 8];
-            if (pcw != 0.0) {
+            if (FULL && pcw != 0.0) {
                 v00 += pcw; v11 += pcw; v22 += pcw;
                 eb0 += pcw * pcd[0]; eb1 += pcw * pcd[1]; eb2 += pcw * pcd[2];
                 ccost += pcw * (pcd[0] * pcd[0] + pcd[1] * pcd[1] + pcd[2] * pcd[2]);
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
     for (int o = os + tid; o < oe; o += 256) {
         const int j = g.obs_cam[o];
         double A[2][CNP], B[2][3], e[2];
-        linearize_obs<CNP>(g.cfg, g.cam_lin + (size_t)j * kCamLin, X, g.obs_xy[o], g.cam_fixed[j] != 0, e, A, B);
+        linearize_obs<CNP, true>(g.cfg, g.cam_lin + (size_t)j * kCamLin, X, g.obs_xy[o], g.cam_fixed[j] != 0, e, A, B);
         cost += e[0] * e[0] + e[1] * e[1];
         v[0] += B[0][0] * B[0][0] + B[1][0] * B[1][0]; v[1] += B[0][0] * B[0][1] + B[1][0] * B[1][1];
         v[2] += B[0][0] * B[0][2] + B[1][0] * B[1][2]; v[3] += B[0][1] * B[0][1] + B[1][1] * B[1][1];
@@ -797,7 +805,7 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
         const double *row = scr + (size_t)(o - os) * kLongRow;
         const double2 xy = g.obs_xy[o];
         double u, v;
-        project_obs(g.cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, xy, u, v);
+        project_obs<true>(g.cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, xy, u, v);
         const double en0 = xy.x - u, en1 = xy.y - v, e0 = row[22], e1 = row[23];
         cn += en0 * en0 + en1 * en1;
         double pc = 0.0;
@@ -1164,7 +1172,7 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
 // (sba_levmar.c:1393-1433), trial point, cost at p + dp (:1468-1476), dL and ||dp||^2 point parts,
 // and Bundler's max relative residual change (:1552-1561).  One wavefront per batch.
 // ------------------------------------------------------------------------------------------
-template <int CNP>
+template <int CNP, bool FULL>
 __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
 {
     __shared__ double sT[kWave * 3], sX[kMaxPtsBatch * 3];
@@ -1227,7 +1235,7 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
                 jc = j;
             }
             double A[2][CNP], B[2][3];
-            linearize_obs<CNP>(cfg, cl, X, xy, g.cam_fixed[j] != 0, e, A, B);
+            linearize_obs<CNP, FULL>(cfg, cl, X, xy, g.cam_fixed[j] != 0, e, A, B);
             double w0 = 0.0, w1 = 0.0;
 #pragma unroll
             for (int t = 0; t < CNP; ++t) { w0 = fma(A[0][t], da[t], w0); w1 = fma(A[1][t], da[t], w1); }
@@ -1264,8 +1272,8 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
                 for (int r = 0; r < 3; ++r) q[r] = cln[3 * r] * Xn[0] + cln[3 * r + 1] * Xn[1] + cln[3 * r + 2] * Xn[2] + cln[10 + r];
             }
             const double iz = 1.0 / q[2], mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
-            const bool md = cfg.undistort == 2;
-            const double gg = cfg.proj_sign * cln[13] * (md ? 1.0 : 1.0 + cln[14] * r2 + cln[15] * r2 * r2);
+            const bool md = FULL && cfg.undistort == 2;
+            const double gg = cfg.proj_sign * cln[13] * ((!FULL || md) ? 1.0 : 1.0 + cln[14] * r2 + cln[15] * r2 * r2);
             double en0 = xy.x - gg * mx, en1 = xy.y - gg * my;
             if (md) { const double kk = cln[14] * (xy.x * xy.x + xy.y * xy.y); en0 = fma(kk, xy.x, en0); en1 = fma(kk, xy.y, en1); }
             cn += en0 * en0 + en1 * en1;
@@ -1299,19 +1307,21 @@ void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const 
     hipLaunchKernelGGL(k_cam_prep, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, cam_a, R0, f_fixed, cam_lin);
 }
 
+template <int CNP, bool FULL>
+static void launch_build_t(hipStream_t st, bool lds_mode, int ntiles, const BuildArgs &a)
+{
+    if (lds_mode) hipLaunchKernelGGL((k_build<CNP, true, FULL>), dim3(ntiles), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_build<CNP, false, FULL>), dim3(ntiles), dim3(64), 0, st, a);
+}
+
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a)
 {
     if (ntiles <= 0) return;
-    if (cnp == 8) {
-        if (lds_mode) hipLaunchKernelGGL((k_build<8, true>), dim3(ntiles), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_build<8, false>), dim3(ntiles), dim3(64), 0, st, a);
-    } else if (cnp == 7) {
-        if (lds_mode) hipLaunchKernelGGL((k_build<7, true>), dim3(ntiles), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_build<7, false>), dim3(ntiles), dim3(64), 0, st, a);
-    } else {
-        if (lds_mode) hipLaunchKernelGGL((k_build<6, true>), dim3(ntiles), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_build<6, false>), dim3(ntiles), dim3(64), 0, st, a);
-    }
+    // the lean instantiation unless the problem carries soft point constraints or measurement distortion
+    const bool full = a.pt_cw != nullptr || a.cfg.undistort != 0;
+    if (cnp == 8) { if (full) launch_build_t<8, true>(st, lds_mode, ntiles, a); else launch_build_t<8, false>(st, lds_mode, ntiles, a); }
+    else if (cnp == 7) { if (full) launch_build_t<7, true>(st, lds_mode, ntiles, a); else launch_build_t<7, false>(st, lds_mode, ntiles, a); }
+    else { if (full) launch_build_t<6, true>(st, lds_mode, ntiles, a); else launch_build_t<6, false>(st, lds_mode, ntiles, a); }
 }
 
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
@@ -1366,9 +1376,10 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, cons
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
 {
     if (a.nbatch <= 0) return;
-    if (cnp == 8) hipLaunchKernelGGL((k_backsub<8>), dim3(a.ngrid), dim3(64), 0, st, a);
-    else if (cnp == 7) hipLaunchKernelGGL((k_backsub<7>), dim3(a.ngrid), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_backsub<6>), dim3(a.ngrid), dim3(64), 0, st, a);
+    const bool full = a.cfg.undistort != 0;
+    if (cnp == 8) { if (full) hipLaunchKernelGGL((k_backsub<8, true>), dim3(a.ngrid), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_backsub<8, false>), dim3(a.ngrid), dim3(64), 0, st, a); }
+    else if (cnp == 7) { if (full) hipLaunchKernelGGL((k_backsub<7, true>), dim3(a.ngrid), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_backsub<7, false>), dim3(a.ngrid), dim3(64), 0, st, a); }
+    else hipLaunchKernelGGL((k_backsub<6, false>), dim3(a.ngrid), dim3(64), 0, st, a);
 }
 
 void launch_long_build(hipStream_t st, int cnp, const LongArgs &a)
