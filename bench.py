@@ -146,7 +146,7 @@ def main():
                        "pcg_tol": args.pcg_tol, "pcg_maxit": args.pcg_maxit},
             "rmse_px": {"initial": rmse0, "after_timed_steps": rmse_after},
             "accepted_steps": int((tr[:, 4] == 1).sum()), "trials": int(len(tr)),
-            "pcg_iters_per_step": tm["pcg_iters"] / max(tm["pcg_solves"], 1),
+            "pcg_iters_per_step": tm["pcg_iters"] / max(tm["pcg_solves"], 1), "pcg_resumes": int(tm["pcg_resumes"]),
             "kernel_ms_per_step": {"build": build_ms, "pcg": tm["pcg_ms"] / max(tm["pcg_solves"], 1),
                                    "backsub": tm["backsub_ms"] / max(tm["backsub_launches"], 1),
                                    "allreduce_host": tm["allreduce_ms"] / max(tm["allreduces"], 1) if world > 1 else 0.0},

@@ -144,7 +144,8 @@ typedef struct {
     double step_ms, steps;                 /* whole trial incl. host control */
     double allreduce_ms, allreduces;
     double build_bytes;                    /* algorithmic HBM bytes of one build launch */
-    double reserved[5];
+    double pcg_resumes;                    /* solves whose unchecked first run of PCG iterations fell short (engine.cpp solve_phase) */
+    double reserved[4];
 } mi_ba_timing;
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_reset_timing(mi_ba_engine *e);

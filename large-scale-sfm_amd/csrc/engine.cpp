@@ -416,11 +416,8 @@ bool Engine::linear_phase(double mu, bool want_diag)
     return hipok(hipGetLastError(), "launch (linear phase)");
 }
 
-// PCG on S da = E, camera update, back-substitution, cost at the trial point
-bool Engine::solve_phase(double mu, double *dB_dev)
+PcgArgs Engine::pcg_args()
 {
-    const Plan &pl = plan_;
-    const ModelCfg mc = model();
     const size_t vec = (size_t)m_ * kCP;
     PcgArgs p{};
     p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_full_.p; p.Minv = d_Minv_.p; p.E = d_E_.p;
@@ -429,24 +426,56 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     p.ng = (m_ + 7) / 8;
     p.rz_hist = d_rzpq_.p; p.rzp = d_rzpq_.p + (cfg.pcg_maxit + 4); p.pqp = p.rzp + 2 * (size_t)p.ng;
     p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = m_; p.it = 0;
-    if (!hipok(hipMemsetAsync(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double), st_), "memset rz/pq")) return false;
-    (void)hipEventRecord(ev_[2], st_);
-    launch_pcg_init(st_, p);
-    int it = 0;
-    const int nrz = cfg.pcg_maxit + 4;
+    return p;
+}
+
+// PCG iterations [it0, pcg_maxit) in chunks with a host check after each (device-side convergence is sticky)
+bool Engine::pcg_chunks(int it0)
+{
+    PcgArgs p = pcg_args();
+    int it = it0;
     while (it < cfg.pcg_maxit) {
         const int chunk = std::min(kPcgChunk, cfg.pcg_maxit - it);
         for (int c = 0; c < chunk; ++c) { p.it = it + c; launch_pcg_iter(st_, p); }
         it += chunk;
-        p.it = it; launch_pcg_tail(st_, p); // rz_hist[it] for the host's convergence check
-        if (!hipok(hipMemcpyAsync(h_scal_ + 64, d_rzpq_.p, sizeof(double) * nrz, hipMemcpyDeviceToHost, st_), "copy rz")) return false;
+        p.it = it; launch_pcg_tail(st_, p); // rz_hist[it] and the converged flag after the chunk's last update
         if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
         if (!hipok(hipStreamSynchronize(st_), "sync (pcg)")) return false;
-        const double *rz = h_scal_ + 64;
-        (void)rz;
         if (h_scal_[SC_PCG_STATUS] != 0.0 || h_scal_[SC_PCG_DONE] != 0.0) break;
     }
+    return true;
+}
+
+// PCG on S da = E.  A host check costs a round trip during which the GPU idles, so after the first solve the
+// iteration count of the previous solve (+ slack) is enqueued in one go, checked once, and only a guess that fell
+// short continues in checked chunks.  Iterations past convergence are no-op launches (sticky device-side flag).
+bool Engine::solve_phase(double mu, double *dB_dev)
+{
+    PcgArgs p = pcg_args();
+    if (!hipok(hipMemsetAsync(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double), st_), "memset rz/pq")) return false;
+    (void)hipEventRecord(ev_[2], st_);
+    launch_pcg_init(st_, p);
+    int it0 = 0;
+    if (pcg_pred_ > kPcgChunk) {
+        it0 = std::min(cfg.pcg_maxit, pcg_pred_ + 2);
+        for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
+        p.it = it0; launch_pcg_tail(st_, p);
+        if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
+        if (!hipok(hipStreamSynchronize(st_), "sync (pcg)")) return false;
+        if (h_scal_[SC_PCG_STATUS] != 0.0 || h_scal_[SC_PCG_DONE] != 0.0) it0 = cfg.pcg_maxit;   // nothing left to do
+        else timing.pcg_resumes += 1;
+    }
+    if (it0 < cfg.pcg_maxit && !pcg_chunks(it0)) return false;
+    pcg_pred_ = (int)h_scal_[SC_PCG_ITERS];
     (void)hipEventRecord(ev_[3], st_);
+    return update_phase(mu, dB_dev);
+}
+
+// camera update, back-substitution, cost at the trial point
+bool Engine::update_phase(double mu, double *dB_dev)
+{
+    const Plan &pl = plan_;
+    const ModelCfg mc = model();
     launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, links_,
                       d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part_.p, d_stage_.p, scal_());
     BacksubArgs b{};

@@ -73,6 +73,10 @@ private:
     bool hipok(hipError_t e, const char *what);
     bool linear_phase(double mu, bool want_diag);                 // cam_prep .. build .. all-reduce .. finalize .. block_inv
     bool solve_phase(double mu, double *dB_dev);  // pcg .. cam_update .. backsub .. all-reduce
+    bool update_phase(double mu, double *dB_dev);
+    bool pcg_chunks(int it0);
+    PcgArgs pcg_args();
+    int pcg_pred_ = 0;                            // iterations of the previous solve
     bool read_scalars();
     bool allreduce1();
     bool allreduce2();
