@@ -268,3 +268,74 @@ class Plan:
         if getattr(self, "h", None):
             self.L.mi_ba_plan_free(self.h)
             self.h = None
+
+
+# ---- multi-view triangulation (include/mi_triangulate.h) -------------------------------------------------------
+class TriConfig(C.Structure):
+    _fields_ = [("min_views", C.c_int), ("min_angle_deg", C.c_double), ("max_error", C.c_double),
+                ("float_normalise", C.c_int), ("polish", C.c_int), ("device", C.c_int), ("reserved", C.c_int * 6)]
+
+
+class Triangulator:
+    """tracks -> 3-D points on the GPU, the pipeline's TriangulationMultiStep loop"""
+
+    def __init__(self, **kw):
+        L = self.L = lib()
+        L.mi_tri_create.restype = C.c_void_p; L.mi_tri_create.argtypes = [C.POINTER(TriConfig)]
+        L.mi_tri_last_error.restype = C.c_char_p; L.mi_tri_last_error.argtypes = [C.c_void_p]
+        L.mi_tri_destroy.argtypes = [C.c_void_p]; L.mi_tri_run.argtypes = [C.c_void_p]
+        L.mi_tri_set_cameras.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp]
+        L.mi_tri_set_tracks.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _dp]
+        L.mi_tri_get.argtypes = [C.c_void_p, _dp, _dp, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.mi_tri_last_ms.restype = C.c_double; L.mi_tri_last_ms.argtypes = [C.c_void_p]
+        L.mi_tri_algorithmic_bytes.restype = C.c_double; L.mi_tri_algorithmic_bytes.argtypes = [C.c_void_p]
+        cfg = TriConfig()
+        L.mi_tri_default_config(C.byref(cfg))
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = L.mi_tri_create(C.byref(cfg))
+        if not self.h:
+            raise RuntimeError("mi_tri_create failed: " + L.mi_tri_last_error(None).decode())
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(what + ": " + self.L.mi_tri_last_error(self.h).decode())
+
+    def set_cameras(self, f, R, t, c=None):
+        f = np.ascontiguousarray(f, np.float64); R = np.ascontiguousarray(R, np.float64).reshape(-1)
+        t = np.ascontiguousarray(t, np.float64).reshape(-1)
+        c = None if c is None else np.ascontiguousarray(c, np.float64).reshape(-1)
+        self._chk(self.L.mi_tri_set_cameras(self.h, len(f), _d(f), _d(R), _d(t), _d(c)), "set_cameras")
+
+    def set_tracks(self, pt_ptr, obs_cam, xy):
+        self._keep = (np.ascontiguousarray(pt_ptr, np.int32), np.ascontiguousarray(obs_cam, np.int32),
+                      np.ascontiguousarray(xy, np.float64).reshape(-1))
+        p, o, x = self._keep
+        self.n = len(p) - 1
+        self._chk(self.L.mi_tri_set_tracks(self.h, self.n, p.ctypes.data_as(_ip), o.ctypes.data_as(_ip), _d(x)), "set_tracks")
+
+    def run(self):
+        self._chk(self.L.mi_tri_run(self.h), "run")
+        return self.L.mi_tri_last_ms(self.h)
+
+    def get(self):
+        n = self.n
+        xyz = np.zeros((n, 3)); err = np.zeros(n); status = np.zeros(n, np.int32)
+        counts = (C.c_int64 * 4)(); s = C.c_double(0); npj = C.c_int64(0)
+        self._chk(self.L.mi_tri_get(self.h, _d(xyz), _d(err), status.ctypes.data_as(_ip), counts, C.byref(s), C.byref(npj)), "get")
+        return dict(xyz=xyz, err=err, status=status, counts=list(counts), sum_sq_px=s.value, nproj=npj.value)
+
+    def algorithmic_bytes(self):
+        return self.L.mi_tri_algorithmic_bytes(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.mi_tri_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

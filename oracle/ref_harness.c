@@ -23,6 +23,7 @@
 #include <string.h>
 #include "sba.h"
 #include "sfm.h"
+#include "triangulate.h"
 
 typedef struct {
     camera_params_t *cams;
@@ -213,4 +214,19 @@ void ref_run_sfm_cons(int n, int m, int ncons, const int *pt_ptr, const int *obs
     }
     for (i = 0; i < n; ++i) { pts[3 * i] = Vx(P[i]); pts[3 * i + 1] = Vy(P[i]); pts[3 * i + 2] = Vz(P[i]); }
     free(vmask); free(cams); free(xx); free(P);
+}
+
+/* Bundler's triangulate_n (imagelib/triangulate.c:181-275) as is: the routine the pipeline's triangulation step copies
+ * (TriangulationMultiStep.cpp:566-672 differs only in how the returned error is normalised).  pv 2*nv, Rs 9*nv, ts 3*nv. */
+void ref_triangulate_n(int nv, const double *pv, const double *Rs, const double *ts, double *X, double *err)
+{
+    v2_t *p = (v2_t *)malloc(sizeof(v2_t) * nv);
+    double *R = (double *)malloc(sizeof(double) * 9 * nv), *t = (double *)malloc(sizeof(double) * 3 * nv);
+    int i;
+    v3_t r;
+    for (i = 0; i < nv; ++i) { Vx(p[i]) = pv[2 * i]; Vy(p[i]) = pv[2 * i + 1]; }
+    memcpy(R, Rs, sizeof(double) * 9 * nv); memcpy(t, ts, sizeof(double) * 3 * nv);
+    r = triangulate_n(nv, p, R, t, err);
+    X[0] = Vx(r); X[1] = Vy(r); X[2] = Vz(r);
+    free(p); free(R); free(t);
 }

@@ -208,3 +208,30 @@ def degenerate_scene(seed=5):
     return scene.Scene(n=base.n, m=base.m, cnp=base.cnp, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0,
                        pt_ptr=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32), obs_cam=base.obs_cam[sel],
                        x=base.x[sel], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true, name="degenerate")
+
+
+# ---- triangulation step (include/mi_triangulate.h) --------------------------------------------------------------
+def tri_scene(seed=21, m=24, n=1500, d=6, noise_px=0.3):
+    """cameras (f, R, t, centres) at the true poses of a seeded scene and its tracks, made awkward on purpose:
+    views of cameras outside the model (index -1), tracks with too few views, a far point seen under a narrow angle,
+    a few gross outliers, a point behind a camera"""
+    sc = vsfm_scene(m=m, n=n, d=d, seed=seed, noise_px=noise_px, strides=(1, 2, 3))
+    rng = np.random.default_rng(seed + 7)
+    cnp = sc.cnp
+    a = sc.p_true[:m * cnp].reshape(m, cnp)
+    R = np.einsum("mij,mjk->mik", rodrigues(a[:, 3:6]), sc.R0.reshape(m, 3, 3))
+    t = a[:, :3].copy(); f = a[:, 6] / 0.001
+    c = -np.einsum("mji,mj->mi", R, t)
+    cam = sc.obs_cam.copy(); xy = sc.x.copy()
+    cam[rng.random(len(cam)) < 0.08] = -1                        # views of cameras that are not part of the model
+    for i in range(0, n, 40):                                    # tracks left with a single usable view
+        cam[sc.pt_ptr[i] + 1:sc.pt_ptr[i + 1]] = -1
+    for i in range(7, n, 53):                                    # gross outlier in one view
+        xy[sc.pt_ptr[i]] += 150.0
+    X = sc.p_true[m * cnp:].reshape(n, 3)
+    for i in range(13, n, 97):                                   # a far point: rays nearly parallel
+        o = slice(sc.pt_ptr[i], sc.pt_ptr[i + 1])
+        far = X[i] * 4000.0
+        q = np.einsum("kij,j->ki", R[sc.obs_cam[o]], far) + t[sc.obs_cam[o]]
+        xy[o] = f[sc.obs_cam[o], None] * q[:, :2] / q[:, 2:3]
+    return dict(f=f, R=R.reshape(m, 9), t=t, c=c, pt_ptr=sc.pt_ptr.astype(np.int32), obs_cam=cam.astype(np.int32), xy=xy, X_true=X, m=m, n=n)
