@@ -8,7 +8,9 @@
 // 52 B per track out) -- the arithmetic is a few hundred flops per view.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -27,7 +29,7 @@ struct TriArgs {
     const double2 *xy;
     double *xyz, *err, *sumsq;
     int *status, *nviews;
-    int n, min_views, float_normalise, polish;
+    int n, min_views, float_normalise, polish, stage_cap;
     double min_angle_deg, max_error;
 };
 
@@ -45,16 +47,41 @@ __device__ __forceinline__ bool solve3(const double H[6], const double g[3], dou
     return true;
 }
 
+constexpr int kTriBlock = 64;     // tracks per workgroup = one wavefront
+constexpr int kTriStage = 1024;   // views a workgroup may stage through LDS (20 KB); longer ranges read HBM / L2 directly
+
 // normalised measurement of a view (TriangulationMultiStep.cpp:1223-1228: a cv::Point2f, hence the float)
-__device__ __forceinline__ void view_pv(const TriArgs &a, int o, double f, double &px, double &py)
+__device__ __forceinline__ void normalise(const TriArgs &a, double2 m, double f, double &px, double &py)
 {
-    const double2 m = a.xy[o];
     px = m.x / f; py = m.y / f;
     if (a.float_normalise) { px = (double)(float)px; py = (double)(float)py; }
 }
 
+// the views of a workgroup's tracks: a contiguous range of the measurement stream, staged once (coalesced, already
+// normalised) in LDS when it fits, else read in place
+struct Views {
+    const TriArgs &a;
+    const double2 *spv; const int *scam;   // LDS images, index o - base
+    int base; bool staged;
+    __device__ __forceinline__ int cam(int o) const { return staged ? scam[o - base] : a.obs_cam[o]; }
+    __device__ __forceinline__ void pv(int o, double f, double &px, double &py) const
+    {
+        if (staged) { const double2 v = spv[o - base]; px = v.x; py = v.y; }
+        else normalise(a, a.xy[o], f, px, py);
+    }
+};
+
+// the 128-B camera record as eight 16-B loads: the gather is bound by the address pipeline (64 lanes, 64 different
+// cameras), so half as many load instructions is half the time
+__device__ __forceinline__ void load_cam(const double *__restrict__ table, int j, double cr[kCamRec])
+{
+    const double2 *p = reinterpret_cast<const double2 *>(table + (size_t)j * kCamRec);
+#pragma unroll
+    for (int k = 0; k < kCamRec / 2; ++k) { const double2 v = p[k]; cr[2 * k] = v.x; cr[2 * k + 1] = v.y; }
+}
+
 // residual of triangulate_n_residual (:548-563) with project() (:533-547)
-__device__ __forceinline__ void resid(const double *__restrict__ cr, double px, double py, const double X[3], double &f0, double &f1, double &depth)
+__device__ __forceinline__ void resid(const double *cr, double px, double py, const double X[3], double &f0, double &f1, double &depth)
 {
     const double q0 = (cr[0] * X[0] + cr[1] * X[1] + cr[2] * X[2]) + cr[9];
     const double q1 = (cr[3] * X[0] + cr[4] * X[1] + cr[5] * X[2]) + cr[10];
@@ -62,15 +89,15 @@ __device__ __forceinline__ void resid(const double *__restrict__ cr, double px, 
     f0 = px - q0 / q2; f1 = py - q1 / q2; depth = q2;
 }
 
-__device__ double fnorm2(const TriArgs &a, int o0, int o1, const double X[3])
+__device__ double fnorm2(const Views &V, int o0, int o1, const double X[3])
 {
     double s = 0.0;
     for (int o = o0; o < o1; ++o) {
-        const int j = a.obs_cam[o];
+        const int j = V.cam(o);
         if (j < 0) continue;
-        const double *cr = a.cam + (size_t)j * kCamRec;
-        double px, py, f0, f1, dz;
-        view_pv(a, o, cr[15], px, py);
+        double cr[kCamRec], px, py, f0, f1, dz;
+        load_cam(V.a.cam, j, cr);
+        V.pv(o, cr[15], px, py);
         resid(cr, px, py, X, f0, f1, dz);
         s += f0 * f0 + f1 * f1;
     }
@@ -78,7 +105,7 @@ __device__ double fnorm2(const TriArgs &a, int o0, int o1, const double X[3])
 }
 
 // fdjac2 (forward differences, h = sqrt(epsmch) |x_j|) folded into N = J^T J and g = J^T f
-__device__ void fd_normal(const TriArgs &a, int o0, int o1, const double X[3], double N[6], double g[3])
+__device__ void fd_normal(const Views &V, int o0, int o1, const double X[3], double N[6], double g[3])
 {
     const double eps = 1.4901161193847656e-08; // sqrt(2^-52)
     double h[3];
@@ -88,11 +115,11 @@ __device__ void fd_normal(const TriArgs &a, int o0, int o1, const double X[3], d
     for (int k = 0; k < 6; ++k) N[k] = 0.0;
     g[0] = g[1] = g[2] = 0.0;
     for (int o = o0; o < o1; ++o) {
-        const int jc = a.obs_cam[o];
+        const int jc = V.cam(o);
         if (jc < 0) continue;
-        const double *cr = a.cam + (size_t)jc * kCamRec;
-        double px, py, f0, f1, dz, J[2][3];
-        view_pv(a, o, cr[15], px, py);
+        double cr[kCamRec], px, py, f0, f1, dz, J[2][3];
+        load_cam(V.a.cam, jc, cr);
+        V.pv(o, cr[15], px, py);
         resid(cr, px, py, X, f0, f1, dz);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -157,15 +184,15 @@ __device__ void lmpar3(const double N[6], const double g[3], const double diag[3
 
 // MINPACK lmdif1(tol) = lmdif(ftol = xtol = tol, gtol 0, maxfev 200 (n+1), epsfcn 0, mode 1, factor 100)
 // (cminpack lmdif1.c, lmdif.c), n = 3
-__device__ void lmdif3(const TriArgs &a, int o0, int o1, double X[3], double tol)
+__device__ void lmdif3(const Views &V, int o0, int o1, double X[3], double tol)
 {
     const double epsmch = 2.220446049250313e-16, factor = 100.0;
     const int maxfev = 800;
-    double fnorm = sqrt(fnorm2(a, o0, o1, X)), par = 0.0, delta = 0.0, xnorm = 0.0, diag[3] = { 1.0, 1.0, 1.0 };
+    double fnorm = sqrt(fnorm2(V, o0, o1, X)), par = 0.0, delta = 0.0, xnorm = 0.0, diag[3] = { 1.0, 1.0, 1.0 };
     int nfev = 1, iter = 1;
     for (;;) {
         double N[6], g[3];
-        fd_normal(a, o0, o1, X, N, g);
+        fd_normal(V, o0, o1, X, N, g);
         nfev += 3;
         const double acn[3] = { sqrt(N[0]), sqrt(N[3]), sqrt(N[5]) };
         if (iter == 1) {
@@ -189,7 +216,7 @@ __device__ void lmdif3(const TriArgs &a, int o0, int o1, double X[3], double tol
             for (int j = 0; j < 3; ++j) { p[j] = -x[j]; Xn[j] = X[j] + p[j]; }
             const double pnorm = sqrt(diag[0] * p[0] * diag[0] * p[0] + diag[1] * p[1] * diag[1] * p[1] + diag[2] * p[2] * diag[2] * p[2]);
             if (iter == 1) delta = fmin(delta, pnorm);
-            const double fnorm1 = sqrt(fnorm2(a, o0, o1, Xn));
+            const double fnorm1 = sqrt(fnorm2(V, o0, o1, Xn));
             ++nfev;
             double actred = -1.0;
             if (0.1 * fnorm1 < fnorm) actred = 1.0 - (fnorm1 / fnorm) * (fnorm1 / fnorm);
@@ -245,60 +272,91 @@ __device__ __forceinline__ double ray_angle_deg(const double *__restrict__ ca, c
     return acos(cs) * (180.0 / 3.14159265358979323846);
 }
 
-__global__ __launch_bounds__(256) void k_triangulate(const TriArgs a)
+// POLISH is a template parameter because lmdif's state triples the register count: the common case keeps its occupancy
+template <bool POLISH>
+__global__ __launch_bounds__(kTriBlock) void k_triangulate(const TriArgs a)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ double2 sDyn[];
+    double2 *sPv = sDyn;
+    int *sCam = reinterpret_cast<int *>(sDyn + a.stage_cap);
+    const int i0 = blockIdx.x * kTriBlock, i = i0 + threadIdx.x;
+    const int ob0 = a.pt_ptr[i0], ob1 = a.pt_ptr[min(i0 + kTriBlock, a.n)];
+    Views V{ a, sPv, sCam, ob0, ob1 - ob0 <= a.stage_cap };
+    if (V.staged) {
+        for (int k = threadIdx.x; k < ob1 - ob0; k += kTriBlock) {
+            const int j = a.obs_cam[ob0 + k];
+            double px = 0.0, py = 0.0;
+            if (j >= 0) normalise(a, a.xy[ob0 + k], a.cam[(size_t)j * kCamRec + 15], px, py);
+            sCam[k] = j; sPv[k] = make_double2(px, py);
+        }
+        __syncthreads();
+    }
     if (i >= a.n) return;
     const int o0 = a.pt_ptr[i], o1 = a.pt_ptr[i + 1];
     double X[3] = { 0.0, 0.0, 0.0 }, err = -1.0, sumsq = 0.0;
     int status = MI_TRI_FEW_VIEWS, nv = 0;
-    for (int o = o0; o < o1; ++o) nv += a.obs_cam[o] >= 0;
+    for (int o = o0; o < o1; ++o) nv += V.cam(o) >= 0;
     if (nv >= a.min_views && nv >= 2) {
-        // one pair of rays above the angle (:1251-1265)
+        // ONE gather of each view's camera serves two things: the normal equations of the linear system (:580-600:
+        // rows (R0 - x R2) X = t2 x - t0, (R1 - y R2) X = t2 y - t1) and the ray-angle test of the pairs (first view, b)
+        // (:1251-1265 asks whether ANY pair of rays is more than min_angle apart; the order it looks in does not matter)
         bool conditioned = false;
-        for (int oa = o0; oa < o1 && !conditioned; ++oa) {
-            const int ja = a.obs_cam[oa];
+        int ofirst = -1;
+        double r0[3] = { 0.0, 0.0, 0.0 }, n0 = 0.0;
+        double H[6] = { 0, 0, 0, 0, 0, 0 }, g[3] = { 0, 0, 0 };
+        for (int o = o0; o < o1; ++o) {
+            const int j = V.cam(o);
+            if (j < 0) continue;
+            double cr[kCamRec], x, y, a0[3], a1[3], rw[3];
+            load_cam(a.cam, j, cr);
+            V.pv(o, cr[15], x, y);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                a0[k] = cr[k] - x * cr[6 + k]; a1[k] = cr[3 + k] - y * cr[6 + k];
+                const double u = cr[k] * x + cr[3 + k] * y + cr[6 + k] * 1.0;      // ComputeRayAngle :505-521
+                rw[k] = (u + cr[12 + k]) - cr[12 + k];
+            }
+            const double b0 = cr[11] * x - cr[9], b1 = cr[11] * y - cr[10];
+            H[0] += a0[0] * a0[0] + a1[0] * a1[0]; H[1] += a0[0] * a0[1] + a1[0] * a1[1]; H[2] += a0[0] * a0[2] + a1[0] * a1[2];
+            H[3] += a0[1] * a0[1] + a1[1] * a1[1]; H[4] += a0[1] * a0[2] + a1[1] * a1[2]; H[5] += a0[2] * a0[2] + a1[2] * a1[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] += a0[k] * b0 + a1[k] * b1;
+            const double nn = sqrt(rw[0] * rw[0] + rw[1] * rw[1] + rw[2] * rw[2]);
+            if (ofirst < 0) { ofirst = o; r0[0] = rw[0]; r0[1] = rw[1]; r0[2] = rw[2]; n0 = nn; }
+            else if (!conditioned) {
+                double cs = (r0[0] * rw[0] + r0[1] * rw[1] + r0[2] * rw[2]) / (n0 * nn);
+                cs = cs < -1.0 + 1.0e-8 ? -1.0 + 1.0e-8 : (cs > 1.0 - 1.0e-8 ? 1.0 - 1.0e-8 : cs);
+                conditioned = acos(cs) * (180.0 / 3.14159265358979323846) > a.min_angle_deg;
+            }
+        }
+        // rare: every ray is within the angle of the first one; the remaining pairs decide
+        for (int oa = ofirst + 1; oa < o1 && !conditioned; ++oa) {
+            const int ja = V.cam(oa);
             if (ja < 0) continue;
             const double *ca = a.cam + (size_t)ja * kCamRec;
             double pax, pay;
-            view_pv(a, oa, ca[15], pax, pay);
+            V.pv(oa, ca[15], pax, pay);
             for (int ob = oa + 1; ob < o1; ++ob) {
-                const int jb = a.obs_cam[ob];
+                const int jb = V.cam(ob);
                 if (jb < 0) continue;
                 const double *cb = a.cam + (size_t)jb * kCamRec;
                 double pbx, pby;
-                view_pv(a, ob, cb[15], pbx, pby);
+                V.pv(ob, cb[15], pbx, pby);
                 if (ray_angle_deg(ca, cb, pax, pay, pbx, pby) > a.min_angle_deg) { conditioned = true; break; }
             }
         }
         status = MI_TRI_NARROW;
         if (conditioned) {
-            // linear system (:580-600): rows (R0 - x R2) X = t2 x - t0, (R1 - y R2) X = t2 y - t1
-            double H[6] = { 0, 0, 0, 0, 0, 0 }, g[3] = { 0, 0, 0 };
-            for (int o = o0; o < o1; ++o) {
-                const int j = a.obs_cam[o];
-                if (j < 0) continue;
-                const double *cr = a.cam + (size_t)j * kCamRec;
-                double x, y, a0[3], a1[3];
-                view_pv(a, o, cr[15], x, y);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { a0[k] = cr[k] - x * cr[6 + k]; a1[k] = cr[3 + k] - y * cr[6 + k]; }
-                const double b0 = cr[11] * x - cr[9], b1 = cr[11] * y - cr[10];
-                H[0] += a0[0] * a0[0] + a1[0] * a1[0]; H[1] += a0[0] * a0[1] + a1[0] * a1[1]; H[2] += a0[0] * a0[2] + a1[0] * a1[2];
-                H[3] += a0[1] * a0[1] + a1[1] * a1[1]; H[4] += a0[1] * a0[2] + a1[1] * a1[2]; H[5] += a0[2] * a0[2] + a1[2] * a1[2];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) g[k] += a0[k] * b0 + a1[k] * b1;
-            }
             if (!solve3(H, g, X)) { X[0] = X[1] = X[2] = 0.0; }
-            if (a.polish) lmdif3(a, o0, o1, X, 1.0e-5);          // lmdif_driver(..., 1.0e-5), :626-630
+            if constexpr (POLISH) lmdif3(V, o0, o1, X, 1.0e-5);  // lmdif_driver(..., 1.0e-5), :626-630
             // errors (:632-661)
             double error = 0.0;
             for (int o = o0; o < o1; ++o) {
-                const int j = a.obs_cam[o];
+                const int j = V.cam(o);
                 if (j < 0) continue;
-                const double *cr = a.cam + (size_t)j * kCamRec;
-                double px, py, f0, f1, dz;
-                view_pv(a, o, cr[15], px, py);
+                double cr[kCamRec], px, py, f0, f1, dz;
+                load_cam(a.cam, j, cr);
+                V.pv(o, cr[15], px, py);
                 resid(cr, px, py, X, f0, f1, dz);
                 const double v = f0 * f0 + f1 * f1, e = sqrt(v);
                 error += v;
@@ -440,7 +498,13 @@ int mi_tri_run(mi_tri_engine *e)
     a.n = e->n; a.min_views = e->cfg.min_views; a.float_normalise = e->cfg.float_normalise; a.polish = e->cfg.polish;
     a.min_angle_deg = e->cfg.min_angle_deg; a.max_error = e->cfg.max_error;
     (void)hipEventRecord(e->ev0, e->st);
-    hipLaunchKernelGGL(k_triangulate, dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->st, a);
+    int cap = kTriStage;
+    if (const char *s = std::getenv("MI_TRI_STAGE")) cap = std::max(0, std::min(atoi(s), 6000));   // experiments
+    a.stage_cap = cap;
+    const size_t lds = (size_t)cap * (sizeof(double2) + sizeof(int));
+    const dim3 grid((unsigned)((e->n + kTriBlock - 1) / kTriBlock)), block(kTriBlock);
+    if (e->cfg.polish) hipLaunchKernelGGL(k_triangulate<true>, grid, block, lds, e->st, a);
+    else hipLaunchKernelGGL(k_triangulate<false>, grid, block, lds, e->st, a);
     (void)hipEventRecord(e->ev1, e->st);
     hipError_t he = hipGetLastError();
     if (he == hipSuccess) he = hipStreamSynchronize(e->st);
