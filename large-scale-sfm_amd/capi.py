@@ -339,3 +339,26 @@ class Triangulator:
             self.close()
         except Exception:
             pass
+
+
+# ---- similarity alignment of two point sets (include/mi_sim3.h) -------------------------------------------------
+class Sim3Config(C.Structure):
+    _fields_ = [("rounds", C.c_int), ("device", C.c_int), ("reserved", C.c_int * 6)]
+
+
+def sim3_align(src, dst, rounds=5000, device=0):
+    """ComputeRigidTransform of the cluster-merge step on the GPU -> dict(scale, R, t, scores, best_round, ms)"""
+    L = lib()
+    L.mi_sim3_last_error.restype = C.c_char_p
+    L.mi_sim3_align.argtypes = [C.POINTER(Sim3Config), C.c_int, _dp, _dp, C.POINTER(C.c_double), _dp, _dp, _dp,
+                                C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    src = np.ascontiguousarray(src, np.float64); dst = np.ascontiguousarray(dst, np.float64)
+    cfg = Sim3Config()
+    L.mi_sim3_default_config(C.byref(cfg))
+    cfg.rounds = rounds; cfg.device = device
+    scale = C.c_double(); R = np.zeros(9); t = np.zeros(3); scores = np.zeros(rounds); best = C.c_int(); ms = C.c_double()
+    rc = L.mi_sim3_align(C.byref(cfg), len(src), _d(src.reshape(-1)), _d(dst.reshape(-1)), C.byref(scale), _d(R), _d(t), _d(scores),
+                         C.byref(best), C.byref(ms))
+    if rc != 0:
+        raise RuntimeError("mi_sim3_align: " + L.mi_sim3_last_error().decode())
+    return dict(scale=scale.value, R=R.reshape(3, 3), t=t, scores=scores, best_round=best.value, ms=ms.value)

@@ -15,7 +15,7 @@ from helpers import model_lib, read_model, vsfm_scene, write_nvm
 def test_library_exports_every_declared_symbol():
     L = pkg("capi").lib()
     names = set()
-    for h in ("mi_ba.h", "mi_model.h", "mi_sfm.h", "mi_triangulate.h"):
+    for h in ("mi_ba.h", "mi_model.h", "mi_sfm.h", "mi_triangulate.h", "mi_sim3.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         names |= set(re.findall(r"\b(mi_[a-z_0-9]+|run_sfm)\s*\(", txt))
