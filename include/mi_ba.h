@@ -154,6 +154,11 @@ int mi_ba_reset_timing(mi_ba_engine *e);
 #define MI_BA_UNIQUE_ID_BYTES 128
 int mi_ba_comm_unique_id(char id[MI_BA_UNIQUE_ID_BYTES]);                 /* rank 0 */
 int mi_ba_comm_init(mi_ba_engine *e, const char id[MI_BA_UNIQUE_ID_BYTES]); /* every rank, before prepare */
+/* test transport: instead of RCCL, every exchange goes device -> host, through `fn` (which must leave the element-wise
+ * sum (op 0) or maximum (op 1) over all ranks in buf), and back.  Lets the sharded engine be exercised by several
+ * processes that share ONE GPU (tests/test_sharding_gpu.py, gloo underneath); never used by bench.py. */
+typedef int (*mi_ba_host_allreduce_fn)(void *user, double *buf, int64_t count, int op);
+int mi_ba_comm_set_host_allreduce(mi_ba_engine *e, mi_ba_host_allreduce_fn fn, void *user);
 
 /* ---- planner (host only; usable without a GPU) -------------------------------------------
  * Same code the engine runs in mi_ba_prepare: point permutation (visibility-signature sort),

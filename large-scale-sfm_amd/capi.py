@@ -52,6 +52,9 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int)
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -70,6 +73,7 @@ def lib() -> C.CDLL:
             "mi_ba_reset_timing": [vp], "mi_ba_set_cameras": [vp, i32, dp, dp, dp], "mi_ba_set_points": [vp, i32, dp],
             "mi_ba_set_observations": [vp, i64, dp, ip, ip], "mi_ba_set_camera_constraints": [vp, dp, dp],
             "mi_ba_set_camera_links": [vp, C.c_int, ip, ip, dp],
+            "mi_ba_comm_set_host_allreduce": [vp, HOST_ALLREDUCE, vp],
             "mi_ba_set_point_constraints": [vp, dp, dp], "mi_ba_set_fixed_cameras": [vp, C.c_void_p], "mi_ba_run": [vp, dp], "mi_ba_get_info": [vp, dp],
             "mi_ba_get_trace": [vp, dp, i32], "mi_ba_get_params": [vp, dp, dp], "mi_ba_set_params": [vp, dp, dp],
             "mi_ba_get_rotations": [vp, dp], "mi_ba_debug_linearize": [vp, dbl, dp, dp, dp, dp, dp, dp, dp],
@@ -136,6 +140,19 @@ class Engine:
                          np.ascontiguousarray(p0[m * cnp:]).reshape(n, 3), sc.x, sc.obs_pt(), sc.obs_cam)
         cons = getattr(sc, "constraints", None) or {}
         self.set_constraints(cons.get("cam_cw"), cons.get("cam_cv"), cons.get("pt_cw"), cons.get("pt_cv"))
+
+    def set_host_allreduce(self, fn):
+        """test transport (mi_ba.h): fn(np.ndarray view, op) must reduce the buffer in place over all ranks (op 0 sum, 1 max)"""
+        def thunk(_user, buf, count, op):
+            try:
+                fn(np.ctypeslib.as_array(buf, shape=(count,)), op)
+                return 0
+            except Exception:      # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return -1
+        self._host_ar = HOST_ALLREDUCE(thunk)
+        self._chk(self.L.mi_ba_comm_set_host_allreduce(self.h, self._host_ar, None), "set_host_allreduce")
 
     def set_camera_links(self, cam_a, cam_b, weights):
         """quadratic couplings w[q, r] (a[cam_a[q], r] - a[cam_b[q], r])^2 (PBA's shared-intrinsics constraints)"""

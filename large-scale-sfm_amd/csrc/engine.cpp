@@ -174,7 +174,7 @@ int Engine::prepare()
     if (!created_) return MI_BA_ERROR;
     if (!m_ || !n_ || !nobs_) { err = "prepare: cameras, points and observations must be set first"; return MI_BA_ERROR; }
     if (cfg.mcon < 0 || cfg.mcon > m_) { err = "prepare: bad mcon"; return MI_BA_ERROR; }
-    if (cfg.world > 1 && !comm_) { err = "prepare: world > 1 needs mi_ba_comm_init first"; return MI_BA_ERROR; }
+    if (cfg.world > 1 && !comm_ && !host_ar_) { err = "prepare: world > 1 needs mi_ba_comm_init first"; return MI_BA_ERROR; }
     if (cfg.world == 1 && !comm_ && std::getenv("MI_BA_FORCE_COMM")) {
         // test hook: run the RCCL exchange on a one-rank communicator, so the collective calls (buffers,
         // counts, stream) are exercised on a single-GPU box
@@ -349,25 +349,37 @@ int Engine::set_params(const double *a, const double *xyz)
     return 0;
 }
 
+// one element-wise reduction over the ranks, in place on the device: RCCL on the engine's stream, or (tests only)
+// the host callback
+bool Engine::exchange(double *dev, size_t count, int op)
+{
+    if (host_ar_) {
+        h_ar_.resize(count);
+        if (!hipok(hipMemcpyAsync(h_ar_.data(), dev, count * sizeof(double), hipMemcpyDeviceToHost, st_), "exchange: download") ||
+            !hipok(hipStreamSynchronize(st_), "exchange: sync")) return false;
+        if (host_ar_(host_ar_user_, h_ar_.data(), (int64_t)count, op) != 0) return fail("host all-reduce callback failed");
+        return hipok(hipMemcpyAsync(dev, h_ar_.data(), count * sizeof(double), hipMemcpyHostToDevice, st_), "exchange: upload") &&
+               hipok(hipStreamSynchronize(st_), "exchange: sync");
+    }
+    ncclResult_t r = ncclAllReduce(dev, dev, count, ncclDouble, op ? ncclMax : ncclSum, (ncclComm_t)comm_, st_);
+    if (r != ncclSuccess) return fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    return true;
+}
+
 bool Engine::allreduce1()
 {
-    if (!comm_) return true;
+    if (!comm_ && !host_ar_) return true;
     double t0 = now_ms();
     const size_t nsum = (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP + 8;
-    ncclResult_t r = ncclAllReduce(d_acc_.p, d_acc_.p, nsum, ncclDouble, ncclSum, (ncclComm_t)comm_, st_);
-    if (r == ncclSuccess) r = ncclAllReduce(scal_() + 8, scal_() + 8, 8, ncclDouble, ncclMax, (ncclComm_t)comm_, st_);
-    if (r != ncclSuccess) return fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    if (!exchange(d_acc_.p, nsum, 0) || !exchange(scal_() + 8, 8, 1)) return false;
     timing.allreduce_ms += now_ms() - t0; timing.allreduces += 1;
     return true;
 }
 
 bool Engine::allreduce2()
 {
-    if (!comm_) return true;
-    ncclResult_t r = ncclAllReduce(scal_() + 32, scal_() + 32, 8, ncclDouble, ncclSum, (ncclComm_t)comm_, st_);
-    if (r == ncclSuccess) r = ncclAllReduce(scal_() + 40, scal_() + 40, 8, ncclDouble, ncclMax, (ncclComm_t)comm_, st_);
-    if (r != ncclSuccess) return fail(std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-    return true;
+    if (!comm_ && !host_ar_) return true;
+    return exchange(scal_() + 32, 8, 0) && exchange(scal_() + 40, 8, 1);
 }
 
 LongArgs Engine::long_args(double mu, bool want_diag, double *dB_dev, int part_row0)
@@ -653,8 +665,7 @@ int Engine::get_params(double *a, double *xyz)
             for (size_t t = 0; t < npl; ++t)
                 for (int r = 0; r < 3; ++r) full[3 * (size_t)pl.perm[pl.pt_begin + t] + r] = pp[3 * t + r];
             if (!hipok(hipMemcpy(d_full_pts_.p, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice), "upload full pts")) return MI_BA_ERROR;
-            ncclResult_t r = ncclAllReduce(d_full_pts_.p, d_full_pts_.p, full.size(), ncclDouble, ncclSum, (ncclComm_t)comm_, st_);
-            if (r != ncclSuccess) { err = std::string("ncclAllReduce: ") + ncclGetErrorString(r); return MI_BA_ERROR; }
+            if (!exchange(d_full_pts_.p, full.size(), 0)) return MI_BA_ERROR;
             if (!hipok(hipStreamSynchronize(st_), "sync")) return MI_BA_ERROR;
             if (!hipok(hipMemcpy(full.data(), d_full_pts_.p, full.size() * sizeof(double), hipMemcpyDeviceToHost), "download full pts")) return MI_BA_ERROR;
             for (int t = 0; t < pl.n_active; ++t)

@@ -45,6 +45,7 @@ public:
 
     int set_cameras(int m, const double *a0, const double *R0, const double *f_fixed);
     int set_fixed_cameras(const unsigned char *mask);
+    int set_host_allreduce(mi_ba_host_allreduce_fn fn, void *user) { host_ar_ = fn; host_ar_user_ = user; return 0; }
     int set_camera_constraints(const double *weights, const double *values);
     int set_camera_links(int nlink, const int *cam_a, const int *cam_b, const double *weights);
     int set_point_constraints(const double *weight, const double *values);
@@ -88,6 +89,10 @@ private:
     hipStream_t st_ = nullptr;
     hipEvent_t ev_[8] = {};
     void *comm_ = nullptr; // ncclComm_t
+    mi_ba_host_allreduce_fn host_ar_ = nullptr;   // test transport: the exchange through a host callback instead of RCCL
+    void *host_ar_user_ = nullptr;
+    std::vector<double> h_ar_;
+    bool exchange(double *dev, size_t count, int op);   // op 0 sum, 1 max; RCCL or the host callback
 
     // host problem
     int m_ = 0, n_ = 0;
