@@ -336,7 +336,7 @@ __device__ __forceinline__ void pair_block(const double *sR, const double *sv, i
 #endif
 
 template <int CNP, bool LDS, bool FULL>
-__global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArgs g) // 8x8 blocks: 128 accumulator VGPRs, one wave per SIMD
+__global__ __launch_bounds__(64, (CNP <= 7 && LDS ? 2 : 1)) void k_build(const BuildArgs g) // 8x8 blocks: 128 accumulator VGPRs, one wave per SIMD
 {
 #ifdef MIBA_STAMPS
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
     // LDS budget: <= 20 KB so that TWO tiles share a SIMD (8 workgroups per CU).  The S blocks live in
     // registers; sStage only transposes them (kStageLanes lanes at a time) into the contiguous 49-double
     // shape a global f64 atomic wants.
-    constexpr int kStageLanes = 5;
-    __shared__ double sStage[LDS ? kStageLanes * BLK : 1], sC[LDS ? kNCSlot * SC : 1];
+    constexpr int kStageLanes = LDS ? 5 : 8;
+    __shared__ double sStage[kStageLanes * BLK], sC[LDS ? kNCSlot * SC : 1];
     __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
     __shared__ int sLp[LDS ? 1 : kWave];      // local point of every observation (direct tiles; LDS tiles carry it in the pair entry)
 
@@ -584,18 +584,43 @@ __global__ __launch_bounds__(64, (CNP <= 7 ? 2 : 1)) void k_build(const BuildArg
                 }
             }
         } else {
-            for (long long q = cur.q0 + lane; q < cur.q1; q += kWave) {
-                const unsigned ent = g.pair[q];
-                const int la = ent & 63, lb = (ent >> 6) & 63;
-                double T0[CNP], T1[CNP];
-                pair_block<CNP, SR>(sR, sV + sLp[la] * SV, la, lb, T0, T1);
-                const double *Aa = sR + la * SR;
-                double *dst = g.S_up + (size_t)g.pair_gblk[q - g.pair_gblk_base] * (kCP * kCP);
+            // direct tiles (points with too many views for the tile's block table): every round of 64 pairs is computed
+            // into registers and handed to HBM at once, kStageLanes blocks at a time through sStage, so that ONE
+            // atomic instruction adds ONE contiguous block (64 lanes adding to 64 different blocks would be 64 cache
+            // lines per instruction: measured 12x slower)
+            const int rr = lane / CNP, cc = lane - rr * CNP;
+            for (long long q0 = cur.q0; q0 < cur.q1; q0 += kWave) {
+                const long long q = q0 + lane;
+                const bool valid = q < cur.q1;
+                double blk[BLK];
+                int gb = -1;
+                if (valid) {
+                    const unsigned ent = g.pair[q];
+                    const int la = ent & 63, lb = (ent >> 6) & 63;
+                    double T0[CNP], T1[CNP];
+                    pair_block<CNP, SR>(sR, sV + sLp[la] * SV, la, lb, T0, T1);
+                    const double *Aa = sR + la * SR;
+                    gb = g.pair_gblk[q - g.pair_gblk_base];
 #pragma unroll
-                for (int r = 0; r < CNP; ++r) {
-                    const double a0 = Aa[r], a1 = Aa[CNP + r];
+                    for (int r = 0; r < CNP; ++r) {
+                        const double a0 = Aa[r], a1 = Aa[CNP + r];
 #pragma unroll
-                    for (int c = 0; c < CNP; ++c) gadd(&dst[r * kCP + c], a0 * T0[c] + a1 * T1[c]);
+                        for (int c = 0; c < CNP; ++c) blk[r * CNP + c] = fma(a1, T1[c], a0 * T0[c]);
+                    }
+                }
+                for (int base = 0; base < kWave; base += kStageLanes) {
+                    const int ql = lane - base;
+                    if (ql >= 0 && ql < kStageLanes && valid) {
+                        double *dst = sStage + ql * BLK;
+#pragma unroll
+                        for (int i = 0; i < BLK; ++i) dst[i] = blk[i];
+                    }
+                    wave_lds_sync();
+                    for (int q2 = 0; q2 < kStageLanes && base + q2 < kWave; ++q2) {
+                        const int gL = rl(gb, base + q2);
+                        if (gL >= 0 && lane < BLK) gadd(&g.S_up[(size_t)gL * (kCP * kCP) + rr * kCP + cc], sStage[q2 * BLK + lane]);
+                    }
+                    wave_lds_sync();
                 }
             }
         }
