@@ -77,8 +77,10 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     pl.perm.resize(n);
     std::iota(pl.perm.begin(), pl.perm.end(), 0);
     auto deg = [&](int i) { return pt_ptr[i + 1] - pt_ptr[i]; };
-    std::sort(pl.perm.begin(), pl.perm.end(), [&](int a, int b) {
-        int ca = point_class(deg(a)), cb = point_class(deg(b));
+    std::vector<uint8_t> cls(n);
+    for (int i = 0; i < n; ++i) cls[i] = (uint8_t)point_class(deg(i));
+    auto by_class_then_signature = [&](int a, int b) {
+        int ca = cls[a], cb = cls[b];
         if (ca != cb) return ca < cb;
         if (ca == 0 || ca == 1) {
             const int *pa = cam.data() + pt_ptr[a], *pb = cam.data() + pt_ptr[b];
@@ -87,7 +89,21 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             if (da != db) return da < db;
         }
         return a < b;
-    });
+    };
+    std::sort(pl.perm.begin(), pl.perm.end(), by_class_then_signature);
+    if (kMinRunObs > 0) { // optional: points whose camera set hardly repeats -> direct tiles (see plan.h: measured slower, off)
+        bool changed = false;
+        int t0 = 0;
+        while (t0 < n && cls[pl.perm[t0]] == 0) {
+            const int i0 = pl.perm[t0], d = deg(i0);
+            int t1 = t0 + 1;
+            while (t1 < n && cls[pl.perm[t1]] == 0 && deg(pl.perm[t1]) == d &&
+                   std::memcmp(cam.data() + pt_ptr[i0], cam.data() + pt_ptr[pl.perm[t1]], sizeof(int) * d) == 0) ++t1;
+            if ((int64_t)(t1 - t0) * d < kMinRunObs) { for (int t = t0; t < t1; ++t) cls[pl.perm[t]] = 1; changed = true; }
+            t0 = t1;
+        }
+        if (changed) std::sort(pl.perm.begin(), pl.perm.end(), by_class_then_signature);
+    }
     pl.n_active = 0;
     for (int i = 0; i < n; ++i) if (deg(i) > 0) pl.n_active++;
 
@@ -242,7 +258,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     // class 0: LDS-accumulated tiles
     for (; t < npl; ++t) {
         int d = pl.pt_obs[t + 1] - pl.pt_obs[t];
-        if (point_class(d) != 0) break;
+        if (cls[pl.perm[pl.pt_begin + t]] != 0) break;
         const int *c = pl.obs_cam.data() + pl.pt_obs[t];
         bool same_sig = (d == sig_d && sig_cams && std::memcmp(sig_cams, c, sizeof(int) * d) == 0);
         // a point that would open a 9th pair round starts a new batch
@@ -304,7 +320,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     rounds_mode = false;
     for (; t < npl; ++t) {
         int d = pl.pt_obs[t + 1] - pl.pt_obs[t];
-        if (point_class(d) != 1) break;
+        if (cls[pl.perm[pl.pt_begin + t]] != 1) break;
         const int *c = pl.obs_cam.data() + pl.pt_obs[t];
         if (cur_obs + d > kWave || pts_in_batch >= kMaxPtsBatch) {
             close_batch(t);

@@ -30,7 +30,9 @@ constexpr int kMaxTileBatches = 32; // batches per tile (k_build keeps a tile's 
 constexpr int kTileSlots = 2048;     // concurrently resident k_build workgroups: 256 CUs x 8 (two per SIMD)
 constexpr int kMaxRounds = 8;    // pair rounds per LDS-tile batch (k_build preloads them into registers)
 constexpr uint32_t kPairInvalid = 0xFFFFFFFFu; // padding entry of a pair round
-constexpr int kMaxViewsLds = 10; // d(d+1)/2 <= kNSlot
+constexpr int kMaxViewsLds = 10;        // d(d+1)/2 <= kNSlot
+constexpr int kMinRunObs = 0;           // > 0: camera sets repeating over fewer observations go to the direct tiles.  Measured (tools/real_run.py,
+                                        // every point a different camera set): 32 made the build 1.2-3x SLOWER than poorly packed register tiles -> off
 constexpr int kCP = 8;           // padded camera block dimension (cnp <= 8)
 
 struct Plan {

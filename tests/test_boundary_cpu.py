@@ -235,6 +235,11 @@ def test_plan_tables_ragged_scene():
     rng = np.random.default_rng(1)
     base = scene.make_scene("x", m=40, n=500, d=20, seed=2, strides=(1,))
     keep = [np.sort(rng.permutation(np.arange(base.pt_ptr[i], base.pt_ptr[i + 1]))[:rng.integers(1, 21)]) for i in range(base.n)]
+    # a camera set has to repeat to earn a register-accumulated tile (plan.h kMinRunObs): the first 350 points keep a
+    # prefix of their views whose length depends on the start camera only, so ~9 points share each camera set
+    start = base.obs_cam[base.pt_ptr[:-1]]
+    for i in range(350):
+        keep[i] = np.arange(base.pt_ptr[i], base.pt_ptr[i] + 1 + (int(start[i]) * 7) % 20)
     sel = np.concatenate(keep)
     sc = scene.Scene(n=base.n, m=base.m, cnp=7, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0,
                      pt_ptr=np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int32),
