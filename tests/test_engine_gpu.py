@@ -453,3 +453,17 @@ def test_full_size_properties(oracle, name):
     ret2, info2 = eng.run()
     assert info2[1] <= info[1] * (1 + 1e-12) and info2[0] == pytest.approx(info[1], rel=1e-12)
     assert info[6] == 8 and info[9] == ret          # Bundler's stop rule, no rejected trial
+    if name == "C2":
+        # the north-star claim at full size: the REAL reference's solve of this very scene (tests/golden/ref_C2.npz,
+        # 13 iterations of sba-1.5 with finite-difference Jacobians and a dense Cholesky, ~100 s on one core)
+        import os
+        from conftest import GOLDEN
+        z = np.load(os.path.join(GOLDEN, "ref_C2.npz"))
+        assert abs(np.abs(sc.x).sum() - float(z["xsum"])) < 1e-9 * float(z["xsum"])
+        want = z["info_final"]
+        assert ret == int(z["ret_final"]) and info[6] == want[6] and info[9] == want[9]
+        rw = np.sqrt(want[1] / sc.nobs)
+        assert abs(rmse - rw) <= max(1e-3, 0.005 * rw) and abs(rmse - rw) < 1e-6          # stated tolerance; measured
+        assert abs(info[0] - want[0]) <= 1e-9 * want[0]
+        k = min(len(acc), len(z["cost_trace"]))
+        assert np.allclose(acc[:k], z["cost_trace"][:k], rtol=1e-4)
