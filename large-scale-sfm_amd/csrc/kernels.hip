@@ -757,36 +757,62 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
 template <int CNP>
 __global__ __launch_bounds__(256) void k_long_pairs(const LongArgs g)
 {
-    const int l = blockIdx.y, ip = g.long_pts[l];
+    // every wavefront computes 64 pair blocks into registers and hands them to HBM kStage at a time through LDS, so
+    // that one atomic instruction adds one contiguous block (the shape of k_build's direct tiles; 64 lanes adding to
+    // 64 different blocks was measured ~6x slower)
+    constexpr int BLK = CNP * CNP, kStage = 8;
+    __shared__ double sStage[4][kStage * BLK];
+    const int l = blockIdx.y, ip = g.long_pts[l], lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int os = g.pt_obs[ip], d = g.pt_obs[ip + 1] - os;
     const long long np = (long long)d * (d + 1) / 2, t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= np) return;
-    // pair index -> (a <= b): t = a*d - a(a-1)/2 + (b - a)
-    int a = (int)floor(((2.0 * d + 1.0) - sqrt((2.0 * d + 1.0) * (2.0 * d + 1.0) - 8.0 * (double)t)) * 0.5);
-    if (a < 0) a = 0;
-    while ((long long)a * d - (long long)a * (a - 1) / 2 > t) --a;
-    while ((long long)(a + 1) * d - (long long)(a + 1) * a / 2 <= t) ++a;
-    const int b = a + (int)(t - ((long long)a * d - (long long)a * (a - 1) / 2));
-    const double *scr = g.scratch + (size_t)g.long_scr[l] * kLongRow;
-    const double *ra = scr + (size_t)a * kLongRow, *rb = scr + (size_t)b * kLongRow;
-    const int ja = g.obs_cam[os + a], jb = g.obs_cam[os + b];
-    if (g.cam_fixed[ja] || g.cam_fixed[jb]) return; // A is zero: the block vanishes
-    int lo = g.up_row[ja], hi = g.up_row[ja + 1] - 1, blk = -1; // cameras ascend inside a point: ja <= jb
-    while (lo <= hi) { const int mid = (lo + hi) >> 1, c = g.up_col[mid]; if (c < jb) lo = mid + 1; else if (c > jb) hi = mid - 1; else { blk = mid; break; } }
-    if (blk < 0) return;
-    double M00 = ra[24] * rb[16] + ra[25] * rb[17] + ra[26] * rb[18], M01 = ra[24] * rb[19] + ra[25] * rb[20] + ra[26] * rb[21];
-    double M10 = ra[27] * rb[16] + ra[28] * rb[17] + ra[29] * rb[18], M11 = ra[27] * rb[19] + ra[28] * rb[20] + ra[29] * rb[21];
-    const double dg = (a == b) ? 1.0 : 0.0;
-    M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
-    double T0[CNP], T1[CNP];
+    if ((long long)blockIdx.x * 256 >= np) return;          // whole workgroup past the end
+    double blk[BLK];
+    int gb = -1;
+    if (t < np) {
+        // pair index -> (a <= b): t = a*d - a(a-1)/2 + (b - a)
+        int a = (int)floor(((2.0 * d + 1.0) - sqrt((2.0 * d + 1.0) * (2.0 * d + 1.0) - 8.0 * (double)t)) * 0.5);
+        if (a < 0) a = 0;
+        while ((long long)a * d - (long long)a * (a - 1) / 2 > t) --a;
+        while ((long long)(a + 1) * d - (long long)(a + 1) * a / 2 <= t) ++a;
+        const int b = a + (int)(t - ((long long)a * d - (long long)a * (a - 1) / 2));
+        const double *scr = g.scratch + (size_t)g.long_scr[l] * kLongRow;
+        const double *ra = scr + (size_t)a * kLongRow, *rb = scr + (size_t)b * kLongRow;
+        const int ja = g.obs_cam[os + a], jb = g.obs_cam[os + b];
+        if (!g.cam_fixed[ja] && !g.cam_fixed[jb]) {         // a fixed camera has A = 0: the block vanishes
+            int lo = g.up_row[ja], hi = g.up_row[ja + 1] - 1; // cameras ascend inside a point: ja <= jb
+            while (lo <= hi) { const int mid = (lo + hi) >> 1, c = g.up_col[mid]; if (c < jb) lo = mid + 1; else if (c > jb) hi = mid - 1; else { gb = mid; break; } }
+        }
+        if (gb >= 0) {
+            double M00 = ra[24] * rb[16] + ra[25] * rb[17] + ra[26] * rb[18], M01 = ra[24] * rb[19] + ra[25] * rb[20] + ra[26] * rb[21];
+            double M10 = ra[27] * rb[16] + ra[28] * rb[17] + ra[29] * rb[18], M11 = ra[27] * rb[19] + ra[28] * rb[20] + ra[29] * rb[21];
+            const double dg = (a == b) ? 1.0 : 0.0;
+            M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
+            double T0[CNP], T1[CNP];
 #pragma unroll
-    for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, rb[8 + c], M00 * rb[c]); T1[c] = fma(M11, rb[8 + c], M10 * rb[c]); }
-    double *dst = g.S_up + (size_t)blk * (kCP * kCP);
+            for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, rb[8 + c], M00 * rb[c]); T1[c] = fma(M11, rb[8 + c], M10 * rb[c]); }
 #pragma unroll
-    for (int r = 0; r < CNP; ++r) {
-        const double a0 = ra[r], a1 = ra[8 + r];
+            for (int r = 0; r < CNP; ++r) {
+                const double a0 = ra[r], a1 = ra[8 + r];
 #pragma unroll
-        for (int c = 0; c < CNP; ++c) gadd(&dst[r * kCP + c], fma(a1, T1[c], a0 * T0[c]));
+                for (int c = 0; c < CNP; ++c) blk[r * CNP + c] = fma(a1, T1[c], a0 * T0[c]);
+            }
+        }
+    }
+    const int rr = lane / CNP, cc = lane - rr * CNP;
+    double *stage = sStage[wv];
+    for (int base = 0; base < kWave; base += kStage) {
+        const int ql = lane - base;
+        if (ql >= 0 && ql < kStage && gb >= 0) {
+            double *dst = stage + ql * BLK;
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) dst[i] = blk[i];
+        }
+        wave_lds_sync();
+        for (int q2 = 0; q2 < kStage; ++q2) {
+            const int gL = rl(gb, base + q2);
+            if (gL >= 0 && lane < BLK) gadd(&g.S_up[(size_t)gL * (kCP * kCP) + rr * kCP + cc], stage[q2 * BLK + lane]);
+        }
+        wave_lds_sync();
     }
 }
 
