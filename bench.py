@@ -39,7 +39,7 @@ def cpu_baseline(scene_mod):
             t0 = time.time()
             r = ref.run(sc, itmax=2)
             dt = time.time() - t0
-            return {"value": float(r["info"][9] / dt), "unit": "LM iterations/s", "cores": 1, "kind": "reference",
+            return {"value": float(r["info"][9] / dt), "unit": "LM iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "reference",
                     "sample": sample + ", 2 LM iterations of the real sba-1.5 (FD Jacobian, dense Cholesky via MKL, "
                     "MKL_NUM_THREADS unset: sba itself is single-threaded), %.1f s" % dt,
                     "rmse_after": float(np.sqrt(r["info"][1] / sc.nobs))}
@@ -49,7 +49,7 @@ def cpu_baseline(scene_mod):
     t0 = time.time()
     r = o.run(sc, itmax=6, fd_jacobian=1)
     dt = time.time() - t0
-    return {"value": float(r["info"][9] / dt), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+    return {"value": float(r["info"][9] / dt), "unit": "LM iterations/s", "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
             "sample": sample + ", 6 LM iterations of oracle/ba_oracle.c (FD Jacobian, dense Cholesky), %.1f s" % dt,
             "rmse_after": float(np.sqrt(r["info"][1] / sc.nobs))}
 
