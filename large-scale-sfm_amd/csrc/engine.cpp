@@ -197,7 +197,7 @@ int Engine::prepare()
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
     const Plan &pl = plan_;
 #define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
-    UP(d_tile_batch_, pl.tile_batch); UP(d_tile_slot_, pl.tile_slot); UP(d_tile_cslot_, pl.tile_cslot);
+    UP(d_tile_batch_, pl.tile_batch); UP(d_tile_slot_, pl.tile_slot); UP(d_tile_cslot_, pl.tile_cslot); UP(d_tile_mode_, pl.tile_mode);
     UP(d_slot_gblk_, pl.slot_gblk); UP(d_cslot_cam_, pl.cslot_cam);
     UP(d_batch_obs_, pl.batch_obs); UP(d_batch_pt_, pl.batch_pt); UP(d_pt_obs_, pl.pt_obs);
     UP(d_obs_cam_, pl.obs_cam); UP(d_obs_pt_, pl.obs_pt); UP(d_obs_cslot_, pl.obs_cslot);
@@ -404,6 +404,7 @@ bool Engine::linear_phase(double mu, bool want_diag)
     launch_cam_prep(st_, m_, cnp, mc, d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p);
     BuildArgs a{};
     a.tile_batch = d_tile_batch_.p; a.tile_slot = d_tile_slot_.p; a.tile_cslot = d_tile_cslot_.p;
+    a.tile_mode = d_tile_mode_.p; a.has_table = pl.ntile_table > 0;
     a.slot_gblk = d_slot_gblk_.p; a.cslot_cam = d_cslot_cam_.p;
     a.batch_obs = d_batch_obs_.p; a.batch_pt = d_batch_pt_.p; a.batch_pair = d_batch_pair_.p; a.pt_obs = d_pt_obs_.p;
     a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p; a.cam_fixed = d_fixed_.p;

@@ -119,6 +119,7 @@ private:
     DevBuf<int> d_long_pts_, d_long_scr_, d_up_row_, d_up_col_;
     DevBuf<double> d_long_scratch_, d_cam_cw_, d_cam_cv_, d_pt_cw_, d_pt_cv_;
     DevBuf<int> d_link_row_, d_link_other_, d_link_blk_;
+    DevBuf<unsigned char> d_tile_mode_;
     DevBuf<double> d_link_w_, d_link_pair_w_, d_cam_part_;
     long long long_max_pairs_ = 0;
     LongArgs long_args(double mu, bool want_diag, double *dB_dev, int part_row0);

@@ -335,9 +335,13 @@ __device__ __forceinline__ void pair_block(const double *sR, const double *sv, i
 #define STAMP(i) do { } while (0)
 #endif
 
-template <int CNP, bool LDS, bool FULL>
-__global__ __launch_bounds__(64, (CNP <= 7 && LDS ? 2 : 1)) void k_build(const BuildArgs g) // 8x8 blocks: 128 accumulator VGPRs, one wave per SIMD
+// TABLE (only with LDS): the tile's blocks are summed in an LDS-resident table by ds_add_f64 and handed to HBM once at
+// the end of the tile, for tiles whose points keep changing camera set (plan.h kTableRuns); the register scheme would
+// flush to HBM almost every round there and the L2's f64 atomic rate (~120 G elements/s) would be the bound
+template <int CNP, bool LDS, bool FULL, bool TABLE>
+__global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_build(const BuildArgs g) // 8x8 blocks: 128 accumulator VGPRs, one wave per SIMD
 {
+    if constexpr (LDS) { if (g.tile_mode[g.tile0 + blockIdx.x] != (TABLE ? 2 : 1)) return; }
 #ifdef MIBA_STAMPS
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -355,7 +359,8 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS ? 2 : 1)) void k_build(const B
     // registers; sStage only transposes them (kStageLanes lanes at a time) into the contiguous 49-double
     // shape a global f64 atomic wants.
     constexpr int kStageLanes = LDS ? 5 : 8;
-    __shared__ double sStage[kStageLanes * BLK], sC[LDS ? kNCSlot * SC : 1];
+    __shared__ double sStage[TABLE ? 1 : kStageLanes * BLK], sC[LDS ? kNCSlot * SC : 1];
+    __shared__ double sTab[TABLE ? kNSlot * BLK : 1];
     __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
     __shared__ int sLp[LDS ? 1 : kWave];      // local point of every observation (direct tiles; LDS tiles carry it in the pair entry)
 
@@ -367,13 +372,14 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS ? 2 : 1)) void k_build(const B
         nslots = g.tile_slot[tile + 1] - g.tile_slot[tile];
         ncs = g.tile_cslot[tile + 1] - g.tile_cslot[tile];
         for (int i = lane; i < ncs * SC; i += kWave) sC[i] = 0.0;
+        if constexpr (TABLE) for (int i = lane; i < nslots * BLK; i += kWave) sTab[i] = 0.0;
     }
     double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0, ccost = 0.0;
     // register-resident accumulator (LDS tiles): this lane's S block follows the lane for as long as its
     // block does not change
-    double acc[LDS ? BLK : 1];
+    double acc[LDS && !TABLE ? BLK : 1];
     int cur_slot = -1;
-    if constexpr (LDS) {
+    if constexpr (LDS && !TABLE) {
 #pragma unroll
         for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
     }
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS ? 2 : 1)) void k_build(const B
     // through sStage so that ONE global f64 atomic instruction adds ONE contiguous 7x7 block (the full-rate
     // atomic shape); then the accumulators restart from zero.
     auto flush_blocks = [&]() {
-        if constexpr (LDS) {
+        if constexpr (LDS && !TABLE) {
             const int rr = lane / CNP, cc = lane - rr * CNP;
             for (int base = 0; base < kWave; base += kStageLanes) {
                 const int q = lane - base;
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS ? 2 : 1)) void k_build(const B
                 const int la = ent & 63, lb = (ent >> 6) & 63, slot = (ent >> 12) & 63, plp = (ent >> 18) & 31;
                 // some lane is about to start another block: everybody flushes (in signature-sorted data all
                 // lanes change together, once per few hundred points)
-                if (__any(valid && cur_slot >= 0 && slot != cur_slot)) flush_blocks();
+                if constexpr (!TABLE) { if (__any(valid && cur_slot >= 0 && slot != cur_slot)) flush_blocks(); }
                 if (valid) {
                     cur_slot = slot;
                     double T0[CNP], T1[CNP];
@@ -579,7 +585,10 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS ? 2 : 1)) void k_build(const B
                     for (int r = 0; r < CNP; ++r) {
                         const double a0 = Aa[r], a1 = Aa[CNP + r];
 #pragma unroll
-                        for (int c = 0; c < CNP; ++c) acc[r * CNP + c] = fma(a1, T1[c], fma(a0, T0[c], acc[r * CNP + c]));
+                        for (int c = 0; c < CNP; ++c) {
+                            if constexpr (TABLE) ladd(&sTab[slot * BLK + r * CNP + c], fma(a1, T1[c], a0 * T0[c]));
+                            else acc[r * CNP + c] = fma(a1, T1[c], fma(a0, T0[c], acc[r * CNP + c]));
+                        }
                     }
                 }
             }
@@ -632,6 +641,13 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS ? 2 : 1)) void k_build(const B
     if constexpr (LDS) {
         flush_blocks();
         wave_lds_sync();
+        if constexpr (TABLE) { // the table goes to HBM once, one contiguous atomic instruction per block
+            const int rr = lane / CNP, cc = lane - rr * CNP;
+            for (int sl = 0; sl < nslots; ++sl) {
+                const int gb = rl(my_gblk, sl);
+                if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + rr * kCP + cc], sTab[sl * BLK + lane]);
+            }
+        }
         const int which = lane / CNP, t = lane - which * CNP;
         for (int k = 0; k < ncs; ++k) {
             const int cam = rl(my_cam, k);
@@ -1361,8 +1377,11 @@ void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const 
 template <int CNP, bool FULL>
 static void launch_build_t(hipStream_t st, bool lds_mode, int ntiles, const BuildArgs &a)
 {
-    if (lds_mode) hipLaunchKernelGGL((k_build<CNP, true, FULL>), dim3(ntiles), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_build<CNP, false, FULL>), dim3(ntiles), dim3(64), 0, st, a);
+    if (lds_mode) {
+        // both variants walk the same tile range; a workgroup whose tile belongs to the other variant leaves at once
+        hipLaunchKernelGGL((k_build<CNP, true, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
+        if (a.has_table) hipLaunchKernelGGL((k_build<CNP, true, FULL, true>), dim3(ntiles), dim3(64), 0, st, a);
+    } else hipLaunchKernelGGL((k_build<CNP, false, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
 }
 
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a)

@@ -220,8 +220,9 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     std::unordered_map<int, int> cmap;
     std::vector<int> sig_slots;       // slots of the previous point's pairs (signature cache)
     const int *sig_cams = nullptr; int sig_d = -1;
-    int cur_obs = 0, batches_in_tile = 0;
+    int cur_obs = 0, batches_in_tile = 0, sig_runs_in_tile = 0;
     t = 0;
+    pl.ntile_table = 0;
 
     std::vector<uint32_t> round_buf;  // pair entries of the round being filled (LDS tiles)
     bool rounds_mode = true;
@@ -248,7 +249,12 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         pl.tile_batch.push_back((int)pl.batch_obs.size() - 1);
         pl.tile_slot.push_back((int)pl.slot_gblk.size());
         pl.tile_cslot.push_back((int)pl.cslot_cam.size());
-        pl.tile_mode.push_back(mode);
+        // many camera sets in one tile: a lane would hand its register block to HBM almost every round (the L2's f64
+        // atomic rate is the bound then) -> the tile sums its <= kNSlot blocks in LDS instead
+        const uint8_t m2 = (mode == 1 && sig_runs_in_tile > kTableRuns) ? 2 : mode;
+        pl.tile_mode.push_back(m2);
+        if (m2 == 2) pl.ntile_table++;
+        sig_runs_in_tile = 0;
         if (mode == 1) tile_log.emplace_back(batches_in_tile, batches_in_tile >= tile_max_batches);
         pl.max_slots = std::max(pl.max_slots, (int)smap.size());
         smap.clear(); cmap.clear(); sig_cams = nullptr; sig_d = -1;
@@ -277,6 +283,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                 close_batch(t);
                 close_tile(1);
             }
+            sig_runs_in_tile++;
             sig_slots.clear();
             for (int a = 0; a < d; ++a) {
                 if (!cmap.count(c[a])) {

@@ -31,6 +31,7 @@ constexpr int kTileSlots = 2048;     // concurrently resident k_build workgroups
 constexpr int kMaxRounds = 8;    // pair rounds per LDS-tile batch (k_build preloads them into registers)
 constexpr uint32_t kPairInvalid = 0xFFFFFFFFu; // padding entry of a pair round
 constexpr int kMaxViewsLds = 10;        // d(d+1)/2 <= kNSlot
+constexpr int kTableRuns = 4;           // a tile whose points change camera set more often than this sums its blocks in an LDS table
 constexpr int kMinRunObs = 0;           // > 0: camera sets repeating over fewer observations go to the direct tiles.  Measured (tools/real_run.py,
                                         // every point a different camera set): 32 made the build 1.2-3x SLOWER than poorly packed register tiles -> off
 constexpr int kCP = 8;           // padded camera block dimension (cnp <= 8)
@@ -55,7 +56,8 @@ struct Plan {
     std::vector<int> batch_obs, batch_pt;            // nbatch+1
     std::vector<int64_t> batch_pair;                 // nbatch+1
     std::vector<int> tile_batch, tile_slot, tile_cslot; // ntile+1
-    std::vector<uint8_t> tile_mode;                  // 1 LDS accumulate, 0 direct global atomics
+    std::vector<uint8_t> tile_mode;                  // 1 register-accumulated blocks, 2 blocks summed in an LDS table, 0 direct global atomics
+    int ntile_table = 0;                             // tiles of mode 2
     std::vector<int> slot_gblk, cslot_cam;
     std::vector<uint32_t> pair;                      // la | lb<<6 | slot<<12 (6 bits) | local point<<18 (LDS tiles)
     std::vector<uint32_t> pair_gblk;                 // direct pairs only: upper block id

@@ -192,7 +192,7 @@ def _check_plan(sc, rank=0, world=1, tmb=0):
         o0, o1 = g["batch_obs"][b], g["batch_obs"][b + 1]
         assert 0 < o1 - o0 <= 64 and g["batch_pt"][b + 1] - g["batch_pt"][b] <= 32
         t = tile_of_batch[b]
-        lds = g["tile_mode"][t] == 1
+        lds = g["tile_mode"][t] in (1, 2)
         ents = g["pair"][g["batch_pair"][b]:g["batch_pair"][b + 1]]
         if lds:
             assert len(ents) % 64 == 0

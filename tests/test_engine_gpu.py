@@ -368,6 +368,8 @@ def test_mixed_track_lengths_and_unsorted_cameras(oracle):
                      pt_ptr=np.concatenate([[0], np.cumsum(np.bincount(pt, minlength=base.n))]).astype(np.int32),
                      obs_cam=cam[order], x=xy[order], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true)
     capi = pkg("capi")
+    modes = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).get("tile_mode")
+    assert (modes == 2).any() and (modes == 0).any()          # LDS block-table tiles (camera sets keep changing) and direct tiles
     eng = capi.Engine(capi.default_config(pcg_tol=1e-12, pcg_maxit=400))
     m, n, cnp = sc.m, sc.n, sc.cnp
     eng.set_problem(sc.p0[:m * cnp].reshape(m, cnp), sc.R0, sc.f_fixed, sc.p0[m * cnp:].reshape(n, 3), xy, pt, cam)
