@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F64_VALU_PEAK_TFLOPS = 78.6  # 256 CUs x 4 SIMDs x 16 f64 FMA lanes x 2 flops x 2.4 GHz
 
 
 def cpu_baseline(scene_mod):
@@ -154,7 +155,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_build<7,LDS> (fused linearise + Schur complement)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": "profiles/r01_kbuild_traffic.json (rocprofv3 FETCH_SIZE/WRITE_SIZE passes)" if traffic else None,
-                         "algorithmic_bytes_per_launch": tm["build_bytes"], "avg_launch_ms": build_ms},
+                         "algorithmic_bytes_per_launch": tm["build_bytes"], "avg_launch_ms": build_ms,
+                         # the kernel is not HBM-bound: its arithmetic against the f64 vector peak
+                         "valu_f64": {"achieved": tm["build_flops"] / (build_ms * 1e-3) / 1e12 if build_ms > 0 else 0.0,
+                                      "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": tm["build_flops"] / (build_ms * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS if build_ms > 0 else 0.0,
+                                      "algorithmic_flops_per_launch": tm["build_flops"]}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_mod)

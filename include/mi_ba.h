@@ -145,7 +145,9 @@ typedef struct {
     double allreduce_ms, allreduces;
     double build_bytes;                    /* algorithmic HBM bytes of one build launch */
     double pcg_resumes;                    /* solves whose unchecked first run of PCG iterations fell short (engine.cpp solve_phase) */
-    double reserved[4];
+    double build_flops;                    /* algorithmic f64 flops of one build launch: 400 per observation (residual, Jacobian,
+                                            * V / e_b / E terms), 2 x 138 per pair block, 120 per point (3x3 inverse, h) */
+    double reserved[3];
 } mi_ba_timing;
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_reset_timing(mi_ba_engine *e);

@@ -85,9 +85,9 @@ int mi_ba_get_timing(const mi_ba_engine *h, mi_ba_timing *t) { if (!h || !t) ret
 int mi_ba_reset_timing(mi_ba_engine *h)
 {
     if (!h) return MI_BA_ERROR;
-    const double bytes = h->e->timing.build_bytes;
+    const double bytes = h->e->timing.build_bytes, flops = h->e->timing.build_flops;
     h->e->timing = mi_ba_timing{};
-    h->e->timing.build_bytes = bytes;
+    h->e->timing.build_bytes = bytes; h->e->timing.build_flops = flops;
     return 0;
 }
 

@@ -320,6 +320,11 @@ int Engine::prepare()
     // pair table 4 B, point in 24 B / ptout 96 B, camera records once, every S block once
     timing.build_bytes = 25.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 120.0 * (double)npl +
                          192.0 * m_ + 512.0 * pl.nb_up() + 4.0 * (double)pl.pair_gblk.size();
+    {   // arithmetic of the same launch (for the f64 vector roofline beside the HBM one)
+        double pairs = 0.0;
+        for (size_t t = 0; t < npl; ++t) { const double d = pl.pt_obs[t + 1] - pl.pt_obs[t]; pairs += 0.5 * d * (d + 1); }
+        timing.build_flops = 400.0 * (double)pl.nobs_local() + 276.0 * pairs + 120.0 * (double)npl;
+    }
     if (cfg.verbose)
         std::fprintf(stderr, "[mi_ba] rank %d/%d: %lld pts %lld obs, %d batches, %d tiles (%d LDS), %zu pairs, S: %d upper / %d full blocks\n",
                      cfg.rank, cfg.world, (long long)npl, (long long)pl.nobs_local(), pl.nbatch(), pl.ntile(), pl.ntile_lds,
