@@ -1,0 +1,79 @@
+"""Randomised parity sweep: small scenes with ragged visibility (single views up to tracks longer than a wavefront, camera
+sets that repeat and camera sets that never do -> register tiles, table tiles, direct tiles and long points in one
+problem), every parameterisation (cnp 6 / 7 / 8, both distortion models, t or C), bundle modes, fixed cameras, soft
+constraints -- the engine against the CPU oracle (itself pinned to the reference), trial by trial."""
+import numpy as np
+import pytest
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def ragged_scene(rng, m, n, est_focal, undistort, explicit_centers, proj_sign, dmax):
+    scene = pkg("scene")
+    base = scene.make_scene("x", m=m, n=n, d=dmax, seed=int(rng.integers(1 << 30)), strides=(1,), est_focal=est_focal,
+                            undistort=undistort, nk=1, explicit_centers=explicit_centers, proj_sign=proj_sign)
+    keep = []
+    for i in range(n):
+        idx = np.arange(base.pt_ptr[i], base.pt_ptr[i + 1])
+        r = rng.random()
+        if r < 0.35:            # repeating camera sets: a prefix whose length depends on the start camera only
+            d = 2 + int(base.obs_cam[idx[0]]) % 7
+            sel = idx[:d]
+        elif r < 0.85:          # never-repeating camera sets
+            d = int(rng.integers(1, min(dmax, 18) + 1))
+            sel = np.sort(rng.permutation(idx)[:d])
+        else:                   # long tracks, some beyond one wavefront
+            d = int(rng.integers(18, dmax + 1))
+            sel = idx[:d]
+        keep.append(sel)
+    sel = np.concatenate(keep)
+    cnt = np.array([len(k) for k in keep])
+    return scene.Scene(n=n, m=m, cnp=base.cnp, est_focal=est_focal, undistort=undistort, nk=1, explicit_centers=explicit_centers,
+                       proj_sign=proj_sign, pt_ptr=np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32),
+                       obs_cam=base.obs_cam[sel], x=base.x[sel], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true)
+
+
+CASES = [  # est_focal, undistort, explicit_centers, proj_sign, mode, mcon, constraints
+    (1, 0, 1, -1.0, 0, 0, False), (1, 0, 0, 1.0, 0, 2, False), (0, 0, 1, -1.0, 0, 0, False), (1, 1, 1, -1.0, 0, 0, False),
+    (0, 1, 0, 1.0, 0, 1, False), (1, 2, 0, 1.0, 0, 2, False), (1, 0, 1, -1.0, 1, 0, False), (1, 0, 1, -1.0, 2, 0, False),
+    (1, 0, 1, -1.0, 0, 0, True), (1, 1, 0, 1.0, 0, 0, True), (0, 2, 0, 1.0, 0, 1, False), (1, 0, 0, 1.0, 0, 3, True),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_random_ragged_scenes_match_the_oracle(oracle, case):
+    est_focal, undistort, explicit_centers, proj_sign, mode, mcon, cons = CASES[case]
+    rng = np.random.default_rng(1000 + case)
+    sc = ragged_scene(rng, m=90, n=1200, est_focal=est_focal, undistort=undistort, explicit_centers=explicit_centers,
+                      proj_sign=proj_sign, dmax=80)
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    if cons:
+        a0 = sc.p0[:m * cnp].reshape(m, cnp); X0 = sc.p0[m * cnp:].reshape(n, 3)
+        cw = np.zeros((m, cnp)); cv = np.zeros((m, cnp))
+        cw[::4, :3] = 30.0; cv[::4, :3] = a0[::4, :3] + 0.01
+        if est_focal:
+            cw[:, 6] = 2e4; cv[:, 6] = 0.8
+        pw = np.zeros(n); pv = np.zeros((n, 3)); pw[::9] = 1e-3; pv[::9] = X0[::9] - 0.01
+        sc.constraints = dict(cam_cw=cw, cam_cv=cv, pt_cw=pw, pt_cv=pv)
+    capi = pkg("capi")
+    modes = capi.Plan(n, m, sc.obs_pt(), sc.obs_cam).get("tile_mode")
+    assert {0, 1, 2} <= set(modes.tolist())                   # every kind of tile takes part
+    eng = capi.Engine(capi.default_config(est_focal=est_focal, undistort=undistort, explicit_centers=explicit_centers,
+                                          proj_sign=proj_sign, mode=mode, mcon=mcon, pcg_tol=1e-12, pcg_maxit=490))
+    eng.load_scene(sc)
+    eng.prepare()
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0, mcon=mcon, mode=mode)
+    assert abs(ret - o["ret"]) <= (0 if mode == 0 else 3)     # the truncated drivers end in a rounding-level tail
+    if mode == 0:
+        assert info[6] == o["info"][6] and info[9] == o["info"][9]
+    assert abs(info[0] - o["info"][0]) < 1e-10 * o["info"][0]
+    assert abs(info[1] - o["info"][1]) < 1e-7 * o["info"][1]
+    tr, to = eng.trace(), o["trace"]
+    k = min(len(tr), len(to)) if mode else len(to)
+    assert np.allclose(tr[:k, 3], to[:k, 3], rtol=1e-6) and np.array_equal(tr[:k, 4], to[:k, 4])   # trial costs, accept / reject
+    if mcon or cons or mode:
+        # (structure-only: a point seen once slides along its ray at no cost; only the damping holds it)
+        assert np.abs(eng.packed_params() - o["p"]).max() < (1e-3 if mode == 2 else 1e-5)
