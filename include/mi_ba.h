@@ -113,6 +113,8 @@ int mi_ba_run(mi_ba_engine *e, double info[MI_BA_INFOSZ]);
  * step() = ONE damping trial = one reduced system built + solved + gain-ratio test.
  * step() returns 1 accepted, 0 rejected, 2 stopped (see info[6]), MI_BA_ERROR on failure. */
 int mi_ba_begin(mi_ba_engine *e);
+/* back to the parameters of the last mi_ba_set_params / mi_ba_prepare (kept in HBM: no host traffic), then mi_ba_begin */
+int mi_ba_restart(mi_ba_engine *e);
 int mi_ba_step(mi_ba_engine *e);
 int mi_ba_get_info(const mi_ba_engine *e, double info[MI_BA_INFOSZ]);
 /* per trial: itno, mu, cost_before, cost_trial, accepted, pcg_iterations (6 doubles each) */

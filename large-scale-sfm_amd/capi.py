@@ -69,7 +69,7 @@ def lib() -> C.CDLL:
         L.mi_ba_plan_get.restype = C.c_int64
         vp, dp, ip, dbl, i32, i64 = C.c_void_p, _dp, _ip, C.c_double, C.c_int, C.c_int64
         sig = {
-            "mi_ba_destroy": [vp], "mi_ba_cnp": [vp], "mi_ba_prepare": [vp], "mi_ba_begin": [vp], "mi_ba_step": [vp],
+            "mi_ba_destroy": [vp], "mi_ba_cnp": [vp], "mi_ba_prepare": [vp], "mi_ba_begin": [vp], "mi_ba_step": [vp], "mi_ba_restart": [vp],
             "mi_ba_reset_timing": [vp], "mi_ba_set_cameras": [vp, i32, dp, dp, dp], "mi_ba_set_points": [vp, i32, dp],
             "mi_ba_set_observations": [vp, i64, dp, ip, ip], "mi_ba_set_camera_constraints": [vp, dp, dp],
             "mi_ba_set_camera_links": [vp, C.c_int, ip, ip, dp],
@@ -140,6 +140,9 @@ class Engine:
                          np.ascontiguousarray(p0[m * cnp:]).reshape(n, 3), sc.x, sc.obs_pt(), sc.obs_cam)
         cons = getattr(sc, "constraints", None) or {}
         self.set_constraints(cons.get("cam_cw"), cons.get("cam_cv"), cons.get("pt_cw"), cons.get("pt_cv"))
+
+    def restart(self):
+        self._chk(self.L.mi_ba_restart(self.h), "restart")
 
     def set_host_allreduce(self, fn):
         """test transport (mi_ba.h): fn(np.ndarray view, op) must reduce the buffer in place over all ranks (op 0 sum, 1 max)"""

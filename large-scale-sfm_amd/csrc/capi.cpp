@@ -65,6 +65,7 @@ int mi_ba_set_observations(mi_ba_engine *h, int64_t nobs, const double *xy, cons
 int mi_ba_prepare(mi_ba_engine *h) { return h ? h->e->prepare() : MI_BA_ERROR; }
 int mi_ba_run(mi_ba_engine *h, double info[MI_BA_INFOSZ]) { return h ? h->e->run(info) : MI_BA_ERROR; }
 int mi_ba_begin(mi_ba_engine *h) { return h ? h->e->begin() : MI_BA_ERROR; }
+int mi_ba_restart(mi_ba_engine *h) { return h ? h->e->restart() : MI_BA_ERROR; }
 int mi_ba_step(mi_ba_engine *h) { return h ? h->e->step() : MI_BA_ERROR; }
 int mi_ba_get_info(const mi_ba_engine *h, double info[MI_BA_INFOSZ]) { if (!h) return MI_BA_ERROR; h->e->fill_info(info); return 0; }
 int mi_ba_get_trace(const mi_ba_engine *h, double *trace, int cap)

@@ -350,8 +350,22 @@ int Engine::set_params(const double *a, const double *xyz)
     cur_ = 0;
     if (!hipok(hipMemcpy(d_cam_a_[0].p, ap.data(), ap.size() * sizeof(double), hipMemcpyHostToDevice), "upload cam_a")) return MI_BA_ERROR;
     if (npl && !hipok(hipMemcpy(d_pts_[0].p, pp.data(), pp.size() * sizeof(double), hipMemcpyHostToDevice), "upload pts")) return MI_BA_ERROR;
+    // a device-resident copy of the starting point, for restart()
+    if (!hipok(d_cam_a_init_.alloc(ap.size()), "alloc cam_a copy") || !hipok(d_pts_init_.alloc(pp.size()), "alloc pts copy")) return MI_BA_ERROR;
+    if (!hipok(hipMemcpy(d_cam_a_init_.p, d_cam_a_[0].p, ap.size() * sizeof(double), hipMemcpyDeviceToDevice), "copy cam_a")) return MI_BA_ERROR;
+    if (npl && !hipok(hipMemcpy(d_pts_init_.p, d_pts_[0].p, pp.size() * sizeof(double), hipMemcpyDeviceToDevice), "copy pts")) return MI_BA_ERROR;
     begun_ = false;
     return 0;
+}
+
+// back to the parameters of the last set_params / prepare without touching the host (a 24 MB device copy at C3), then begin()
+int Engine::restart()
+{
+    if (!prepared_ || !d_cam_a_init_.p) { err = "restart: prepare first"; return MI_BA_ERROR; }
+    cur_ = 0;
+    if (!hipok(hipMemcpyAsync(d_cam_a_[0].p, d_cam_a_init_.p, d_cam_a_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore cam_a")) return MI_BA_ERROR;
+    if (d_pts_init_.n && !hipok(hipMemcpyAsync(d_pts_[0].p, d_pts_init_.p, d_pts_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore pts")) return MI_BA_ERROR;
+    return begin();
 }
 
 // one element-wise reduction over the ranks, in place on the device: RCCL on the engine's stream, or (tests only)
@@ -475,7 +489,8 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     launch_pcg_init(st_, p);
     int it0 = 0;
     if (pcg_pred_ > kPcgChunk) {
-        it0 = std::min(cfg.pcg_maxit, pcg_pred_ + 2);
+        // the count grows from trial to trial while the damping falls: extrapolate the last increase
+        it0 = std::min(cfg.pcg_maxit, pcg_pred_ + std::max(2, pcg_pred_ - pcg_pred_prev_ + 1));
         for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
         p.it = it0; launch_pcg_tail(st_, p);
         if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
@@ -484,6 +499,7 @@ bool Engine::solve_phase(double mu, double *dB_dev)
         else timing.pcg_resumes += 1;
     }
     if (it0 < cfg.pcg_maxit && !pcg_chunks(it0)) return false;
+    pcg_pred_prev_ = pcg_pred_ > 0 ? pcg_pred_ : (int)h_scal_[SC_PCG_ITERS];
     pcg_pred_ = (int)h_scal_[SC_PCG_ITERS];
     (void)hipEventRecord(ev_[3], st_);
     return update_phase(mu, dB_dev);
@@ -520,6 +536,7 @@ int Engine::begin()
 {
     if (!prepared_) { err = "begin: prepare first"; return MI_BA_ERROR; }
     mu_ = 0; nu_ = 2; itno_ = 0; stop_ = 0; nfev_ = 1; njev_ = 0; nlss_ = 0; dp_L2_ = DBL_MAX; new_outer_ = true;
+    pcg_pred_ = pcg_pred_prev_ = 0;      // a new solve: nothing to extrapolate from
     trace.clear();
     // probe pass: cost at p0 and the largest diagonal entry of U, V -> mu0 = tau * max (sba_levmar.c:1124-1128)
     if (!linear_phase(1.0, true) || !read_scalars()) return MI_BA_ERROR;

@@ -53,6 +53,7 @@ public:
     int set_observations(int64_t nobs, const double *xy, const int *pt_idx, const int *cam_idx);
     int prepare();
     int begin();
+    int restart();
     int step();
     int run(double info[MI_BA_INFOSZ]);
     void fill_info(double info[MI_BA_INFOSZ]) const;
@@ -77,7 +78,7 @@ private:
     bool update_phase(double mu, double *dB_dev);
     bool pcg_chunks(int it0);
     PcgArgs pcg_args();
-    int pcg_pred_ = 0;                            // iterations of the previous solve
+    int pcg_pred_ = 0, pcg_pred_prev_ = 0;        // iterations of the previous two solves of this LM run
     bool read_scalars();
     bool allreduce1();
     bool allreduce2();
@@ -120,6 +121,7 @@ private:
     DevBuf<double> d_long_scratch_, d_cam_cw_, d_cam_cv_, d_pt_cw_, d_pt_cv_;
     DevBuf<int> d_link_row_, d_link_other_, d_link_blk_;
     DevBuf<unsigned char> d_tile_mode_;
+    DevBuf<double> d_cam_a_init_, d_pts_init_;
     DevBuf<double> d_link_w_, d_link_pair_w_, d_cam_part_;
     long long long_max_pairs_ = 0;
     LongArgs long_args(double mu, bool want_diag, double *dB_dev, int part_row0);
