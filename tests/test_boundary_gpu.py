@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT, pkg, scene_from_golden
-from helpers import ladybug_like_scene, model_lib, read_model, vsfm_scene, write_bal, write_nvm
+from helpers import ladybug_like_scene, model_lib, read_model, rodrigues, vsfm_scene, write_bal, write_nvm
 
 pytestmark = pytest.mark.gpu
 
@@ -297,3 +297,47 @@ def test_config_c5_merged_clusters_global_refine(tmp_path, oracle):
     assert rmse1 < 0.21                                                # seams closed, noise level reached
     assert [int(x) for x in open(nvm).read().split("\n")[2:4][0].split()[:1]] == [1000]   # camera names kept
     assert len(mdl["f"]) == m and np.all(np.abs(mdl["f"] - 800) < 40)
+
+
+def test_two_clusters_aligned_merged_and_refined(tmp_path):
+    """the cluster-merge flow end to end on the GPU (Merge3D3D.cpp:564-904): two sub-reconstructions of one scene, the second
+    in its own similarity frame; their common points give scale, R, t (mi_sim3_align); the second cluster's cameras and
+    points are brought over, the models merged into one NVM, and optimizer_all refines the result to the noise level"""
+    scene, capi = pkg("scene"), pkg("capi")
+    sc = vsfm_scene(m=60, n=6000, d=6, seed=123, strides=(1, 2, 3), cam_noise=0.002, pt_noise=0.004, f_noise=0.002)
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    rng = np.random.default_rng(9)
+    a = sc.p0[:m * cnp].reshape(m, cnp).copy(); X = sc.p0[m * cnp:].reshape(n, 3).copy()
+    R = np.einsum("mij,mjk->mik", rodrigues(a[:, 3:6]), sc.R0.reshape(m, 3, 3)); t = a[:, :3].copy()
+    in_b = np.arange(m) >= 30                                          # cluster B = cameras 30..59
+    first, last = sc.obs_cam[sc.pt_ptr[:-1]], sc.obs_cam[sc.pt_ptr[1:] - 1]
+    pts_a, pts_b = first < 30, last >= 30                              # a point is in a cluster that sees it
+    common = pts_a & pts_b
+    assert common.sum() > 300
+    # cluster B lives in its own frame: X_A = s Rg X_B + T
+    s_true = 1.8; Rg = scene._rodrigues(np.array([0.4, -0.7, 0.5])); T = np.array([3.0, -1.0, 2.0])
+    XB = (X - T) @ Rg / s_true + rng.normal(0, 0.002, X.shape)         # B's own estimate of every point it sees
+    RB = np.einsum("mij,jk->mik", R, Rg); tB = (t + np.einsum("mij,j->mi", R, T)) / s_true      # x = RB XB + tB (same image)
+    got = capi.sim3_align(XB[common], X[common], rounds=2000)
+    # (the winning round is picked by a score that applies the scale twice, Merge3D3D.cpp:379 -- kept -- so with s = 1.8
+    #  the rotation is only good to about a degree; closing that seam is what the bundle after the merge is for)
+    assert abs(got["scale"] - s_true) < 0.01 and np.abs(got["R"] - Rg).max() < 0.05
+    sa, Ra, Ta = got["scale"], got["R"], got["t"]
+    # bring B over (x_A = Ra (sa x_B) + Ta) and merge: cameras < 30 and points of A from A, the rest from B
+    Rm, tm, Xm = R.copy(), t.copy(), X.copy()
+    Rm[in_b] = np.einsum("mij,kj->mik", RB[in_b], Ra)                  # R' = R_B Ra^T
+    tm[in_b] = sa * tB[in_b] - np.einsum("mij,j->mi", Rm[in_b], Ta)
+    only_b = pts_b & ~pts_a
+    Xm[only_b] = sa * XB[only_b] @ Ra.T + Ta
+    merged = np.concatenate([np.column_stack([tm, np.zeros((m, 3)), a[:, 6]]).reshape(-1), Xm.reshape(-1)])
+    sc.R0 = np.ascontiguousarray(Rm.reshape(m, 9))
+    d = tmp_path / "dendogram" / "cluster7"; d.mkdir(parents=True)
+    nvm = str(d / "outputVSFM_GB.nvm")
+    write_nvm(nvm, sc, merged)
+    L = model_lib()
+    h = L.mi_model_load_nvm(nvm.encode()); rmse0 = L.mi_model_rmse(h); L.mi_model_free(h)
+    exe = os.path.join(ROOT, "large-scale-sfm_amd", "bin", "optimizer_all")
+    out = subprocess.run([exe, str(d) + "/", "0", "100", "16", "32", "0.5", "0"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    h = L.mi_model_load_nvm(nvm.encode()); rmse1 = L.mi_model_rmse(h); L.mi_model_free(h)
+    assert rmse0 > 3 * rmse1 and rmse1 < 0.21                           # the alignment left a seam; the bundle closed it
