@@ -402,6 +402,7 @@ struct mi_tri_engine {
     int64_t nobs = 0;
     Buf<double> cam, xy, xyz, errv, sumsq;
     Buf<int> pt_ptr, obs_cam, status, nviews;
+    std::vector<int> order;       // internal position -> track (tracks sorted by their first cameras, see set_tracks)
     hipStream_t st = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = 0.0;
@@ -476,6 +477,32 @@ int mi_tri_set_tracks(mi_tri_engine *e, int n, const int *pt_ptr, const int *obs
     const int64_t nobs = pt_ptr[n];
     for (int64_t o = 0; o < nobs; ++o) if (obs_cam[o] >= e->m) { e->err = "set_tracks: camera index out of range"; return -1; }
     (void)hipSetDevice(e->cfg.device);
+    // The kernel gathers a 128-B camera record per view: in the caller's order 64 neighbouring lanes want 64 different
+    // cameras and the gathers run at L2 speed.  Tracks are therefore processed in the order of their first cameras
+    // (neighbours then share records in L1); the views inside a track keep their order, and results go back in the
+    // caller's order, so nothing observable changes.
+    e->order.resize(n);
+    {
+        std::vector<unsigned long long> key(n);
+        for (int i = 0; i < n; ++i) {
+            unsigned long long k = 0;
+            int taken = 0;
+            for (int o = pt_ptr[i]; o < pt_ptr[i + 1] && taken < 3; ++o)
+                if (obs_cam[o] >= 0) { k |= (unsigned long long)(obs_cam[o] & 0x1fffff) << (42 - 21 * taken); ++taken; }
+            key[i] = k;
+            e->order[i] = i;
+        }
+        std::stable_sort(e->order.begin(), e->order.end(), [&](int a, int b) { return key[a] < key[b]; });
+    }
+    std::vector<int> pp((size_t)n + 1, 0), oc((size_t)nobs);
+    std::vector<double> xx((size_t)nobs * 2);
+    for (int t = 0; t < n; ++t) {
+        const int i = e->order[t], o0 = pt_ptr[i], d = pt_ptr[i + 1] - o0;
+        std::memcpy(oc.data() + pp[t], obs_cam + o0, sizeof(int) * (size_t)d);
+        std::memcpy(xx.data() + 2 * (size_t)pp[t], xy + 2 * (size_t)o0, sizeof(double) * 2 * (size_t)d);
+        pp[t + 1] = pp[t] + d;
+    }
+    pt_ptr = pp.data(); obs_cam = oc.data(); xy = xx.data();
     hipError_t he;
     if ((he = e->pt_ptr.upload(pt_ptr, (size_t)n + 1)) != hipSuccess || (he = e->obs_cam.upload(obs_cam, (size_t)nobs)) != hipSuccess ||
         (he = e->xy.upload(xy, (size_t)nobs * 2)) != hipSuccess || (he = e->xyz.alloc((size_t)n * 3)) != hipSuccess ||
@@ -521,24 +548,29 @@ int mi_tri_get(mi_tri_engine *e, double *xyz, double *err, int *status, int64_t 
     (void)hipSetDevice(e->cfg.device);
     const size_t n = (size_t)e->n;
     std::vector<int> st(n), nv(n);
-    std::vector<double> ss(n);
+    std::vector<double> ss(n), X(n * 3), er(n);
     hipError_t he = hipSuccess;
     if (n) {
-        if (xyz) he = hipMemcpy(xyz, e->xyz.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
-        if (he == hipSuccess && err) he = hipMemcpy(err, e->errv.p, n * sizeof(double), hipMemcpyDeviceToHost);
+        he = hipMemcpy(X.data(), e->xyz.p, n * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (he == hipSuccess) he = hipMemcpy(er.data(), e->errv.p, n * sizeof(double), hipMemcpyDeviceToHost);
         if (he == hipSuccess) he = hipMemcpy(st.data(), e->status.p, n * sizeof(int), hipMemcpyDeviceToHost);
         if (he == hipSuccess) he = hipMemcpy(nv.data(), e->nviews.p, n * sizeof(int), hipMemcpyDeviceToHost);
         if (he == hipSuccess) he = hipMemcpy(ss.data(), e->sumsq.p, n * sizeof(double), hipMemcpyDeviceToHost);
         if (he != hipSuccess) { e->fail("download", he); return -1; }
     }
-    if (status) std::memcpy(status, st.data(), n * sizeof(int));
-    // the reference's counters and its running sum, in track order (:1303)
+    // back to the caller's order; the reference's counters and its running sum in track order (:1303)
+    std::vector<int> where(n);
+    for (size_t t = 0; t < n; ++t) where[(size_t)e->order[t]] = (int)t;
     int64_t c1 = 0, c2 = 0, c3 = 0, np = 0;
     double sum = 0.0;
     for (size_t i = 0; i < n; ++i) {
-        if (st[i] != MI_TRI_FEW_VIEWS) ++c1;
-        if (st[i] >= MI_TRI_LARGE_ERROR) ++c2;
-        if (st[i] == MI_TRI_KEPT) { ++c3; sum += ss[i]; np += nv[i]; }
+        const size_t t = (size_t)where[i];
+        if (xyz) { xyz[3 * i] = X[3 * t]; xyz[3 * i + 1] = X[3 * t + 1]; xyz[3 * i + 2] = X[3 * t + 2]; }
+        if (err) err[i] = er[t];
+        if (status) status[i] = st[t];
+        if (st[t] != MI_TRI_FEW_VIEWS) ++c1;
+        if (st[t] >= MI_TRI_LARGE_ERROR) ++c2;
+        if (st[t] == MI_TRI_KEPT) { ++c3; sum += ss[t]; np += nv[t]; }
     }
     if (counts) { counts[0] = c1; counts[1] = c2; counts[2] = c3; counts[3] = c3; }
     if (sum_sq_px) *sum_sq_px = sum;
