@@ -627,7 +627,12 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
                     wave_lds_sync();
                     for (int q2 = 0; q2 < kStageLanes && base + q2 < kWave; ++q2) {
                         const int gL = rl(gb, base + q2);
-                        if (gL >= 0 && lane < BLK) gadd(&g.S_up[(size_t)gL * (kCP * kCP) + rr * kCP + cc], sStage[q2 * BLK + lane]);
+                        if (gL < 0 || (q2 > 0 && rl(gb, base + q2 - 1) == gL)) continue;   // nothing, or merged into the lane before
+                        // the plan sorted the batch's pairs by block: a run of lanes with the same block becomes one atomic
+                        double v = lane < BLK ? sStage[q2 * BLK + lane] : 0.0;
+                        for (int q3 = q2 + 1; q3 < kStageLanes && base + q3 < kWave && rl(gb, base + q3) == gL; ++q3)
+                            if (lane < BLK) v += sStage[q3 * BLK + lane];
+                        if (lane < BLK) gadd(&g.S_up[(size_t)gL * (kCP * kCP) + rr * kCP + cc], v);
                     }
                     wave_lds_sync();
                 }

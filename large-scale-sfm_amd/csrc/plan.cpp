@@ -238,6 +238,15 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     auto close_batch = [&](int t_end) {
         if (cur_obs == 0) return;
         if (rounds_mode) flush_round();
+        else {
+            // direct tiles: the batch's pairs in block order, so that pairs of different points that land on the same
+            // block sit in neighbouring lanes and the kernel merges them before the atomic (k_build, direct branch)
+            const size_t q0 = (size_t)pl.batch_pair.back(), q1 = pl.pair.size(), base = (size_t)pl.npair_lds;
+            std::vector<std::pair<uint32_t, uint32_t>> tmp(q1 - q0);
+            for (size_t q = q0; q < q1; ++q) tmp[q - q0] = { pl.pair_gblk[q - base], pl.pair[q] };
+            std::stable_sort(tmp.begin(), tmp.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+            for (size_t q = q0; q < q1; ++q) { pl.pair_gblk[q - base] = tmp[q - q0].first; pl.pair[q] = tmp[q - q0].second; }
+        }
         pl.batch_obs.push_back(pl.pt_obs[t_end]);
         pl.batch_pt.push_back(t_end);
         pl.batch_pair.push_back((int64_t)pl.pair.size());
