@@ -200,6 +200,7 @@ int Engine::prepare()
     UP(d_tile_batch_, pl.tile_batch); UP(d_tile_slot_, pl.tile_slot); UP(d_tile_cslot_, pl.tile_cslot); UP(d_tile_mode_, pl.tile_mode);
     UP(d_slot_gblk_, pl.slot_gblk); UP(d_cslot_cam_, pl.cslot_cam);
     UP(d_batch_obs_, pl.batch_obs); UP(d_batch_pt_, pl.batch_pt); UP(d_pt_obs_, pl.pt_obs);
+    UP(d_bs_batch_obs_, pl.bs_batch_obs); UP(d_bs_batch_pt_, pl.bs_batch_pt);
     UP(d_obs_cam_, pl.obs_cam); UP(d_obs_pt_, pl.obs_pt); UP(d_obs_cslot_, pl.obs_cslot);
     UP(d_pair_, pl.pair); UP(d_pair_gblk_, pl.pair_gblk);
     UP(d_bsr_row_, pl.bsr_row); UP(d_bsr_col_, pl.bsr_col); UP(d_bsr_src_, pl.bsr_src); UP(d_bsr_trans_, pl.bsr_trans);
@@ -513,10 +514,10 @@ bool Engine::update_phase(double mu, double *dB_dev)
     launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, links_,
                       d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part_.p, d_stage_.p, scal_());
     BacksubArgs b{};
-    b.batch_obs = d_batch_obs_.p; b.batch_pt = d_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
+    b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
-    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = pl.nbatch(); b.ngrid = std::min(pl.nbatch(), kBacksubGrid); b.cfg = mc;
+    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, kBacksubGrid); b.cfg = mc;
     (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, false, dB_dev, b.ngrid));

@@ -381,6 +381,20 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         }
         if (best_tmb != tile_max_batches) { do_tiling(best_tmb); if (!tiling_error.empty()) return tiling_error; }
     }
+    // batches for the back-substitution: the same points, packed 64 observations at a time whatever the tiles of the
+    // build look like (a tile boundary closes a build batch; on scenes with ever-changing camera sets that leaves one
+    // point per batch, and k_backsub has no use for tiles)
+    {
+        pl.bs_batch_obs.assign(1, 0); pl.bs_batch_pt.assign(1, 0);
+        const int nshort = npl - (int)pl.long_pts.size();      // long points come last and have their own kernels
+        int cur = 0, pts = 0;
+        for (int t2 = 0; t2 < nshort; ++t2) {
+            const int d = pl.pt_obs[t2 + 1] - pl.pt_obs[t2];
+            if (cur + d > kWave || pts >= kMaxPtsBatch) { pl.bs_batch_obs.push_back(pl.pt_obs[t2]); pl.bs_batch_pt.push_back(t2); cur = 0; pts = 0; }
+            cur += d; ++pts;
+        }
+        if (cur) { pl.bs_batch_obs.push_back(pl.pt_obs[nshort]); pl.bs_batch_pt.push_back(nshort); }
+    }
     return "";
 }
 

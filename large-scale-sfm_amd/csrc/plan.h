@@ -54,6 +54,7 @@ struct Plan {
     std::vector<int64_t> obs_src;                    // original observation index
     std::vector<uint8_t> obs_cslot;                  // tile-local camera slot (LDS tiles)
     std::vector<int> batch_obs, batch_pt;            // nbatch+1
+    std::vector<int> bs_batch_obs, bs_batch_pt;      // batches of k_backsub (same points, packed regardless of tiles)
     std::vector<int64_t> batch_pair;                 // nbatch+1
     std::vector<int> tile_batch, tile_slot, tile_cslot; // ntile+1
     std::vector<uint8_t> tile_mode;                  // 1 register-accumulated blocks, 2 blocks summed in an LDS table, 0 direct global atomics
