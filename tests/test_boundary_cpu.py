@@ -87,6 +87,41 @@ def test_nvm_round_trip(tmp_path):
     assert not L.mi_model_load_nvm(str(tmp_path / "missing.nvm").encode())
 
 
+def test_nvm_quaternion_variant_and_number_spellings(tmp_path):
+    """the older NVM_V3 header: rotation as a quaternion, then the camera CENTRE (util_VSFM.h:176-181,
+    DataInterface.h:183-207, 279-283); and the spellings a number can take in a hand-edited file"""
+    from helpers import rodrigues
+    L = model_lib()
+    sc = vsfm_scene(m=6, n=40, d=3, seed=8)
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    a = sc.p0[:m * cnp].reshape(m, cnp); X = sc.p0[m * cnp:].reshape(n, 3)
+    R = np.einsum("mij,mjk->mik", rodrigues(a[:, 3:6]), sc.R0.reshape(m, 3, 3)); t = a[:, :3]
+    path = str(tmp_path / "q.nvm")
+    with open(path, "w") as fo:
+        fo.write("NVM_V3\n\n%d\n" % m)
+        for j in range(m):
+            Rj = R[j]
+            qw = 0.5 * np.sqrt(max(1e-30, 1 + Rj[0, 0] + Rj[1, 1] + Rj[2, 2]))
+            q = [qw, (Rj[2, 1] - Rj[1, 2]) / (4 * qw), (Rj[0, 2] - Rj[2, 0]) / (4 * qw), (Rj[1, 0] - Rj[0, 1]) / (4 * qw)]
+            C = -Rj.T @ t[j]
+            fo.write("img%d.jpg\t+%.10e " % (j, a[j, 6] / 0.001) + " ".join("%+.15e" % v for v in q + list(C)) + " 0 0\r\n")
+        fo.write("\n%d\n" % n)
+        for i in range(n):
+            o0, o1 = sc.pt_ptr[i], sc.pt_ptr[i + 1]
+            fo.write("%.9E %.9g %.9g 1 2 3 %d " % (*X[i], o1 - o0))
+            fo.write(" ".join("%d %d %.6f %.6f" % (sc.obs_cam[o], 7 * o, sc.x[o, 0], sc.x[o, 1]) for o in range(o0, o1)) + "\n")
+        fo.write("\n0\n\n#the last part of NVM file points to the PLY files\n0\n")
+    h = L.mi_model_load_nvm(path.encode())
+    assert h, L.mi_model_last_error()
+    mdl = read_model(L, h)
+    assert np.abs(mdl["R"].reshape(m, 3, 3) - R).max() < 1e-12 and np.abs(mdl["t"] - t).max() < 1e-10
+    assert np.abs(mdl["f"] - a[:, 6] / 0.001).max() < 1e-6 and np.abs(mdl["xyz"] - X).max() < 1e-8
+    assert np.array_equal(mdl["cam"], sc.obs_cam) and np.abs(mdl["xy"] - sc.x).max() < 1e-6 and mdl["fid"][5] == 35
+    L.mi_model_free(h)
+    open(path, "w").write("NVM_V3_R9T\n3\nimg 800 1 0 0\n")                       # truncated in the first camera
+    assert not L.mi_model_load_nvm(path.encode()) and b"NVM" in L.mi_model_last_error()
+
+
 def test_bal_round_trip_and_convention(tmp_path):
     """BAL text is the -z (Bundler) camera; the loader flips it to +z exactly as LoadBundlerModel does"""
     L = model_lib()
