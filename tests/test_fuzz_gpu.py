@@ -79,3 +79,20 @@ def test_random_ragged_scenes_match_the_oracle(oracle, case):
         # (truncated drivers: a point seen once slides along its ray, a camera with a handful of views along its weak
         #  directions, at next to no cost -- where the rounding-level tail stops moves them by ~1e-4; the cost is the check)
         assert np.abs(eng.packed_params() - o["p"]).max() < (1e-3 if mode else 1e-5)
+
+
+@pytest.mark.parametrize("m,n,d", [(2, 20, 2), (3, 9, 3), (9, 80, 2), (17, 33, 9)])
+def test_tiny_problems(oracle, m, n, d):
+    """the smallest problems sba accepts (2 cameras; barely more measurements than unknowns)"""
+    sc = pkg("scene").make_scene("x", m=m, n=n, d=d, seed=m * 100 + n)
+    capi = pkg("capi")
+    eng = capi.Engine(capi.default_config(pcg_tol=1e-13, pcg_maxit=400))
+    eng.load_scene(sc)
+    eng.prepare()
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert abs(info[0] - o["info"][0]) < 1e-10 * o["info"][0]
+    # few measurements per unknown: the normal equations are poorly conditioned and the tail of the run is rounding-level,
+    # so compare where the cost ends up, not how many trials it took
+    assert abs(info[1] - o["info"][1]) < 1e-6 * max(o["info"][1], 1e-12) or abs(np.sqrt(info[1] / sc.nobs) - np.sqrt(o["info"][1] / sc.nobs)) < 1e-6
+    assert abs(oracle.cost(sc, eng.packed_params()) - info[1]) < 1e-9 * max(info[1], 1e-12)
