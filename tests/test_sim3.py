@@ -117,6 +117,11 @@ def test_full_round_count_and_errors():
     got = capi.sim3_align(src, dst)                            # 5000 rounds, 4.5 M ratios
     assert abs(got["scale"] - 1.0) < 0.01 and np.abs(got["R"] - R).max() < 0.01 and np.abs(got["t"] - t).max() < 0.05
     print("sim3: n = 3000, 5000 rounds, %.1f ms on the device" % got["ms"])
+    # 12 000 points: 72 M ratios (576 MB) materialised and selected from, samples of up to 12 000 indices per round
+    src, dst, scale, R, t = two_clusters(n=12000, seed=6, outliers=600, scale=1.0)
+    got = capi.sim3_align(src, dst, rounds=400)
+    assert abs(got["scale"] - 1.0) < 0.005 and np.abs(got["R"] - R).max() < 0.005 and np.abs(got["t"] - t).max() < 0.03
+    print("sim3: n = 12000, 400 rounds, %.1f ms on the device" % got["ms"])
     with pytest.raises(RuntimeError, match="bad argument"):
         capi.sim3_align(src[:1], dst[:1])
     same = np.ones((5, 3))
