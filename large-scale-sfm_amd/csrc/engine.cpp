@@ -546,6 +546,8 @@ int Engine::begin()
     maxdiag_ = measured_maxdiag();
     eab_inf_ = std::max(h_scal_[SC_EA_INF], h_scal_[SC_EB_INF]);
     mu_ = std::fabs(cfg.opts[0]) * maxdiag_;
+    if (cfg.verbose && cfg.rank == 0)   // sba's own line, sba_levmar.c:844
+        std::printf("initial motstr-SBA error %g [%g]\n", p_eL2_ / (double)nobs_, p_eL2_);
     if (!std::isfinite(p_eL2_)) stop_ = 7;
     begun_ = true;
     return 0;
@@ -624,6 +626,9 @@ int Engine::step()
                     // QUIRK kept (sba_levmar.c:1569-1572): stop 8 leaves before p <- p + dp
                     if (cfg.mode == 0 && s[SC_MAX_PCT] < eps5 && itno_ >= 4) { stop_ = 8; discard = true; } // motstr only
                 }
+                if (cfg.verbose > 1 && cfg.rank == 0)   // per accepted step: iteration, damping, cost, PCG iterations, Bundler's max_pct_change (:1563)
+                    std::printf("[mi_ba] it %3d  mu %.3e  cost %.9g -> %.9g  pcg %3d  max_pct_change %.4g\n", itno_, mu, p_eL2_, pdp_eL2,
+                                (int)s[SC_PCG_ITERS], s[SC_MAX_PCT]);
                 if (!discard) { accept_trial(); p_eL2_ = pdp_eL2; c_lag_ = c_cur; }
                 end_outer();
                 ret = stop_ ? 2 : 1;

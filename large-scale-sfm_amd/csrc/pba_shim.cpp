@@ -123,7 +123,7 @@ int ParallelBA::RunBundleAdjustment()
     cfg.itmax = c.__lm_max_iteration;
     cfg.opts[5] = 0.0;                     // Bundler's "residuals changed by < 4 %" exit (stop 8) is not a PBA rule
     cfg.pcg_maxit = c.__cg_max_iteration; cfg.pcg_tol = c.__cg_norm_threshold;
-    cfg.device = o.device; cfg.verbose = c.__verbose_level;
+    cfg.device = o.device; cfg.verbose = c.__verbose_level >= 3 ? 2 : 0;   // level 2 prints the reference-style lines below, 3 the engine's too
     cfg.mode = c.__bundle_mode_next == 1 ? 1 : c.__bundle_mode_next == 2 ? 2 : 0;        // SetNextBundleMode, pba.h:103
     c.__bundle_mode_next = 0;                                                             // ResetTemporarySetting, ConfigBA.cpp:149-157
     // SetFocalMask: soft equality of focal length (and distortion) inside a group, as a ring of links between its
@@ -199,6 +199,8 @@ int ParallelBA::RunBundleAdjustment()
         c.__num_lm_iteration = (int)info[9];
         if (st == 1) {
             c.__num_lm_success++;
+            if (c.__verbose_level > 1)   // the reference's per-iteration line, SparseBundleCPU.cpp:3910-3919 (iteration, PCG steps, MSE)
+                std::printf("#%-3d %3d  e=%g\n", c.__num_lm_success - 1, (int)c.__num_lm_iteration, (double)o.mse.load());
             // the reference's tests after every successful step (SparseBundleCPU.cpp:3919-3935)
             const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
             if (c.__bundle_time_budget > 0 && secs > c.__bundle_time_budget) { early = 'T'; break; }
