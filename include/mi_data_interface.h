@@ -64,6 +64,83 @@ struct CameraT_ {
         for (int i = 1; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = -m[i][j];
         SetTranslation(T); t[1] = -t[1]; t[2] = -t[2];
     }
+    /* and back (DataInterface.h:298-305), the same with a 3x3 matrix instead of a Rodrigues vector (:306-322) */
+    template <class F> void GetInvertedRT(F e[3], F T[3]) const
+    {
+        CameraT_ flipped;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) flipped.m[i][j] = i ? -m[i][j] : m[i][j];
+        flipped.GetRodriguesRotation(e);
+        T[0] = (F)t[0]; T[1] = (F)-t[1]; T[2] = (F)-t[2];
+    }
+    template <class F> void SetInvertedR9T(const F e[9], const F T[3])
+    {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = (float_t)(i ? -e[3 * i + j] : e[3 * i + j]);
+        t[0] = (float_t)T[0]; t[1] = (float_t)-T[1]; t[2] = (float_t)-T[2];
+    }
+    template <class F> void GetInvertedR9T(F e[9], F T[3]) const
+    {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) e[3 * i + j] = (F)(i ? -m[i][j] : m[i][j]);
+        T[0] = (F)t[0]; T[1] = (F)-t[1]; T[2] = (F)-t[2];
+    }
+    template <class CameraX> void SetCameraT(const CameraX &cam) /* copy across precisions (DataInterface.h:60-68) */
+    {
+        f = (float_t)cam.f;
+        for (int i = 0; i < 3; ++i) { t[i] = (float_t)cam.t[i]; for (int j = 0; j < 3; ++j) m[i][j] = (float_t)cam.m[i][j]; }
+        radial = (float_t)cam.radial; distortion_type = cam.distortion_type; constant_camera = (float_t)cam.constant_camera;
+    }
+    /* unit quaternion (w, x, y, z) <-> R (DataInterface.h:183-242); the input is normalised, (0,0,0,0) gives the identity */
+    template <class F> void SetQuaternionRotation(const F q[4])
+    {
+        const double nq = std::sqrt((double)(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+        const double w = nq > 0 ? q[0] / nq : 1.0, x = nq > 0 ? q[1] / nq : 0.0, y = nq > 0 ? q[2] / nq : 0.0, z = nq > 0 ? q[3] / nq : 0.0;
+        m[0][0] = float_t(w * w + x * x - y * y - z * z); m[0][1] = float_t(2 * (x * y - z * w));         m[0][2] = float_t(2 * (y * w + z * x));
+        m[1][0] = float_t(2 * (x * y + w * z));         m[1][1] = float_t(w * w - x * x + y * y - z * z); m[1][2] = float_t(2 * (z * y - x * w));
+        m[2][0] = float_t(2 * (x * z - y * w));         m[2][1] = float_t(2 * (y * z + w * x));         m[2][2] = float_t(w * w - x * x - y * y + z * z);
+    }
+    template <class F> void GetQuaternionRotation(F q[4]) const
+    {
+        const double tr = 1.0 + m[0][0] + m[1][1] + m[2][2];
+        if (tr > 1e-9) {
+            const double w = std::sqrt(tr) / 2.0;
+            q[0] = (F)w; q[1] = (F)((m[2][1] - m[1][2]) / (4.0 * w)); q[2] = (F)((m[0][2] - m[2][0]) / (4.0 * w)); q[3] = (F)((m[1][0] - m[0][1]) / (4.0 * w));
+            return;
+        }
+        /* rotation by ~pi: branch on the largest diagonal entry, signs as the reference leaves them */
+        const int k = (m[0][0] > m[1][1] && m[0][0] > m[2][2]) ? 0 : (m[1][1] > m[2][2] ? 1 : 2), a = (k + 1) % 3, b = (k + 2) % 3;
+        const double s = 2.0 * std::sqrt(1.0 + m[k][k] - m[a][a] - m[b][b]);
+        q[1 + k] = (F)(0.25 * s);
+        q[1 + a] = (F)((m[k][a] + m[a][k]) / s);
+        q[1 + b] = (F)((m[k][b] + m[b][k]) / s);
+        q[0] = (F)((k == 0 ? m[1][2] - m[2][1] : k == 1 ? m[0][2] - m[2][0] : m[0][1] - m[1][0]) / s);
+    }
+    /* R -> Rodrigues vector (DataInterface.h:108-181): zero for the identity, the pi cases by the largest diagonal entry */
+    template <class F> void GetRodriguesRotation(F r[3]) const
+    {
+        const double pi = 3.14159265358979323846, c = (m[0][0] + m[1][1] + m[2][2] - 1.0) / 2.0, eps = 0.01;
+        const bool symmetric = std::fabs(m[0][1] - m[1][0]) < eps && std::fabs(m[1][2] - m[2][1]) < eps && std::fabs(m[0][2] - m[2][0]) < eps;
+        if (!symmetric) {
+            const double a = std::acos(c), b = 0.5 * a / std::sin(a);
+            r[0] = (F)(b * (m[2][1] - m[1][2])); r[1] = (F)(b * (m[0][2] - m[2][0])); r[2] = (F)(b * (m[1][0] - m[0][1]));
+            return;
+        }
+        if (std::fabs(m[0][1] + m[1][0]) < 0.1 && std::fabs(m[1][2] + m[2][1]) < 0.1 && std::fabs(m[0][2] + m[2][0]) < 0.1 && c > 0.9) {
+            r[0] = r[1] = r[2] = 0;
+            return;
+        }
+        const double d[3] = { (m[0][0] + 1.0) / 2.0, (m[1][1] + 1.0) / 2.0, (m[2][2] + 1.0) / 2.0 };
+        const double o[3][3] = { { 0, (m[0][1] + m[1][0]) / 4.0, (m[0][2] + m[2][0]) / 4.0 },
+                                 { (m[0][1] + m[1][0]) / 4.0, 0, (m[1][2] + m[2][1]) / 4.0 },
+                                 { (m[0][2] + m[2][0]) / 4.0, (m[1][2] + m[2][1]) / 4.0, 0 } };
+        const int k = (d[0] > d[1] && d[0] > d[2]) ? 0 : (d[1] > d[2] ? 1 : 2), a = (k + 1) % 3, b = (k + 2) % 3;
+        if (d[k] < eps) { r[k] = 0; r[a] = r[b] = (F)(std::sqrt(0.5) * pi); return; }
+        const double s = std::sqrt(d[k]);
+        r[k] = (F)(s * pi); r[a] = (F)(o[k][a] / s * pi); r[b] = (F)(o[k][b] / s * pi);
+    }
+    float GetRotationMatrixDeterminant() const
+    {
+        return (float)(m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]));
+    }
 };
 
 template <class FT>

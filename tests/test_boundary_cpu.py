@@ -54,6 +54,35 @@ def test_the_references_own_parallelba_runs_behind_our_header(tmp_path):
         assert np.abs(r["f"] - z[name + "_f"]).max() < 1e-3 and np.abs(r["pts"] - z[name + "_pts"]).max() < 1e-6
 
 
+def test_camera_rotation_helpers(tmp_path):
+    """CameraT_'s quaternion / Rodrigues / inverted-frame helpers (DataInterface.h:93-322) against scipy"""
+    import subprocess
+    from scipy.spatial.transform import Rotation
+    exe = str(tmp_path / "camera_methods")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "camera_methods.cpp"), "-o", exe])
+    rng = np.random.default_rng(3)
+    rots = [Rotation.from_rotvec(v) for v in rng.normal(0, 1.2, (40, 3))]
+    rots += [Rotation.from_rotvec(np.pi * v / np.linalg.norm(v)) for v in rng.normal(0, 1, (6, 3))]          # half turns
+    rots += [Rotation.identity(), Rotation.from_rotvec([1e-4, -2e-4, 3e-4])]
+    inp = "\n".join(" ".join("%.17g" % v for v in r.as_matrix().reshape(-1)) for r in rots)
+    out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout
+    vals = np.array([[float(v) for v in ln.split()] for ln in out.strip().splitlines()])
+    for r, v in zip(rots, vals):
+        R = r.as_matrix()
+        q = v[[1, 2, 3, 0]]                                             # (w, x, y, z) -> scipy's (x, y, z, w)
+        assert np.abs(Rotation.from_quat(q).as_matrix() - R).max() < 1e-9
+        assert np.abs(v[7:16].reshape(3, 3) - R).max() < 1e-9           # SetQuaternionRotation(GetQuaternionRotation)
+        ang = np.linalg.norm(r.as_rotvec())
+        if ang > 0.2 and ang < np.pi - 0.05:                            # (the reference zeroes small rotations and special-cases pi)
+            assert np.abs(Rotation.from_rotvec(v[4:7]).as_matrix() - R).max() < 1e-9
+            assert np.abs(v[16:25].reshape(3, 3) - R).max() < 1e-9
+        elif ang <= 0.2 and np.abs(R - R.T).max() < 0.01 and np.trace(R) > 2.8:
+            assert np.all(v[4:7] == 0)
+        assert v[25] < 1e-24 and abs(v[27] - 1.0) < 1e-6
+        assert v[26] < 1e-3                                             # (within 0.01 of a half turn the reference's formula is approximate)
+        assert abs(v[28] - np.float32(R[1, 2])) < 1e-7                  # SetCameraT: double -> float copy
+
+
 def test_no_gpu_is_a_loud_error():
     import torch
     if torch.cuda.is_available():
