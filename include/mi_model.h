@@ -54,11 +54,26 @@ int mi_model_set_focal_mask(mi_model *mdl, const int *mask /* ncam */, double we
 /* bundle adjust in place.  cfg: only itmax, opts, pcg_*, est_focal, mcon, device, verbose are read (the
  * camera convention of the file fixes the rest).  Returns LM iterations or MI_BA_ERROR. */
 int mi_model_optimize(mi_model *mdl, const mi_ba_config *cfg, double info[MI_BA_INFOSZ]);
+/* one rank of a point-sharded solve (one process per GPU): cfg->rank / cfg->world name the shard and cfg->device
+ * the GPU; every rank holds the whole model and ends with the whole answer.  Transport: unique_id (mi_ba_comm_unique_id of
+ * rank 0, handed to the others by the caller: RCCL over xGMI) or host_allreduce (mi_ba_comm_set_host_allreduce).
+ * rendezvous, optional: called once with ok = "this rank opened its device", returns non-zero when every rank did -- so that
+ * no rank enters a collective another one will never reach.  shard NULL = mi_model_optimize. */
+typedef struct {
+    const char *unique_id;
+    mi_ba_host_allreduce_fn host_allreduce;
+    void *host_user;
+    int (*rendezvous)(void *user, int ok);
+    void *rendezvous_user;
+} mi_model_shard;
+int mi_model_optimize_shard(mi_model *mdl, const mi_ba_config *cfg, double info[MI_BA_INFOSZ], const mi_model_shard *shard);
 /* sqrt(sum ||x - x^||^2 / nproj) in pixels with the cameras/points currently in the model (host) */
 double mi_model_rmse(const mi_model *mdl);
 
 /* the process ABI:  optimizer_all <dir>/ A B C D E F   (SiftGPU/MergeClusters.cpp:1099-1110).
- * Reads <dir>/outputVSFM_GB.nvm, refines, overwrites it.  Returns the process exit status. */
+ * Reads <dir>/outputVSFM_GB.nvm, refines, overwrites it.  Returns the process exit status.
+ * MI_BA_GPUS=N in the environment: the process forks N - 1 further ranks before it touches HIP, one GPU each
+ * (MI_BA_DEVICE + rank), points sharded, RCCL all-reduce per trial; rank 0 writes the file. */
 int mi_optimizer_all_main(int argc, char **argv);
 
 #ifdef __cplusplus

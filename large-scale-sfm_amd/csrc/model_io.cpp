@@ -1,6 +1,7 @@
 // model_io.cpp -- NVM / BAL text I/O and the optimizer_all process contract (include/mi_model.h).
 // Host code; the numeric work is mi_ba.h's engine.
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <chrono>
 #include <cmath>
@@ -8,10 +9,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <sstream>
 #include <string>
 #include <vector>
+
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "focal_links.h"
 
@@ -472,16 +479,34 @@ int mi_model_set_focal_mask(mi_model *m, const int *mask, double weight)
 
 int mi_model_optimize(mi_model *m, const mi_ba_config *user, double info[MI_BA_INFOSZ])
 {
+    return mi_model_optimize_shard(m, user, info, nullptr);
+}
+
+int mi_model_optimize_shard(mi_model *m, const mi_ba_config *user, double info[MI_BA_INFOSZ], const mi_model_shard *shard)
+{
     if (!m) return MI_BA_ERROR;
     mi_ba_config cfg;
     mi_ba_default_config(&cfg);
     if (user) {
         cfg.itmax = user->itmax; std::memcpy(cfg.opts, user->opts, sizeof(cfg.opts)); cfg.pcg_maxit = user->pcg_maxit; cfg.pcg_tol = user->pcg_tol;
         cfg.est_focal = user->est_focal; cfg.mcon = user->mcon; cfg.device = user->device; cfg.verbose = user->verbose;
+        if (shard) { cfg.rank = user->rank; cfg.world = user->world; }
     }
     cfg.explicit_centers = 0; cfg.proj_sign = 1.0; // file convention: x^ = f (R X + t).xy / z
+    const bool sharded = shard && cfg.world > 1;
+    if (sharded && !shard->unique_id && !shard->host_allreduce) { g_err = "optimize_shard: world > 1 needs a transport"; return MI_BA_ERROR; }
     mi_ba_engine *e = mi_ba_create(&cfg);
-    if (!e) { g_err = mi_ba_last_error(nullptr); return MI_BA_ERROR; }
+    if (!e) g_err = mi_ba_last_error(nullptr);
+    if (shard && shard->rendezvous && !shard->rendezvous(shard->rendezvous_user, e != nullptr)) { // every rank has its device, or none goes on
+        if (e) { g_err = "optimize_shard: another rank failed to open its device"; mi_ba_destroy(e); }
+        return MI_BA_ERROR;
+    }
+    if (!e) return MI_BA_ERROR;
+    if (sharded) {
+        const int rc = shard->host_allreduce ? mi_ba_comm_set_host_allreduce(e, shard->host_allreduce, shard->host_user)
+                                             : mi_ba_comm_init(e, shard->unique_id);
+        if (rc != 0) { g_err = mi_ba_last_error(e); mi_ba_destroy(e); return MI_BA_ERROR; }
+    }
     const int ncam = (int)m->ncam(), npt = (int)m->npt(), cnp = mi_ba_cnp(e);
     miba::FocalLinks fl;
     if (!m->focal_mask.empty() && cfg.est_focal) { // shared intrinsics, as ParallelBA::SetFocalMask (pba.h:124)
@@ -516,11 +541,82 @@ int mi_model_optimize(mi_model *m, const mi_ba_config *user, double info[MI_BA_I
     return ret;
 }
 
+// ---- several GPUs behind the one process the callers spawn --------------------------------------------------------------------
+// MI_BA_GPUS=N: optimizer_all forks N - 1 further ranks BEFORE anything touches HIP (the model is already parsed, the children
+// share its pages), every rank opens its own GPU (MI_BA_DEVICE + rank), takes its shard of the points and the ranks meet in
+// the engine's one exchange per trial (mi_ba.h; RCCL over xGMI).  What the ranks share is one anonymous mapping: the RCCL
+// unique id, one status word per rank, and -- for MI_BA_TRANSPORT=host only -- the arena of a host all-reduce that lets the
+// ranks share ONE GPU (how the tests run this path on a one-GPU box).
+struct RankShared {
+    static constexpr int kMaxRanks = 64;
+    static constexpr int64_t kChunk = 1 << 20; // doubles per rank and round of the host all-reduce
+    std::atomic<int> status[kMaxRanks];        // 0 not there yet, 1 device open, -1 failed
+    std::atomic<int> uid_ready, failed, arrived, generation;
+    char uid[MI_BA_UNIQUE_ID_BYTES];
+    int world;
+    double *slot(int r) { return reinterpret_cast<double *>(reinterpret_cast<char *>(this) + 4096) + (size_t)r * kChunk; }
+    static size_t bytes(int world, bool arena) { return 4096 + (arena ? sizeof(double) * (size_t)kChunk * world : 0); }
+};
+static_assert(sizeof(RankShared) <= 4096, "header page");
+
+struct RankCtx { RankShared *sh; int rank; };
+
+static bool wait_until(RankShared *sh, const std::function<bool()> &ready, double limit_s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spin = 0; !ready(); ++spin) {
+        if (sh->failed.load()) return false;
+        if ((spin & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+            sh->failed.store(1);
+            return false;
+        }
+        sched_yield();
+    }
+    return true;
+}
+
+static bool rank_barrier(RankShared *sh)
+{
+    const int g = sh->generation.load();
+    if (sh->arrived.fetch_add(1) + 1 == sh->world) { sh->arrived.store(0); sh->generation.fetch_add(1); return !sh->failed.load(); }
+    return wait_until(sh, [&]() { return sh->generation.load() != g; }, 600.0);
+}
+
+static int rank_rendezvous(void *user, int ok)
+{
+    RankCtx *c = static_cast<RankCtx *>(user);
+    c->sh->status[c->rank].store(ok ? 1 : -1);
+    if (!ok) c->sh->failed.store(1);
+    return wait_until(c->sh, [&]() {
+        for (int r = 0; r < c->sh->world; ++r) if (c->sh->status[r].load() == 0) return false;
+        return true; }, 600.0) ? 1 : 0;
+}
+
+// sum / maximum over the ranks in rank order: every rank computes the same bits
+static int rank_host_allreduce(void *user, double *buf, int64_t count, int op)
+{
+    RankCtx *c = static_cast<RankCtx *>(user);
+    RankShared *sh = c->sh;
+    for (int64_t off = 0; off < count; off += RankShared::kChunk) {
+        const int64_t len = std::min<int64_t>(RankShared::kChunk, count - off);
+        std::memcpy(sh->slot(c->rank), buf + off, sizeof(double) * (size_t)len);
+        if (!rank_barrier(sh)) return -1;
+        for (int64_t i = 0; i < len; ++i) {
+            double acc = sh->slot(0)[i];
+            for (int r = 1; r < sh->world; ++r) { const double v = sh->slot(r)[i]; acc = op == 1 ? std::max(acc, v) : acc + v; }
+            buf[off + i] = acc;
+        }
+        if (!rank_barrier(sh)) return -1;
+    }
+    return 0;
+}
+
 // optimizer_all <dir>/ A B C D E F.  The reference's main (Optimizer/main_all.cpp) is missing from its
 // tree, so the meaning of A..F is the one documented in INTEGRATION.md:
 //   A  which blocks are free (utils.h:112 whatToCalibrate): < 0 -> intrinsics held (cnp 6), >= 0 -> pose + focal (cnp 7)
 //   B  maximum LM iterations          C, D  accepted, unused (always 16 / 32 at the call sites)
 //   E  accepted, unused (curErrorThresh, utils.cpp:35)        F  back end selector: every value runs this engine
+// Environment: MI_BA_DEVICE (first GPU, default 0), MI_BA_GPUS (ranks = GPUs, default 1), MI_BA_TRANSPORT (rccl | host).
 int mi_optimizer_all_main(int argc, char **argv)
 {
     if (argc < 2) {
@@ -542,10 +638,64 @@ int mi_optimizer_all_main(int argc, char **argv)
     cfg.est_focal = A >= 0 ? 1 : 0;
     cfg.itmax = B > 0 ? B : 1;
     if (const char *dev = std::getenv("MI_BA_DEVICE")) cfg.device = std::atoi(dev);
+    const char *gpus = std::getenv("MI_BA_GPUS"), *transport = std::getenv("MI_BA_TRANSPORT");
+    const int world = gpus ? std::atoi(gpus) : 1;
+    const bool host_transport = transport && std::strcmp(transport, "host") == 0;
+    if (world < 1 || world > RankShared::kMaxRanks || (transport && !host_transport && std::strcmp(transport, "rccl") != 0)) {
+        std::fprintf(stderr, "optimizer_all: MI_BA_GPUS must be 1..%d and MI_BA_TRANSPORT rccl or host\n", RankShared::kMaxRanks);
+        mi_model_free(m);
+        return 2;
+    }
     double info[MI_BA_INFOSZ] = { 0 };
     const double rmse0 = mi_model_rmse(m);
     std::printf("%zu cameras; %zu 3D points; %zu projections\n", m->ncam(), m->npt(), m->nproj());
-    const int it = mi_model_optimize(m, &cfg, info);
+    int it = MI_BA_ERROR;
+    if (world == 1) {
+        it = mi_model_optimize(m, &cfg, info);
+    } else {
+        const size_t bytes = RankShared::bytes(world, host_transport);
+        void *mem = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (mem == MAP_FAILED) { std::fprintf(stderr, "optimizer_all: cannot map the ranks' shared page\n"); mi_model_free(m); return 1; }
+        RankShared *sh = new (mem) RankShared; // zero pages: every atomic starts at 0
+        sh->world = world;
+        std::fflush(stdout); std::fflush(stderr);
+        int rank = 0;
+        std::vector<pid_t> kids;
+        for (int r = 1; r < world; ++r) { // no HIP call has been made yet: the children start with a clean runtime
+            const pid_t pid = fork();
+            if (pid < 0) { sh->failed.store(1); std::fprintf(stderr, "optimizer_all: fork failed\n"); break; }
+            if (pid == 0) { rank = r; kids.clear(); break; }
+            kids.push_back(pid);
+        }
+        RankCtx ctx{ sh, rank };
+        cfg.rank = rank; cfg.world = world;
+        if (!host_transport) cfg.device += rank;
+        if (rank != 0) cfg.verbose = 0;
+        mi_model_shard shard = {};
+        shard.rendezvous = rank_rendezvous; shard.rendezvous_user = &ctx;
+        bool ok = !sh->failed.load();
+        if (host_transport) { shard.host_allreduce = rank_host_allreduce; shard.host_user = &ctx; }
+        else if (ok) {
+            if (rank == 0) {
+                if (mi_ba_comm_unique_id(sh->uid) == 0) sh->uid_ready.store(1);
+                else { sh->failed.store(1); ok = false; g_err = "cannot create the RCCL unique id"; }
+            } else ok = wait_until(sh, [&]() { return sh->uid_ready.load() != 0; }, 600.0);
+            shard.unique_id = sh->uid;
+        }
+        if (ok) it = mi_model_optimize_shard(m, &cfg, info, &shard);
+        if (it == MI_BA_ERROR) sh->failed.store(1);
+        if (rank != 0) {
+            if (it == MI_BA_ERROR) std::fprintf(stderr, "optimizer_all: rank %d: %s\n", rank, g_err.empty() ? "another rank failed" : g_err.c_str());
+            std::fflush(stderr);
+            std::_Exit(it == MI_BA_ERROR ? 1 : 0); // the answer is rank 0's to write
+        }
+        for (pid_t pid : kids) {
+            int st = 0;
+            if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { if (it != MI_BA_ERROR) g_err = "a rank ended abnormally"; it = MI_BA_ERROR; }
+        }
+        munmap(mem, bytes);
+        if (it != MI_BA_ERROR) std::printf("optimizer_all: %d ranks, %s\n", world, host_transport ? "host all-reduce on one GPU" : "RCCL all-reduce, one GPU each");
+    }
     if (it == MI_BA_ERROR) { std::fprintf(stderr, "optimizer_all: %s\n", mi_model_last_error()); mi_model_free(m); return 1; }
     const double t_solve = seconds();
     std::printf("optimizer_all: %d LM iterations (stop %d), reprojection RMSE %.6f -> %.6f px\n", it, (int)info[6], rmse0, mi_model_rmse(m));

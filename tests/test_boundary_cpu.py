@@ -92,6 +92,28 @@ def test_no_gpu_is_a_loud_error():
         capi.Engine()
 
 
+@pytest.mark.parametrize("env", [{"MI_BA_GPUS": "3"}, {"MI_BA_GPUS": "2", "MI_BA_TRANSPORT": "host"}])
+def test_optimizer_all_ranks_without_a_gpu_end_loudly_and_together(tmp_path, env):
+    """MI_BA_GPUS=N forks N - 1 ranks; when a rank cannot open its device every rank gives up (no rank waits in a collective
+    the others never reach) and the file is left alone"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    sc = vsfm_scene(m=8, n=200, d=4, seed=3)
+    d = tmp_path / "c"; d.mkdir()
+    nvm = str(d / "outputVSFM_GB.nvm")
+    write_nvm(nvm, sc)
+    before = open(nvm).read()
+    exe = os.path.join(ROOT, "large-scale-sfm_amd", "bin", "optimizer_all")
+    out = subprocess.run([exe, str(d) + "/", "0", "20", "16", "32", "0.5", "0"], capture_output=True, text=True, timeout=120,
+                         env={**os.environ, **env})
+    assert out.returncode == 1 and "optimizer_all:" in out.stderr
+    assert open(nvm).read() == before
+    bad = subprocess.run([exe, str(d) + "/"], capture_output=True, text=True, timeout=60, env={**os.environ, "MI_BA_GPUS": "65"})
+    assert bad.returncode == 2 and "MI_BA_GPUS" in bad.stderr
+
+
 def test_nvm_round_trip(tmp_path):
     L = model_lib()
     sc = vsfm_scene(m=8, n=120, d=4, seed=4)

@@ -297,6 +297,22 @@ def test_config_c5_merged_clusters_global_refine(tmp_path, oracle):
     assert rmse1 < 0.21                                                # seams closed, noise level reached
     assert [int(x) for x in open(nvm).read().split("\n")[2:4][0].split()[:1]] == [1000]   # camera names kept
     assert len(mdl["f"]) == m and np.all(np.abs(mdl["f"] - 800) < 40)
+    # the same refine with the points sharded over 3 ranks (MI_BA_GPUS; here the ranks share the one GPU of the box through the
+    # host all-reduce -- on a node every rank has its own GPU and the exchange is RCCL's): same decisions, same answer
+    d3 = tmp_path / "dendogram" / "cluster16"; d3.mkdir(parents=True)
+    nvm3 = str(d3 / "outputVSFM_GB.nvm")
+    write_nvm(nvm3, sc, p_init, names=["%d" % (1000 + j) for j in range(m)])
+    out3 = subprocess.run([exe, str(d3) + "/", "0", "100", "16", "32", "1", "0"], capture_output=True, text=True, timeout=600,
+                          env={**os.environ, "MI_BA_GPUS": "3", "MI_BA_TRANSPORT": "host"})
+    assert out3.returncode == 0, out3.stderr
+    assert "3 ranks" in out3.stdout
+    lm = [l for l in out.stdout.splitlines() if "LM iterations" in l][0].split("reprojection")[0]
+    lm3 = [l for l in out3.stdout.splitlines() if "LM iterations" in l][0].split("reprojection")[0]
+    assert lm == lm3                                                   # iterations and stop reason
+    h = L.mi_model_load_nvm(nvm3.encode()); rmse3 = L.mi_model_rmse(h)
+    mdl3 = read_model(L, h); L.mi_model_free(h)
+    assert abs(rmse3 - rmse1) < 1e-6
+    assert np.abs(mdl3["xyz"] - mdl["xyz"]).max() < 1e-5 and np.abs(mdl3["t"] - mdl["t"]).max() < 1e-5 and np.abs(mdl3["f"] - mdl["f"]).max() < 1e-3
 
 
 def test_two_clusters_aligned_merged_and_refined(tmp_path):

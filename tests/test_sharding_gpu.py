@@ -15,26 +15,47 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, outdir, with_long_tracks):
+def _case(kind):
+    """scene, config keywords and the extras applied to an engine before prepare()"""
+    from conftest import pkg as _pkg
+    scene = _pkg("scene")
+    if kind == "long":
+        from helpers import ladybug_like_scene
+        return ladybug_like_scene(m=120, n=3000, dmax=90, seed=9), {}, lambda eng: None
+    if kind == "extras":   # radial coefficient, links between cameras, soft constraints on cameras and points: the camera-side
+        sc = scene.make_scene("x", m=40, n=6000, d=6, seed=78, undistort=1, nk=1)   # terms are replicated, the point-side sharded
+        rng = np.random.default_rng(4)
+        la = np.arange(0, 12); lb = (la + 1) % 12
+        w = np.zeros((12, sc.cnp)); w[:, 6] = 2e6
+        cam_w = np.zeros((sc.m, sc.cnp)); cam_w[5:9, :3] = 50.0
+        cam_v = sc.p0[:sc.m * sc.cnp].reshape(sc.m, sc.cnp).copy()
+        pt_w = np.where(rng.random(sc.n) < 0.05, 1e-3, 0.0)
+        pt_v = sc.p0[sc.m * sc.cnp:].reshape(sc.n, 3) + rng.normal(0, 0.01, (sc.n, 3))
+
+        def extras(eng):
+            eng.set_camera_links(la, lb, w)
+            eng.set_constraints(cam_w, cam_v, pt_w, pt_v)
+        return sc, dict(undistort=1), extras
+    return scene.make_scene("x", m=40, n=6000, d=6, seed=77), {}, lambda eng: None
+
+
+def _worker(rank, world, port, outdir, kind):
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     from conftest import pkg as _pkg
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    scene, capi = _pkg("scene"), _pkg("capi")
-    if with_long_tracks:
-        from helpers import ladybug_like_scene
-        sc = ladybug_like_scene(m=120, n=3000, dmax=90, seed=9)
-    else:
-        sc = scene.make_scene("x", m=40, n=6000, d=6, seed=77)
-    eng = capi.Engine(capi.default_config(rank=rank, world=world, device=0, pcg_tol=1e-12, pcg_maxit=400, mcon=1))
+    capi = _pkg("capi")
+    sc, kw, extras = _case(kind)
+    eng = capi.Engine(capi.default_config(rank=rank, world=world, device=0, pcg_tol=1e-12, pcg_maxit=400, mcon=1, **kw))
 
     def allreduce(buf, op):
         t = torch.from_numpy(buf)                       # shares memory with the engine's staging buffer
         dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
     eng.set_host_allreduce(allreduce)
     eng.load_scene(sc)
+    extras(eng)
     eng.prepare()
     ret, info = eng.run()
     p = eng.packed_params()
@@ -44,26 +65,22 @@ def _worker(rank, world, port, outdir, with_long_tracks):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,long_tracks", [(2, False), (3, True)])
-def test_ranks_sharing_one_gpu_reproduce_the_single_rank_solve(tmp_path, world, long_tracks):
+@pytest.mark.parametrize("world,kind", [(2, "plain"), (3, "long"), (2, "extras")])
+def test_ranks_sharing_one_gpu_reproduce_the_single_rank_solve(tmp_path, world, kind):
     import torch.multiprocessing as mp
     from conftest import pkg
-    port = 29600 + (os.getpid() % 2000) + world
-    mp.spawn(_worker, args=(world, port, str(tmp_path), long_tracks), nprocs=world, join=True)
+    port = 29600 + (os.getpid() % 2000) + world + 7 * len(kind)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), kind), nprocs=world, join=True)
     res = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     # every rank took the same decisions and holds the same answer, bit for bit
     for r in res[1:]:
         assert int(r["ret"]) == int(res[0]["ret"]) and np.array_equal(r["info"], res[0]["info"])
         assert np.array_equal(r["p"], res[0]["p"]) and np.array_equal(r["trace"], res[0]["trace"])
     # and it is the single-rank answer (the partial sums are added in another order: rounding-level differences)
-    scene, capi = pkg("scene"), pkg("capi")
-    if long_tracks:
-        from helpers import ladybug_like_scene
-        sc = ladybug_like_scene(m=120, n=3000, dmax=90, seed=9)
-    else:
-        sc = scene.make_scene("x", m=40, n=6000, d=6, seed=77)
-    eng = capi.Engine(capi.default_config(pcg_tol=1e-12, pcg_maxit=400, mcon=1))
-    eng.load_scene(sc); eng.prepare()
+    capi = pkg("capi")
+    sc, kw, extras = _case(kind)
+    eng = capi.Engine(capi.default_config(pcg_tol=1e-12, pcg_maxit=400, mcon=1, **kw))
+    eng.load_scene(sc); extras(eng); eng.prepare()
     ret, info = eng.run()
     assert abs(int(res[0]["ret"]) - ret) <= 1 and res[0]["info"][6] == info[6]
     assert abs(res[0]["info"][1] - info[1]) < 1e-9 * info[1]
