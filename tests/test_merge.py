@@ -1,0 +1,229 @@
+"""The cluster-merge step (include/mi_merge.h; SiftGPU/Merge3D3D.cpp:564-908): correspondences by point id, the second model
+moved into the first one's frame by the GPU alignment, tracks fused, side files, and the Merge3D3D process with its
+optimizer_all children.  The reference file cannot be built here (Eigen, OpenCV): the expected model is a numpy
+restatement of its steps, the expected transform comes from oracle/sim3_oracle.c."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, pkg
+from helpers import model_lib, read_model, rodrigues, vsfm_scene
+from test_sim3 import Sim3Oracle
+
+
+class MergeConfig(C.Structure):
+    _fields_ = [("rounds", C.c_int), ("device", C.c_int), ("keep_colours", C.c_int), ("reserved", C.c_int * 5)]
+
+
+class MergeResult(C.Structure):
+    _fields_ = [("ncorr", C.c_int64), ("scale", C.c_double), ("R", C.c_double * 9), ("t", C.c_double * 3), ("best_round", C.c_int),
+                ("device_ms", C.c_double), ("ncam_first", C.c_int64), ("npt_first", C.c_int64)]
+
+
+def merge_lib():
+    L = model_lib()
+    L.mi_model_merge_3d3d.restype = C.c_void_p
+    L.mi_model_merge_3d3d.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(MergeConfig), C.POINTER(MergeResult)]
+    L.mi_model_save_merge_side_files.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.mi_model_last_error.restype = C.c_char_p
+    return L
+
+
+def write_cluster(path, cl):
+    with open(path, "w") as fo:
+        fo.write("NVM_V3_R9T\n%d\n" % len(cl["f"]))
+        for j in range(len(cl["f"])):
+            fo.write("%s %.12g " % (cl["names"][j], cl["f"][j]) + " ".join("%.12g" % v for v in cl["R"][j].reshape(-1)))
+            fo.write(" %.12g %.12g %.12g 0 0\n" % tuple(cl["t"][j]))
+        fo.write("%d\n" % len(cl["X"]))
+        for i, tr in enumerate(cl["tracks"]):
+            fo.write("%.12g %.12g %.12g %d %d %d %d " % (*cl["X"][i], *cl["rgb"][i], len(tr)))
+            fo.write("".join("%d %d %.12g %.12g " % v for v in tr) + "\n")
+
+
+def clusters_of(sc, ranges, frames, rng, est_noise=0.002):
+    """sub-reconstructions of one scene: cluster c holds the cameras ranges[c] and the points at least two of them see, in its
+    own similarity frame X_world = s Rg X_c + T"""
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    a = sc.p0[:m * cnp].reshape(m, cnp); X = sc.p0[m * cnp:].reshape(n, 3)
+    R = np.einsum("mij,mjk->mik", rodrigues(a[:, 3:6]), sc.R0.reshape(m, 3, 3)); t = a[:, :3]
+    out = []
+    for (lo, hi), (s, Rg, T) in zip(ranges, frames):
+        cl = dict(names=["%d" % (500 + j) for j in range(lo, hi)], f=a[lo:hi, 6] / 0.001, R=np.einsum("mij,jk->mik", R[lo:hi], Rg),
+                  t=(t[lo:hi] + np.einsum("mij,j->mi", R[lo:hi], T)) / s, X=[], rgb=[], tracks=[], gid=[])
+        for i in range(n):
+            obs = [o for o in range(sc.pt_ptr[i], sc.pt_ptr[i + 1]) if lo <= sc.obs_cam[o] < hi]
+            if len(obs) < 2:
+                continue
+            cl["X"].append((X[i] - T) @ Rg / s + rng.normal(0, est_noise, 3))
+            cl["rgb"].append((i % 256, (2 * i) % 256, (3 * i) % 256))
+            cl["tracks"].append([(int(sc.obs_cam[o]) - lo, 1000 + i, float(sc.x[o, 0]), float(sc.x[o, 1])) for o in obs])
+            cl["gid"].append(i)
+        cl["X"] = np.array(cl["X"])
+        out.append(cl)
+    return out
+
+
+def np_views(cl):
+    """ReadNVM, Merge3D3D.cpp:508-523: the id is the last view's field, a view on the previous view's camera is dropped"""
+    ids, tracks = [], []
+    for tr in cl["tracks"]:
+        ids.append(tr[-1][1] if tr else -1)
+        kept, prev = [], -1
+        for v in tr:
+            if v[0] == prev:
+                continue
+            prev = v[0]; kept.append(v)
+        tracks.append(kept)
+    return ids, tracks
+
+
+def np_merge(c1, c2, s, R, T, recolour=True):
+    id1, tr1 = np_views(c1); id2, tr2 = np_views(c2)
+    match = []
+    for i, a in enumerate(id1):                                         # :646-683, the quadratic scan as written there
+        for j, b in enumerate(id2):
+            if a == b:
+                match.append((i, j)); break
+    nc1, n1 = len(c1["f"]), len(c1["X"])
+    X2 = (s * c2["X"]) @ R.T + T
+    R2 = np.einsum("mij,kj->mik", c2["R"], R)
+    cen = -np.einsum("mji,mj->mi", c2["R"], c2["t"])
+    cen = (s * cen) @ R.T + T
+    t2 = -np.einsum("mij,mj->mi", R2, cen)
+    rgb1 = np.tile([255, 0, 0], (n1, 1)) if recolour else np.array(c1["rgb"])
+    rgb2 = np.tile([0, 255, 0], (len(c2["X"]), 1)) if recolour else np.array(c2["rgb"])
+    tracks = [list(t) for t in tr1]
+    for i, j in match:
+        if recolour:
+            rgb1[i] = (0, 0, 255); rgb2[j] = (255, 255, 255)
+        tracks[i] += [(v[0] + nc1,) + v[1:] for v in tr2[j]]
+    tracks += [[(v[0] + nc1,) + v[1:] for v in t] for t in tr2]
+    ids = id1 + id2
+    cam = [v[0] for t in tracks for v in t]; pt = [i for i, t in enumerate(tracks) for _ in t]
+    fid = [ids[i] for i, t in enumerate(tracks) for _ in t]; xy = [(v[2], v[3]) for t in tracks for v in t]
+    return dict(match=match, f=np.concatenate([c1["f"], c2["f"]]), R=np.concatenate([c1["R"], R2]).reshape(-1, 9), t=np.concatenate([c1["t"], t2]),
+                xyz=np.concatenate([c1["X"], X2]), rgb=np.concatenate([rgb1, rgb2]), cam=np.array(cam), pt=np.array(pt), fid=np.array(fid),
+                xy=np.array(xy), names=c1["names"] + c2["names"])
+
+
+FRAMES = [(1.0, np.eye(3), np.zeros(3)), (1.8, rodrigues(np.array([[0.4, -0.7, 0.5]]))[0], np.array([3.0, -1.0, 2.0])),
+          (0.6, rodrigues(np.array([[-0.2, 0.3, 1.1]]))[0], np.array([-2.0, 0.5, 1.0]))]
+
+
+def test_side_files_of_a_model(tmp_path):
+    """host only: the files the reference leaves beside the merged NVM, formats of Merge3D3D.cpp:811-900"""
+    L = merge_lib()
+    sc = vsfm_scene(m=6, n=40, d=3, seed=2)
+    rng = np.random.default_rng(0)
+    cl = clusters_of(sc, [(0, 6)], FRAMES[:1], rng)[0]
+    nvm = str(tmp_path / "m.nvm"); write_cluster(nvm, cl)
+    h = L.mi_model_load_nvm(nvm.encode())
+    assert L.mi_model_save_merge_side_files(h, str(tmp_path).encode(), 5) == 0
+    L.mi_model_free(h)
+    n = len(cl["X"])
+    ply = open(tmp_path / "merged.ply").read().split("\n")
+    assert ply[0] == "ply" and ply[1] == "format ascii 1.0" and ply[2].split() == ["element", "vertex", str(n + 5)]
+    assert ply[3] == "property float x" and ply[9] == "end_header" and len(ply) == 10 + n + 5 + 1
+    assert ply[10 + n:10 + n + 5] == ply[10 + n - 5:10 + n]              # the tail is listed twice
+    foc = open(tmp_path / "focal_for_optimisation.txt").read().split("\n")
+    assert foc[0] == "6" and foc[1] == "500 %.9f 2" % cl["f"][0]
+    assert open(tmp_path / "Invmap.txt").read().split("\n")[5] == "5 505"
+    rt = np.loadtxt(tmp_path / "RTglobalmapped_for_optimisation.txt", max_rows=1)
+    assert np.abs(rt - cl["R"][0].reshape(-1)).max() < 1e-8
+    cen = np.array([float(v) for v in open(tmp_path / "RTglobalmapped_for_optimisation.txt").read().split("\n")[1].split()])
+    assert np.abs(cen + cl["R"][0].T @ cl["t"][0]).max() < 1e-8
+    ours = open(tmp_path / "ours_new.txt").read().split("\n")[0].split()
+    tr = cl["tracks"][0]
+    assert int(ours[6]) == len(tr) and [int(ours[7]), int(ours[8])] == [tr[0][0], tr[0][1]] and abs(float(ours[9]) - tr[0][2]) < 1e-6
+    assert L.mi_model_save_merge_side_files(None, b"/tmp", 0) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keep_colours", [0, 1])
+def test_merge_matches_the_restated_steps(tmp_path, keep_colours):
+    L = merge_lib()
+    sc = vsfm_scene(m=60, n=3000, d=6, seed=123, strides=(1, 2, 3), cam_noise=0.002, pt_noise=0.004, f_noise=0.002)
+    rng = np.random.default_rng(9)
+    c1, c2 = clusters_of(sc, [(0, 30), (30, 60)], FRAMES[:2], rng)
+    # the reference's quirks: a repeated camera in a track, an id taken from the last view, an id that occurs twice in the second model
+    c1["tracks"][3].insert(1, c1["tracks"][3][0])
+    common = sorted(set(c1["gid"]) & set(c2["gid"]))
+    assert len(common) > 300
+    j_a, j_b = c2["gid"].index(common[5]), c2["gid"].index(common[9])
+    c2["tracks"][j_b] = [(v[0], 1000 + common[5], v[2], v[3]) for v in c2["tracks"][j_b]]       # j_b now carries common[5]'s id too
+    k = c2["gid"].index(common[20])
+    c2["tracks"][k][-1] = (c2["tracks"][k][-1][0], 77, c2["tracks"][k][-1][2], c2["tracks"][k][-1][3])   # its id becomes 77: no partner
+    p1, p2 = str(tmp_path / "a.nvm"), str(tmp_path / "b.nvm")
+    write_cluster(p1, c1); write_cluster(p2, c2)
+    h1, h2 = L.mi_model_load_nvm(p1.encode()), L.mi_model_load_nvm(p2.encode())
+    cfg = MergeConfig(rounds=300, device=0, keep_colours=keep_colours); res = MergeResult()
+    h = L.mi_model_merge_3d3d(h1, h2, C.byref(cfg), C.byref(res))
+    assert h, L.mi_model_last_error()
+    got = read_model(L, h)
+    # the transform: the GPU alignment against the CPU restatement on the same correspondences (second -> first)
+    ref = np_merge(c1, c2, res.scale, np.array(res.R).reshape(3, 3), np.array(res.t), recolour=not keep_colours)
+    assert res.ncorr == len(ref["match"]) == len(common) - 2            # the id-77 point and the shadowed duplicate drop out
+    assert (min(j_a, j_b) in [j for _, j in ref["match"]]) and (max(j_a, j_b) not in [j for _, j in ref["match"]])
+    src = np.array([c2["X"][j] for _, j in ref["match"]]); dst = np.array([c1["X"][i] for i, _ in ref["match"]])
+    o = Sim3Oracle().align(src, dst, 300)
+    assert res.best_round == o["best_round"] and abs(res.scale - o["scale"]) < 1e-12 * o["scale"]
+    assert np.abs(np.array(res.R).reshape(3, 3) - o["R"]).max() < 1e-9 and np.abs(np.array(res.t) - o["t"]).max() < 1e-8
+    assert abs(res.scale - 1.8) < 0.01 and (res.ncam_first, res.npt_first) == (30, len(c1["X"]))
+    # the merged model
+    assert np.array_equal(got["cam"], ref["cam"]) and np.array_equal(got["pt"], ref["pt"]) and np.array_equal(got["fid"], ref["fid"])
+    assert np.array_equal(got["rgb"], ref["rgb"]) and np.abs(got["xy"] - ref["xy"]).max() < 1e-9
+    assert np.abs(got["f"] - ref["f"]).max() < 1e-9 and np.abs(got["R"] - ref["R"]).max() < 1e-9
+    assert np.abs(got["t"] - ref["t"]).max() < 1e-8 and np.abs(got["xyz"] - ref["xyz"]).max() < 1e-8
+    assert len(got["xyz"]) == len(c1["X"]) + len(c2["X"])               # the matched points of the second model stay as well
+    # a similarity moves cameras and points together: the second model's own views keep their residuals
+    n1 = len(c1["X"])
+    own = got["pt"] >= n1
+    Rm = got["R"].reshape(-1, 3, 3)[got["cam"][own]]; Xm = got["xyz"][got["pt"][own]]
+    q = np.einsum("kij,kj->ki", Rm, Xm) + got["t"][got["cam"][own]]
+    res_px = got["xy"][own] - got["f"][got["cam"][own], None] * q[:, :2] / q[:, 2:]
+    assert abs(np.sqrt((res_px ** 2).sum() / own.sum()) - L.mi_model_rmse(h2)) < 1e-6
+    nvm = str(tmp_path / "m.nvm")
+    assert L.mi_model_save_nvm(h, nvm.encode()) == 0
+    for x in (h, h1, h2):
+        L.mi_model_free(x)
+    # too few common points is an error, not a crash
+    c3 = dict(c2); c3["tracks"] = [[(v[0], 5, v[2], v[3]) for v in t] for t in c2["tracks"]]
+    p3 = str(tmp_path / "c.nvm"); write_cluster(p3, c3)
+    h1, h3 = L.mi_model_load_nvm(p1.encode()), L.mi_model_load_nvm(p3.encode())
+    assert not L.mi_model_merge_3d3d(h1, h3, C.byref(cfg), C.byref(res)) and b"common points" in L.mi_model_last_error()
+    L.mi_model_free(h1); L.mi_model_free(h3)
+
+
+@pytest.mark.gpu
+def test_merge3d3d_process_merges_three_clusters_and_refines(tmp_path):
+    """Merge3D3D <dir>: dendogram/fullclustermergeinfo.txt names two merges (D = A + B, E = D + C); every merged cluster gets its
+    NVM and side files and is bundle adjusted by the optimizer_all child; the final model holds all 90 cameras at the noise level"""
+    L = merge_lib()
+    sc = vsfm_scene(m=90, n=5000, d=6, seed=31, strides=(1, 2, 3), cam_noise=0.002, pt_noise=0.004, f_noise=0.002)
+    rng = np.random.default_rng(3)
+    cls = clusters_of(sc, [(0, 30), (30, 60), (60, 90)], FRAMES, rng)
+    den = tmp_path / "dendogram"
+    for name, cl in zip("ABC", cls):
+        (den / ("cluster" + name)).mkdir(parents=True)
+        write_cluster(str(den / ("cluster" + name) / "outputVSFM_GB.nvm"), cl)
+    (den / "fullclustermergeinfo.txt").write_text("D A B\nE D C\n")
+    exe = os.path.join(ROOT, "large-scale-sfm_amd", "bin", "Merge3D3D")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("#Correspondences") == 2 and out.stdout.count("LM iterations") == 2
+    for name in "DE":
+        for fn in ("outputVSFM_GB.nvm", "RTglobalmapped_for_optimisation.txt", "focal_for_optimisation.txt", "Invmap.txt", "ours_new.txt", "merged.ply"):
+            assert (den / ("cluster" + name) / fn).stat().st_size > 0
+    h = L.mi_model_load_nvm(str(den / "clusterE" / "outputVSFM_GB.nvm").encode())
+    mdl = read_model(L, h)
+    assert len(mdl["f"]) == 90 and L.mi_model_rmse(h) < 0.25            # three frames, two seams, one model at the noise level
+    assert np.all(np.abs(mdl["f"] - 800) < 40)
+    L.mi_model_free(h)
+    assert [l.split()[1] for l in open(den / "clusterE" / "Invmap.txt").read().split("\n")[:90]] == ["%d" % (500 + j) for j in range(90)]
+    # a missing list is an error message, not a crash
+    bad = subprocess.run([exe, str(tmp_path / "nowhere")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
