@@ -1,7 +1,8 @@
 /*
  * mi_merge.h -- C ABI of the cluster-merge step around the similarity alignment.
  *
- * Replaces the body of the stage program SiftGPU/Merge3D3D.cpp (main, :564-908): for every line "new first second" of
+ * Replaces the bodies of the stage programs SiftGPU/Merge3D3D.cpp (main, :564-908; below) and SiftGPU/MergeClusters.cpp (the
+ * same fusion with a transform chosen among candidates; mi_mergeclusters_main at the end).  Merge3D3D: for every line "new first second" of
  * <dir>/dendogram/fullclustermergeinfo.txt, two reconstructions are read, their common points found, the second one is
  * brought into the frame of the first (mi_sim3.h on the GPU), the tracks are fused, the merged model and its side files
  * written, and optimizer_all refines it.  What is kept from the reference, quirks included:
@@ -50,6 +51,22 @@ typedef struct {
 void mi_merge_default_config(mi_merge_config *cfg);
 /* a new model (mi_model_free); first and second are not modified */
 mi_model *mi_model_merge_3d3d(const mi_model *first, const mi_model *second, const mi_merge_config *cfg, mi_merge_result *res);
+/* the same fusion with a given transform x_first = R (scale x_second) + t.  erase_matched = 0: as above; 1: MergeClusters.cpp's
+ * variant (:971-995) -- a point of the second model disappears once its views went to its partner (with the reference's
+ * behaviour when two points of the first model share a partner: the later one takes, and removes, the next surviving track) */
+mi_model *mi_model_merge_with_transform(const mi_model *first, const mi_model *second, double scale, const double R[9], const double t[3],
+                                        int erase_matched, int keep_colours, mi_merge_result *res);
+/* how well a candidate transform brings the second model onto the first (MergeClusters.cpp:701-861): over the common points,
+ * the distance |R (s x_second) + t - x_first|, and the first model's point projected into the second model's moved cameras
+ * (radial coefficient k1 applied, :817) against the second model's measurements */
+typedef struct {
+    int64_t ncorr, nproj, inliers;        /* inliers: distances below their mean (:847-851) */
+    double mean_reproj, median_reproj;    /* pixels */
+    double median_dist, mean_dist;
+} mi_merge_score;
+/* dist: ncorr distances in the order of the correspondences, or NULL; debug_path: the reference's debug_<k>.txt, or NULL */
+int mi_model_score_transform(const mi_model *first, const mi_model *second, double scale, const double R[9], const double t[3],
+                             mi_merge_score *score, double *dist, const char *debug_path);
 /* the files the reference leaves beside the merged NVM (:811-900): RTglobalmapped_for_optimisation.txt (R and centre per
  * camera), focal_for_optimisation.txt, Invmap.txt (index -> camera name), ours_new.txt (points with their tracks) and
  * merged.ply (which lists the last nply_tail points twice, as the reference does with the second model's) */
@@ -57,6 +74,13 @@ int mi_model_save_merge_side_files(const mi_model *merged, const char *dir, int6
 /* the process:  Merge3D3D <output dir>.  Spawns optimizer_all (beside this executable, or $MI_OPTIMIZER_ALL) on every
  * merged cluster with the reference's arguments "0 100 16 32 0 0" (:903).  Returns the exit status. */
 int mi_merge3d3d_main(int argc, char **argv);
+/* the process:  MergeClusters <output dir> <index>  (SiftGPU/MergeClusters.cpp:553-1115): merge number <index> of
+ * fullclustermergeinfo.txt with the best of the candidate transforms other stage programs left in the new cluster's directory
+ * (RTS2D2D.txt, RTS3D3D.txt, RTS2DR3DT.txt, RTSRefined.txt, RTSRefined_1.txt: scale / 9 numbers / 3 numbers) -- the one with
+ * the smallest mean distance (:875-885) -- matched points erased, then optimizer_all "0 50 16 32 0.5 0" when that candidate's
+ * mean reprojection error exceeds 10 pixels and "-1 5 16 32 0.5 0" otherwise (:1102-1108).  A missing candidate file is
+ * skipped (the reference would stop on it). */
+int mi_mergeclusters_main(int argc, char **argv);
 
 #ifdef __cplusplus
 }
