@@ -1104,36 +1104,38 @@ __global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a)
     }
 }
 
-// one wavefront per block row: lane (r,c) multiplies element (r,c) of each 8x8 block (a 512-B
-// contiguous wave load), reduction over c by three xor-shuffles.  No atomics: p.Sp goes out as one
-// partial per row, r.z comes in as one partial per k_pcg_update workgroup and is re-summed by every
-// wavefront in the same order (a few hundred L2-resident doubles), so every workgroup takes the
-// same converged / not converged decision; the decision is made sticky through SC_PCG_DONE.
-__global__ __launch_bounds__(64) void k_pcg_spmv(const PcgArgs a)
+// one workgroup of four wavefronts per block row: lane (r,c) multiplies element (r,c) of each 8x8 block (a 512-B
+// contiguous wave load), wavefront w takes the blocks w, w + 4, ... of the row with four loads in flight each; the sum
+// over c by three xor-shuffles, the four wavefronts' row sums through LDS in a fixed order.  What bounds the kernel is
+// the latency of dependent rounds of loads, not bytes (S stays in L2 / MALL across the iterations of a solve; with one
+// wavefront per row and one load at a time it streams at ~3 TB/s): 16 blocks in flight per row take a 55-block row from
+// 14 rounds to 4.  No atomics: p.Sp goes out as one partial per row, r.z comes in as one partial per k_pcg_update
+// workgroup and is re-summed by every wavefront in the same order (a few hundred L2-resident doubles), so every
+// workgroup takes the same converged / not converged decision; the decision is made sticky through SC_PCG_DONE.
+__global__ __launch_bounds__(256) void k_pcg_spmv(const PcgArgs a)
 {
-    const int j = blockIdx.x, lane = threadIdx.x, r = lane >> 3, c = lane & 7;
+    __shared__ double part[4][8];
+    const int j = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane >> 3, c = lane & 7;
     if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return;
     const double rz = wave_total(a.rzp + (size_t)(a.it & 1) * a.ng, a.ng, lane);
-    if (j == 0 && lane == 0) a.rz_hist[a.it] = rz;
+    if (j == 0 && threadIdx.x == 0) a.rz_hist[a.it] = rz;
     // rz_hist[0] is written by this very launch when it == 0; use the local value then
     if (a.it == 0 ? !(rz > 0.0) : pcg_converged(a, rz)) {
-        if (j == 0 && lane == 0) a.scal[SC_PCG_DONE] = 1.0;
+        if (j == 0 && threadIdx.x == 0) a.scal[SC_PCG_DONE] = 1.0;
         return;
     }
     const double *pprev = (a.it & 1) ? a.p0 : a.p1;   // p_{it-1}
     double *pcur = (a.it & 1) ? a.p1 : a.p0;          // p_it (it = 0: p0 = z, written by k_pcg_init)
     const double beta = a.it ? rz / a.rz_hist[a.it - 1] : 0.0;
-    // four independent 512-B block loads in flight per wavefront: with one load at a time the chip holds
-    // ~0.5 MB in flight and the MALL-resident S streams at only ~3 TB/s
     const double *__restrict__ Sv = a.S;
     const double *__restrict__ zv = a.z;
     const int q0 = a.bsr_row[j], q1 = a.bsr_row[j + 1];
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int q = q0;
-    for (; q + 3 < q1; q += 4) {
-        const int k0 = a.bsr_col[q], k1 = a.bsr_col[q + 1], k2 = a.bsr_col[q + 2], k3 = a.bsr_col[q + 3];
-        const double s0 = Sv[(size_t)q * 64 + lane], s1 = Sv[(size_t)(q + 1) * 64 + lane];
-        const double s2 = Sv[(size_t)(q + 2) * 64 + lane], s3 = Sv[(size_t)(q + 3) * 64 + lane];
+    int q = q0 + wv;
+    for (; q + 12 < q1; q += 16) {
+        const int k0 = a.bsr_col[q], k1 = a.bsr_col[q + 4], k2 = a.bsr_col[q + 8], k3 = a.bsr_col[q + 12];
+        const double s0 = Sv[(size_t)q * 64 + lane], s1 = Sv[(size_t)(q + 4) * 64 + lane];
+        const double s2 = Sv[(size_t)(q + 8) * 64 + lane], s3 = Sv[(size_t)(q + 12) * 64 + lane];
         double p0 = zv[k0 * 8 + c], p1 = zv[k1 * 8 + c], p2 = zv[k2 * 8 + c], p3 = zv[k3 * 8 + c];
         if (a.it) {
             p0 = fma(beta, pprev[k0 * 8 + c], p0); p1 = fma(beta, pprev[k1 * 8 + c], p1);
@@ -1141,28 +1143,45 @@ __global__ __launch_bounds__(64) void k_pcg_spmv(const PcgArgs a)
         }
         acc0 = fma(s0, p0, acc0); acc1 = fma(s1, p1, acc1); acc2 = fma(s2, p2, acc2); acc3 = fma(s3, p3, acc3);
     }
-    for (; q < q1; ++q) {
+    for (; q < q1; q += 4) {
         const int k = a.bsr_col[q];
         const double pk = a.it ? fma(beta, pprev[k * 8 + c], zv[k * 8 + c]) : zv[k * 8 + c];
         acc0 = fma(Sv[(size_t)q * 64 + lane], pk, acc0);
     }
     double acc = (acc0 + acc1) + (acc2 + acc3);
     acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
-    double part = 0.0;
+    if (c == 0) part[wv][r] = acc;
+    __syncthreads();
+    if (wv != 0) return;
+    double pq = 0.0;
     if (c == 0) {
+        acc = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
         const int idx = j * 8 + r;
         const double pj = a.it ? fma(beta, pprev[idx], a.z[idx]) : a.z[idx];   // same expression as in the products above
         a.q[idx] = acc;
         pcur[idx] = pj;
-        part = acc * pj;
+        pq = acc * pj;
     }
-    part = wave_sum(part);
-    if (lane == 0) a.pqp[j] = part;
+    pq = wave_sum(pq);
+    if (lane == 0) a.pqp[j] = pq;
 }
 
 __global__ __launch_bounds__(64) void k_pcg_update(const PcgArgs a)
 {
     if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return; // DONE: set by k_pcg_spmv(it), a launch ago
+    const double *pcur = (a.it & 1) ? a.p1 : a.p0;
+    const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+    // all 8 row-lanes of a camera need that camera's 8 new residuals: each lane recomputes them from
+    // r_it (read-only here; r_{it+1} goes to the other buffer, so there is no read/write overlap)
+    const double *rin = (a.it & 1) ? a.r1 : a.r;
+    double *rout = (a.it & 1) ? a.r : a.r1;
+    // everything this lane reads is requested before the reduction that gives alpha: one round of memory latency, not three
+    const bool live = j < a.m;
+    const int jj = live ? j : 0, idx = jj * 8 + r;
+    double mi[8], rv[8], qv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { mi[c] = a.Minv[(size_t)jj * 64 + r * 8 + c]; rv[c] = rin[jj * 8 + c]; qv[c] = a.q[jj * 8 + c]; }
+    const double xo = a.x[idx], po = pcur[idx];
     const double rz = a.rz_hist[a.it];
     const double pq = wave_total(a.pqp, a.m, threadIdx.x);
     if (!(pq > 0.0) || !isfinite(pq)) { // S not positive definite along p: "not solved" (dpotrf info > 0)
@@ -1172,24 +1191,16 @@ __global__ __launch_bounds__(64) void k_pcg_update(const PcgArgs a)
         return;
     }
     const double alpha = rz / pq;
-    const double *pcur = (a.it & 1) ? a.p1 : a.p0;
-    const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
     double part = 0.0;
-    // all 8 row-lanes of a camera need that camera's 8 new residuals: each lane recomputes them from
-    // r_it (read-only here; r_{it+1} goes to the other buffer, so there is no read/write overlap)
-    const double *rin = (a.it & 1) ? a.r1 : a.r;
-    double *rout = (a.it & 1) ? a.r : a.r1;
-    if (j < a.m) {
-        const double *Mi = a.Minv + (size_t)j * 64 + r * 8;
+    if (live) {
         double zz = 0.0, rr = 0.0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const double rc = rin[j * 8 + c] - alpha * a.q[j * 8 + c];
-            zz += Mi[c] * rc;
+            const double rc = rv[c] - alpha * qv[c];
+            zz += mi[c] * rc;
             if (c == r) rr = rc;
         }
-        const int idx = j * 8 + r;
-        a.x[idx] += alpha * pcur[idx];
+        a.x[idx] = xo + alpha * po;
         a.z[idx] = zz;
         rout[idx] = rr;
         part = rr * zz;
@@ -1424,7 +1435,7 @@ void launch_pcg_init(hipStream_t st, const PcgArgs &a)
 
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
 {
-    hipLaunchKernelGGL(k_pcg_spmv, dim3(a.m), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_pcg_spmv, dim3(a.m), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_pcg_update, dim3(a.ng), dim3(64), 0, st, a);
 }
 
