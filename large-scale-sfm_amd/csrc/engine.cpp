@@ -18,6 +18,7 @@ namespace {
 constexpr double kEpsilonSq = 1E-12 * 1E-12; // SBA_EPSILON_SQ, sba_levmar.c:37-38
 constexpr double kOneThird = 0.3333333334;   // SBA_ONE_THIRD, sba_levmar.c:40
 constexpr int kPcgChunk = 8;                 // PCG iterations launched between two host checks
+constexpr int kPcgRowPerWorkgroupMax = 512; // up to this many cameras a block row of S~ gets a whole workgroup (4 wavefronts), above: a wavefront
 
 double now_ms()
 {
@@ -302,10 +303,10 @@ int Engine::prepare()
     }
     const size_t acc_n = (size_t)pl.nb_up() * 64 + (size_t)3 * m_ * kCP + kScalCount;
     if (!hipok(d_ptout_.alloc(npl * kPtOut), "alloc ptout") || !hipok(d_acc_.alloc(acc_n), "alloc acc") ||
-        !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Minv_.alloc((size_t)m_ * 64), "alloc Minv") ||
+        !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Linv_.alloc((size_t)m_ * 64), "alloc Linv") || !hipok(d_S_pcg_.alloc((size_t)pl.nb_full() * 64), "alloc S~") ||
         !hipok(d_E_.alloc((size_t)m_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)m_ * kCP), "alloc dA") ||
-        !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)m_ * kCP * 7), "alloc pcg") ||
-        !hipok(d_rzpq_.alloc((size_t)(cfg.pcg_maxit + 4) + 2 * (size_t)((m_ + 7) / 8) + (size_t)m_), "alloc rz/pq") ||
+        !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)m_ * kCP * 8), "alloc pcg") ||
+        !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)m_), "alloc rz/pq") ||
         !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGrid) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
         !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage") ||
         !hipok(d_cam_part_.alloc((size_t)((m_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials"))
@@ -445,7 +446,8 @@ bool Engine::linear_phase(double mu, bool want_diag)
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
                     S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
                     d_cam_part_.p, d_stage_.p, scal_());
-    launch_block_inv(st_, m_, d_bsr_diag_.p, d_S_full_.p, d_Minv_.p, scal_());
+    launch_block_inv(st_, m_, d_bsr_diag_.p, d_S_full_.p, d_Linv_.p, scal_());
+    launch_scale_blocks(st_, pl.nb_full(), d_bsr_rowidx_.p, d_bsr_col_.p, d_S_full_.p, d_Linv_.p, d_S_pcg_.p);
     return hipok(hipGetLastError(), "launch (linear phase)");
 }
 
@@ -453,11 +455,12 @@ PcgArgs Engine::pcg_args()
 {
     const size_t vec = (size_t)m_ * kCP;
     PcgArgs p{};
-    p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_full_.p; p.Minv = d_Minv_.p; p.E = d_E_.p;
-    p.x = d_dA_.p; p.r = d_pcg_.p; p.r1 = d_pcg_.p + vec; p.z = d_pcg_.p + 2 * vec; p.p0 = d_pcg_.p + 3 * vec;
-    p.p1 = d_pcg_.p + 4 * vec; p.q = d_pcg_.p + 5 * vec;
-    p.ng = (m_ + 7) / 8;
-    p.rz_hist = d_rzpq_.p; p.rzp = d_rzpq_.p + (cfg.pcg_maxit + 4); p.pqp = p.rzp + 2 * (size_t)p.ng;
+    p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_pcg_.p; p.Linv = d_Linv_.p; p.E = d_E_.p;
+    double *v = d_pcg_.p;
+    p.da = d_dA_.p; p.x = v; p.p = v + vec; p.r0 = v + 2 * vec; p.r1 = v + 3 * vec; p.w0 = v + 4 * vec; p.w1 = v + 5 * vec;
+    p.s0 = v + 6 * vec; p.s1 = v + 7 * vec;
+    p.ng = (m_ + 7) / 8; p.nwg = m_ <= kPcgRowPerWorkgroupMax ? m_ : (m_ + 3) / 4;
+    p.rz_hist = d_rzpq_.p; p.alpha_hist = p.rz_hist + (cfg.pcg_maxit + 4); p.gp = p.alpha_hist + (cfg.pcg_maxit + 4); p.dp = p.gp + 2 * (size_t)p.nwg;
     p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = m_; p.it = 0;
     return p;
 }
@@ -504,6 +507,7 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     if (it0 < cfg.pcg_maxit && !pcg_chunks(it0)) return false;
     pcg_pred_prev_ = pcg_pred_ > 0 ? pcg_pred_ : (int)h_scal_[SC_PCG_ITERS];
     pcg_pred_ = (int)h_scal_[SC_PCG_ITERS];
+    launch_pcg_finish(st_, p);
     (void)hipEventRecord(ev_[3], st_);
     return update_phase(mu, dB_dev);
 }

@@ -15,7 +15,8 @@ namespace miba {
 // S_up     [nb_up][64]  upper blocks of the reduced camera matrix (8x8 padded, row-major)
 // camvec   [3][m][8]    ea_j | E_j partial (= sum A^T(e - B h)) | diag U_j
 // ptout    [npl][12]    (V_i + mu I)^-1 (6: 00 01 02 11 12 22) | h_i = V*^-1 eb_i (3) | eb_i (3)
-// S_full   [nb][64]     BSR values used by the PCG, Minv [m][64] block-Jacobi preconditioner
+// S_full   [nb][64]     BSR values of the reduced system, Linv [m][64] inverse Cholesky factors of its diagonal blocks,
+// S_pcg    [nb][64]     Linv S Linv^T, what the CG multiplies with
 constexpr int kCamLin = 24;
 constexpr int kPtOut = 12;
 constexpr int kPartW = 8;      // per-workgroup partial row: [0,4) sums, [4,8) maxima
@@ -105,11 +106,12 @@ struct LongArgs {
 
 struct PcgArgs {
     const int *bsr_row, *bsr_col;
-    const double *S, *Minv, *E;
-    double *x, *r, *r1, *z, *p0, *p1, *q;   // r/r1 and p0/p1 alternate by iteration parity
-    double *rzp, *pqp, *rz_hist, *scal;     // rzp [2][ng] r.z partials, pqp [m] p.Sp partials, rz_hist [maxit+2]
+    const double *S, *Linv, *E;                        // S = the scaled matrix S~ (k_scale_blocks)
+    double *x, *da, *p, *r0, *r1, *w0, *w1, *s0, *s1;  // r, w, s alternate by iteration parity (read by the neighbours' rows)
+    double *gp, *dp, *rz_hist, *alpha_hist, *scal;     // gp, dp [2][nwg]: partials of r.r and w.r per workgroup; histories [maxit+2]
     double tol;
-    int m, ng, it;                          // ng = ceil(m / 8) workgroups of k_pcg_init / k_pcg_update
+    int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init / k_pcg_finish); product kernels: nwg = m (one block row per
+                                                       // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
 };
 
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
@@ -119,10 +121,12 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
                      const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal);
-void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal);
+void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Linv, double *scal);
+void launch_scale_blocks(hipStream_t st, int nb, const int *bsr_rowidx, const int *bsr_col, const double *S_full, const double *Linv, double *S_pcg);
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);
-void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // spmv + update for iteration a.it
-void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . z_it
+void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one launch
+void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . M^-1 r_it
+void launch_pcg_finish(hipStream_t st, const PcgArgs &a); // da = Linv^T x~
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max);
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
                        const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,

@@ -2,7 +2,7 @@
 //
 // One LM damping trial (sba_levmar.c:1131-1612) is
 //   k_cam_prep -> k_build (-> RCCL all-reduce) -> k_finalize{,_vec} -> k_block_inv
-//   -> PCG (k_pcg_init, k_pcg_spmv, k_pcg_update) -> k_cam_update -> k_backsub (-> all-reduce)
+//   -> k_scale_blocks -> CG (k_pcg_init, k_pcg_start, k_pcg_iter per iteration, k_pcg_finish) -> k_cam_update -> k_backsub (-> all-reduce)
 // All arithmetic is IEEE double.  Wavefront = 64 lanes; k_build and k_backsub use ONE wavefront
 // per workgroup so every LDS hand-off is wave-synchronous (the s_barrier of a one-wave workgroup
 // costs nothing) and no inter-wave protocol exists anywhere in this file; cross-workgroup
@@ -1007,11 +1007,14 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
 }
 
 // ------------------------------------------------------------------------------------------
-// block-Jacobi preconditioner: Minv_j = S_jj^-1 by an unrolled 8x8 Cholesky, one thread per camera
-// (PBA: ComputeDiagonalBlockC + InvertSymmetricMatrix, SparseBundleCPU.cpp:1604-1734)
+// block-Jacobi preconditioning, applied to the matrix once per trial instead of to a vector twice per iteration:
+// with S_jj = L_j L_j^T (unrolled 8x8 Cholesky, one thread per camera; PBA: ComputeDiagonalBlockC +
+// InvertSymmetricMatrix, SparseBundleCPU.cpp:1604-1734) the solve runs on  S~ = L^-1 S L^-T  (unit diagonal blocks),
+// E~ = L^-1 E, and da = L^-T x~.  Same iterates as block-Jacobi PCG on S (r~ = L^-1 r, so r~.r~ = r.M^-1 r, the quantity
+// the stopping rule looks at).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_block_inv(int m, const int *__restrict__ bsr_diag, const double *__restrict__ S_full,
-                                                 double *__restrict__ Minv, double *__restrict__ scal)
+                                                 double *__restrict__ Linv, double *__restrict__ scal)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
@@ -1029,35 +1032,63 @@ __global__ __launch_bounds__(64) void k_block_inv(int m, const int *__restrict__
             else L[r][c] = s / L[c][c];
         }
     if (!ok) atomic_max_pos(&scal[SC_NOT_PD], 1.0);
-    // Linv (lower), then Minv = Linv^T Linv
-    double Li[8][8];
+    double *out = Linv + (size_t)j * 64;
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
+    for (int c = 0; c < 8; ++c) {
+        double col[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            if (r < c) { Li[r][c] = 0.0; continue; }
+            if (r < c) { col[r] = 0.0; out[r * 8 + c] = 0.0; continue; }
             double s = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = 0; k < r; ++k) if (k >= c) s -= L[r][k] * Li[k][c];
-            Li[r][c] = s / L[r][r];
+            for (int k = 0; k < r; ++k) if (k >= c) s -= L[r][k] * col[k];
+            col[r] = s / L[r][r];
+            out[r * 8 + c] = col[r];
         }
-    double *out = Minv + (size_t)j * 64;
+    }
+}
+
+// S~_jk = Linv_j S_jk Linv_k^T, one wavefront per block, lane (r,c)
+__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const int *__restrict__ rowidx, const int *__restrict__ col,
+                                                     const double *__restrict__ S_full, const double *__restrict__ Linv,
+                                                     double *__restrict__ S_pcg)
+{
+    __shared__ double sh[4][2][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+    const int b = blockIdx.x * 4 + wv;
+    const bool live = b < nb;
+    const int bb = live ? b : 0;
+    const int j = rowidx[bb], k = col[bb];
+    sh[wv][0][lane] = S_full[(size_t)bb * 64 + lane];
+    const double lj[8] = { Linv[(size_t)j * 64 + r * 8], Linv[(size_t)j * 64 + r * 8 + 1], Linv[(size_t)j * 64 + r * 8 + 2], Linv[(size_t)j * 64 + r * 8 + 3],
+                           Linv[(size_t)j * 64 + r * 8 + 4], Linv[(size_t)j * 64 + r * 8 + 5], Linv[(size_t)j * 64 + r * 8 + 6], Linv[(size_t)j * 64 + r * 8 + 7] };
+    const double lk[8] = { Linv[(size_t)k * 64 + c * 8], Linv[(size_t)k * 64 + c * 8 + 1], Linv[(size_t)k * 64 + c * 8 + 2], Linv[(size_t)k * 64 + c * 8 + 3],
+                           Linv[(size_t)k * 64 + c * 8 + 4], Linv[(size_t)k * 64 + c * 8 + 5], Linv[(size_t)k * 64 + c * 8 + 6], Linv[(size_t)k * 64 + c * 8 + 7] };
+    __syncthreads();
+    double t = 0.0;                                   // T = Linv_j S
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+    for (int a = 0; a < 8; ++a) t = fma(lj[a], sh[wv][0][a * 8 + c], t);
+    sh[wv][1][lane] = t;
+    __syncthreads();
+    double o = 0.0;                                   // T Linv_k^T
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) if (k >= r && k >= c) s += Li[k][r] * Li[k][c];
-            out[r * 8 + c] = s;
-        }
+    for (int a = 0; a < 8; ++a) o = fma(sh[wv][1][r * 8 + a], lk[a], o);
+    if (live) S_pcg[(size_t)b * 64 + lane] = (j == k) ? (r == c ? 1.0 : 0.0) : o;   // the diagonal blocks are the identity by construction
 }
 
 // ------------------------------------------------------------------------------------------
-// PCG on the block-sparse reduced camera system (the role of sba_Axb_Chol; algorithm of PBA's
-// SolveNormalEquationPCGX, SparseBundleCPU.cpp:3347-3474, with S explicit).
-//   rz[it] = r_it . z_it, pq[it] = p_it . S p_it live in HBM, one slot per iteration, so no kernel
-//   ever waits on the host; every workgroup takes the same converged/breakdown decision from them.
+// CG on the scaled block-sparse reduced camera system (the role of sba_Axb_Chol; what PBA's SolveNormalEquationPCGX,
+// SparseBundleCPU.cpp:3347-3474, does with implicit products), in the Chronopoulos-Gear arrangement (one reduction per iteration):
+//   w_i = S~ r_i,  gamma_i = r_i.r_i,  delta_i = w_i.r_i        (both dot products over vectors of the same launch)
+//   beta_i = gamma_i / gamma_{i-1},  alpha_i = gamma_i / (delta_i - beta_i gamma_i / alpha_{i-1})
+//   p_i = r_i + beta_i p_{i-1},  s_i = w_i + beta_i s_{i-1} (= S~ p_i),  x += alpha_i p_i,  r_{i+1} = r_i - alpha_i s_i
+// so an iteration needs ONE grid-wide synchronisation -- one launch -- where the textbook arrangement needs two (p.Sp
+// before the update, r.r after): a launch in this chain costs ~4.2 us however little it does.  The
+// product of launch i needs r_{i+1} of the neighbouring block rows, which their owners are only writing in that same
+// launch: every wavefront recomputes it from the neighbours' r_i, w_i, s_{i-1} and the two scalars (two fma per element),
+// which is why r, w and s alternate between two buffers.  gamma_i, delta_i live in HBM as one partial per workgroup and
+// are re-summed by every wavefront in the same order, so every workgroup takes the same converged / breakdown decision
+// and no kernel ever waits on the host; the decision is sticky through SC_PCG_DONE.
 // ------------------------------------------------------------------------------------------
 // sum of n partials, every lane of the wavefront gets the total
 __device__ __forceinline__ double wave_total(const double *__restrict__ v, int n, int lane)
@@ -1074,142 +1105,195 @@ __device__ __forceinline__ bool pcg_converged(const PcgArgs &a, double rz_it)
     return sqrt(fabs(rz_it) / rz0) < a.tol;
 }
 
-// 8 cameras per 64-lane group: lane = (camera, row).  Partial r.z per workgroup -> rzp[0][g].
+// 8 cameras per 64-lane group: lane = (camera, row).  r_0 = E~ = Linv E, x~_0 = 0.
 __global__ __launch_bounds__(64) void k_pcg_init(const PcgArgs a)
 {
     const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
-    double part = 0.0;
-    if (j < a.m) {
-        const double *Mi = a.Minv + (size_t)j * 64 + r * 8, *Ej = a.E + (size_t)j * 8;
-        double zz = 0.0;
+    if (j >= a.m) return;
+    const double *Li = a.Linv + (size_t)j * 64 + r * 8, *Ej = a.E + (size_t)j * 8;
+    double rr = 0.0;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) zz += Mi[c] * Ej[c];
-        const int idx = j * 8 + r;
-        a.x[idx] = 0.0; a.r[idx] = Ej[r]; a.z[idx] = zz; a.p0[idx] = zz;
-        part = Ej[r] * zz;
-    }
-    part = wave_sum(part);
-    if (threadIdx.x == 0) a.rzp[blockIdx.x] = part;
+    for (int c = 0; c < 8; ++c) rr += Li[c] * Ej[c];
+    const int idx = j * 8 + r;
+    a.x[idx] = 0.0; a.r0[idx] = rr; a.p[idx] = 0.0; a.s0[idx] = 0.0; a.s1[idx] = 0.0;
 }
 
-// rz_hist[it] = sum of the r.z partials of iteration it, and the sticky converged flag; one wavefront.
-// Launched at the end of every chunk so the host sees the state AFTER the chunk's last update.
+// da = Linv^T x~
+__global__ __launch_bounds__(64) void k_pcg_finish(const PcgArgs a)
+{
+    const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
+    if (j >= a.m) return;
+    const double *Li = a.Linv + (size_t)j * 64, *xj = a.x + (size_t)j * 8;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v += Li[c * 8 + r] * xj[c];
+    a.da[j * 8 + r] = v;
+}
+
+// the workgroup's two dot-product partials: four wavefronts, fixed order
+__device__ __forceinline__ void publish_partials(const PcgArgs &a, int slot, double g, double d, double (*sh)[2])
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    g = wave_sum(g); d = wave_sum(d);
+    if (lane == 0) { sh[wv][0] = g; sh[wv][1] = d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.gp[(size_t)slot * a.nwg + blockIdx.x] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+        a.dp[(size_t)slot * a.nwg + blockIdx.x] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+    }
+}
+
+// products of a block row with NV vectors in one pass over its blocks q = qb, qb + stride, ... < qe: lane (r,c) multiplies
+// element (r,c) of each 8x8 block (a 512-B contiguous wave load) with element c of the neighbour's vectors; eight
+// independent block loads in flight (with one at a time the MALL-resident S streams at only ~3 TB/s, and a wavefront that
+// waits out a round of memory latency per four blocks spends most of a launch waiting); the sum over c by three
+// xor-shuffles leaves row r's value in all 8 lanes of the row
+template <int NV>
+__device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, int stride, int lane, const double *const (&vec)[NV], double (&out)[NV])
+{
+    const int c = lane & 7;
+    const double *__restrict__ Sv = a.S;
+    double acc[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = acc[v][2] = acc[v][3] = 0.0;
+    int q = qb;
+    for (; q + 7 * stride < qe; q += 8 * stride) {
+        int k[8];
+        double sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { k[u] = a.bsr_col[q + u * stride] * 8 + c; sv[u] = Sv[(size_t)(q + u * stride) * 64 + lane]; }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = vec[v][k[u]];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[v][u & 3] = fma(sv[u], x[u], acc[v][u & 3]);
+        }
+    }
+    for (; q < qe; q += stride) {
+        const int k = a.bsr_col[q] * 8 + c;
+        const double sv = Sv[(size_t)q * 64 + lane];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v][0] = fma(sv, vec[v][k], acc[v][0]);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double t = (acc[v][0] + acc[v][1]) + (acc[v][2] + acc[v][3]);
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+        out[v] = t;
+    }
+}
+
+// ROWS = 4: one wavefront per block row, four rows per workgroup.  ROWS = 1 (few cameras: fewer block rows than the chip
+// has CUs): the four wavefronts of a workgroup share one row, block q to wavefront q mod 4, and add up through LDS in a
+// fixed order -- the result is in wavefront 0.  Returns whether this wavefront holds a row's finished products.
+template <int ROWS, int NV>
+__device__ __forceinline__ bool workgroup_row_products(const PcgArgs &a, int q0, int q1, const double *const (&vec)[NV], double (&out)[NV], double (*red)[NV][8])
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (ROWS == 4) { row_products<NV>(a, q0, q1, 1, lane, vec, out); return true; }
+    row_products<NV>(a, q0 + wv, q1, 4, lane, vec, out);
+    if ((lane & 7) == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) red[wv][v][lane >> 3] = out[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) out[v] = (red[0][v][lane >> 3] + red[1][v][lane >> 3]) + (red[2][v][lane >> 3] + red[3][v][lane >> 3]);
+    return wv == 0;
+}
+
+// w_0 = S~ r_0 and the partials of gamma_0, delta_0
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_pcg_start(const PcgArgs a)
+{
+    __shared__ double sh[4][2];
+    __shared__ double red[4][1][8];
+    const int lane = threadIdx.x & 63, j = ROWS == 4 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x, r = lane >> 3, c = lane & 7;
+    const bool live = j < a.m;
+    const int jj = live ? j : 0;
+    const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
+    const double *const vec[1] = { a.r0 };
+    double w[1];
+    const bool mine = workgroup_row_products<ROWS, 1>(a, q0, q1, vec, w, red);
+    double g = 0.0, d = 0.0;
+    if (live && mine && c == 0) {
+        const double rr = a.r0[j * 8 + r];
+        a.w0[j * 8 + r] = w[0];
+        g = rr * rr; d = w[0] * rr;
+    }
+    publish_partials(a, 0, g, d, sh);
+}
+
+// rz_hist[it] = gamma_it, and the sticky converged flag; one wavefront.  Launched at the end of every chunk so the host
+// sees the state AFTER the chunk's last update.
 __global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a)
 {
     if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return;
-    const double rz = wave_total(a.rzp + (size_t)(a.it & 1) * a.ng, a.ng, threadIdx.x);
+    const double g = wave_total(a.gp + (size_t)(a.it & 1) * a.nwg, a.nwg, threadIdx.x);
     if (threadIdx.x == 0) {
-        a.rz_hist[a.it] = rz;
-        if (a.it == 0 ? !(rz > 0.0) : pcg_converged(a, rz)) a.scal[SC_PCG_DONE] = 1.0;
+        a.rz_hist[a.it] = g;
+        if (a.it == 0 ? !(g > 0.0) : pcg_converged(a, g)) a.scal[SC_PCG_DONE] = 1.0;
     }
 }
 
-// one workgroup of four wavefronts per block row: lane (r,c) multiplies element (r,c) of each 8x8 block (a 512-B
-// contiguous wave load), wavefront w takes the blocks w, w + 4, ... of the row with four loads in flight each; the sum
-// over c by three xor-shuffles, the four wavefronts' row sums through LDS in a fixed order.  What bounds the kernel is
-// the latency of dependent rounds of loads, not bytes (S stays in L2 / MALL across the iterations of a solve; with one
-// wavefront per row and one load at a time it streams at ~3 TB/s): 16 blocks in flight per row take a 55-block row from
-// 14 rounds to 4.  No atomics: p.Sp goes out as one partial per row, r.z comes in as one partial per k_pcg_update
-// workgroup and is re-summed by every wavefront in the same order (a few hundred L2-resident doubles), so every
-// workgroup takes the same converged / not converged decision; the decision is made sticky through SC_PCG_DONE.
-__global__ __launch_bounds__(256) void k_pcg_spmv(const PcgArgs a)
+// iteration a.it.  The product w_{it+1} = S~ r_{it+1} needs r_{it+1} = r_it - alpha (w_it + beta s_{it-1}) of the neighbouring block
+// rows, which their owners are only writing in this same launch, and alpha, beta, which every wavefront first has to sum up:
+// so the pass over the row's blocks forms S~ r_it, S~ w_it and S~ s_{it-1} separately -- its loads depend on nothing but
+// the row pointers and are in flight while the partials are summed -- and the scalars combine the three at the end.
+// What this launch costs is rounds of dependent memory latency (~4.2 us of it is the launch itself), so everything that
+// can be requested at once is: flags, partials, histories and row pointers together, then blocks and column indices, then
+// the neighbours' vectors.
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_pcg_iter(const PcgArgs a)
 {
-    __shared__ double part[4][8];
-    const int j = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r = lane >> 3, c = lane & 7;
-    if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return;
-    const double rz = wave_total(a.rzp + (size_t)(a.it & 1) * a.ng, a.ng, lane);
-    if (j == 0 && threadIdx.x == 0) a.rz_hist[a.it] = rz;
-    // rz_hist[0] is written by this very launch when it == 0; use the local value then
-    if (a.it == 0 ? !(rz > 0.0) : pcg_converged(a, rz)) {
-        if (j == 0 && threadIdx.x == 0) a.scal[SC_PCG_DONE] = 1.0;
-        return;
-    }
-    const double *pprev = (a.it & 1) ? a.p0 : a.p1;   // p_{it-1}
-    double *pcur = (a.it & 1) ? a.p1 : a.p0;          // p_it (it = 0: p0 = z, written by k_pcg_init)
-    const double beta = a.it ? rz / a.rz_hist[a.it - 1] : 0.0;
-    const double *__restrict__ Sv = a.S;
-    const double *__restrict__ zv = a.z;
-    const int q0 = a.bsr_row[j], q1 = a.bsr_row[j + 1];
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    int q = q0 + wv;
-    for (; q + 12 < q1; q += 16) {
-        const int k0 = a.bsr_col[q], k1 = a.bsr_col[q + 4], k2 = a.bsr_col[q + 8], k3 = a.bsr_col[q + 12];
-        const double s0 = Sv[(size_t)q * 64 + lane], s1 = Sv[(size_t)(q + 4) * 64 + lane];
-        const double s2 = Sv[(size_t)(q + 8) * 64 + lane], s3 = Sv[(size_t)(q + 12) * 64 + lane];
-        double p0 = zv[k0 * 8 + c], p1 = zv[k1 * 8 + c], p2 = zv[k2 * 8 + c], p3 = zv[k3 * 8 + c];
-        if (a.it) {
-            p0 = fma(beta, pprev[k0 * 8 + c], p0); p1 = fma(beta, pprev[k1 * 8 + c], p1);
-            p2 = fma(beta, pprev[k2 * 8 + c], p2); p3 = fma(beta, pprev[k3 * 8 + c], p3);
-        }
-        acc0 = fma(s0, p0, acc0); acc1 = fma(s1, p1, acc1); acc2 = fma(s2, p2, acc2); acc3 = fma(s3, p3, acc3);
-    }
-    for (; q < q1; q += 4) {
-        const int k = a.bsr_col[q];
-        const double pk = a.it ? fma(beta, pprev[k * 8 + c], zv[k * 8 + c]) : zv[k * 8 + c];
-        acc0 = fma(Sv[(size_t)q * 64 + lane], pk, acc0);
-    }
-    double acc = (acc0 + acc1) + (acc2 + acc3);
-    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
-    if (c == 0) part[wv][r] = acc;
-    __syncthreads();
-    if (wv != 0) return;
-    double pq = 0.0;
-    if (c == 0) {
-        acc = (part[0][r] + part[1][r]) + (part[2][r] + part[3][r]);
-        const int idx = j * 8 + r;
-        const double pj = a.it ? fma(beta, pprev[idx], a.z[idx]) : a.z[idx];   // same expression as in the products above
-        a.q[idx] = acc;
-        pcur[idx] = pj;
-        pq = acc * pj;
-    }
-    pq = wave_sum(pq);
-    if (lane == 0) a.pqp[j] = pq;
-}
-
-__global__ __launch_bounds__(64) void k_pcg_update(const PcgArgs a)
-{
-    if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return; // DONE: set by k_pcg_spmv(it), a launch ago
-    const double *pcur = (a.it & 1) ? a.p1 : a.p0;
-    const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
-    // all 8 row-lanes of a camera need that camera's 8 new residuals: each lane recomputes them from
-    // r_it (read-only here; r_{it+1} goes to the other buffer, so there is no read/write overlap)
-    const double *rin = (a.it & 1) ? a.r1 : a.r;
-    double *rout = (a.it & 1) ? a.r : a.r1;
-    // everything this lane reads is requested before the reduction that gives alpha: one round of memory latency, not three
+    __shared__ double sh[4][2];
+    __shared__ double red[4][3][8];
+    const int lane = threadIdx.x & 63, j = ROWS == 4 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x, r = lane >> 3, c = lane & 7;
+    const int par = a.it & 1, prev = a.it ? a.it - 1 : 0;
     const bool live = j < a.m;
     const int jj = live ? j : 0, idx = jj * 8 + r;
-    double mi[8], rv[8], qv[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { mi[c] = a.Minv[(size_t)jj * 64 + r * 8 + c]; rv[c] = rin[jj * 8 + c]; qv[c] = a.q[jj * 8 + c]; }
-    const double xo = a.x[idx], po = pcur[idx];
-    const double rz = a.rz_hist[a.it];
-    const double pq = wave_total(a.pqp, a.m, threadIdx.x);
-    if (!(pq > 0.0) || !isfinite(pq)) { // S not positive definite along p: "not solved" (dpotrf info > 0)
-        if (blockIdx.x == 0 && threadIdx.x == 0) a.scal[SC_PCG_STATUS] = 2.0;
-        // the partial of the next iteration must still be defined
-        if (threadIdx.x == 0) a.rzp[(size_t)((a.it + 1) & 1) * a.ng + blockIdx.x] = 0.0;
+    const double *__restrict__ rc = par ? a.r1 : a.r0, *__restrict__ wc = par ? a.w1 : a.w0, *__restrict__ so = par ? a.s1 : a.s0;
+    // round 1
+    const double st = a.scal[SC_PCG_STATUS], dn = a.scal[SC_PCG_DONE];
+    double gs = 0.0, ds = 0.0;
+    for (int i = lane; i < a.nwg; i += 64) { gs += a.gp[(size_t)par * a.nwg + i]; ds += a.dp[(size_t)par * a.nwg + i]; }
+    const double g_prev = a.rz_hist[prev], g_zero = a.rz_hist[0], a_prev = a.alpha_hist[prev];
+    const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
+    const double r_own = rc[idx], w_own = wc[idx], s_own = so[idx], p_own = a.p[idx], x_own = a.x[idx];
+    if (st != 0.0 || dn != 0.0) return;
+    // rounds 2 and 3
+    const double *const vec[3] = { rc, wc, so };
+    double S3[3];
+    const bool mine = workgroup_row_products<ROWS, 3>(a, q0, q1, vec, S3, red);
+    const double gamma = wave_sum(gs), delta = wave_sum(ds);
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    if (first) a.rz_hist[a.it] = gamma;
+    const bool conv = a.it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < a.tol);
+    if (conv) {
+        if (first) a.scal[SC_PCG_DONE] = 1.0;
         return;
     }
-    const double alpha = rz / pq;
-    double part = 0.0;
-    if (live) {
-        double zz = 0.0, rr = 0.0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const double rc = rv[c] - alpha * qv[c];
-            zz += mi[c] * rc;
-            if (c == r) rr = rc;
-        }
-        a.x[idx] = xo + alpha * po;
-        a.z[idx] = zz;
-        rout[idx] = rr;
-        part = rr * zz;
+    const double beta = a.it ? gamma / g_prev : 0.0;
+    const double den = a.it ? delta - beta * gamma / a_prev : delta;   // = p.S~p
+    if (!(den > 0.0) || !isfinite(den)) { // S not positive definite along p: "not solved" (dpotrf info > 0)
+        if (first) a.scal[SC_PCG_STATUS] = 2.0;
+        return;
     }
-    part = wave_sum(part);
-    if (threadIdx.x == 0) {
-        a.rzp[(size_t)((a.it + 1) & 1) * a.ng + blockIdx.x] = part;
-        if (blockIdx.x == 0) a.scal[SC_PCG_ITERS] = (double)(a.it + 1);
+    const double alpha = gamma / den;
+    double *rn = par ? a.r0 : a.r1, *wn = par ? a.w0 : a.w1, *sn = par ? a.s0 : a.s1;
+    double g = 0.0, d = 0.0;
+    if (live && mine && c == 0) {
+        const double s_new = fma(beta, s_own, w_own), r_new = fma(-alpha, s_new, r_own), p_new = fma(beta, p_own, r_own);
+        const double w_new = fma(-alpha, fma(beta, S3[2], S3[1]), S3[0]);
+        sn[idx] = s_new; rn[idx] = r_new; wn[idx] = w_new;
+        a.p[idx] = p_new;
+        a.x[idx] = fma(alpha, p_new, x_own);
+        g = r_new * r_new; d = w_new * r_new;
     }
+    publish_partials(a, par ^ 1, g, d, sh);
+    if (first) { a.alpha_hist[a.it] = alpha; a.scal[SC_PCG_ITERS] = (double)(a.it + 1); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1428,16 +1512,25 @@ void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *
     hipLaunchKernelGGL(k_block_inv, dim3((m + 63) / 64), dim3(64), 0, st, m, bsr_diag, S_full, Minv, scal);
 }
 
+void launch_scale_blocks(hipStream_t st, int nb, const int *bsr_rowidx, const int *bsr_col, const double *S_full, const double *Linv, double *S_pcg)
+{
+    hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, bsr_rowidx, bsr_col, S_full, Linv, S_pcg);
+}
+
 void launch_pcg_init(hipStream_t st, const PcgArgs &a)
 {
     hipLaunchKernelGGL(k_pcg_init, dim3(a.ng), dim3(64), 0, st, a);
+    if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_start<1>, dim3(a.nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_pcg_start<4>, dim3(a.nwg), dim3(256), 0, st, a);
 }
 
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
 {
-    hipLaunchKernelGGL(k_pcg_spmv, dim3(a.m), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_pcg_update, dim3(a.ng), dim3(64), 0, st, a);
+    if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_iter<1>, dim3(a.nwg), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_pcg_iter<4>, dim3(a.nwg), dim3(256), 0, st, a);
 }
+
+void launch_pcg_finish(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_finish, dim3(a.ng), dim3(64), 0, st, a); }
 
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_tail, dim3(1), dim3(64), 0, st, a); }
 
