@@ -312,6 +312,7 @@ int Engine::prepare()
         !hipok(d_cam_part_.alloc((size_t)((m_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
+    if (!hipok(hipMemset(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double)), "memset rz/pq")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
     if (std::getenv("MI_BA_STAMPS")) {
         if (!hipok(d_dbg_.alloc(8), "alloc dbg") || !hipok(hipMemset(d_dbg_.p, 0, 64), "memset dbg")) return MI_BA_ERROR;
@@ -443,11 +444,9 @@ bool Engine::linear_phase(double mu, bool want_diag)
     (void)hipEventRecord(ev_[1], st_);
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
-    launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p,
-                    S_up_(), d_S_full_.p, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
-                    d_cam_part_.p, d_stage_.p, scal_());
-    launch_block_inv(st_, m_, d_bsr_diag_.p, d_S_full_.p, d_Linv_.p, scal_());
-    launch_scale_blocks(st_, pl.nb_full(), d_bsr_rowidx_.p, d_bsr_col_.p, d_S_full_.p, d_Linv_.p, d_S_pcg_.p);
+    launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
+                    S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
+                    d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p);
     return hipok(hipGetLastError(), "launch (linear phase)");
 }
 
@@ -488,7 +487,7 @@ bool Engine::pcg_chunks(int it0)
 bool Engine::solve_phase(double mu, double *dB_dev)
 {
     PcgArgs p = pcg_args();
-    if (!hipok(hipMemsetAsync(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double), st_), "memset rz/pq")) return false;
+    // (histories and partials need no reset: every slot a launch reads was written by an earlier launch of this solve)
     (void)hipEventRecord(ev_[2], st_);
     launch_pcg_init(st_, p);
     int it0 = 0;

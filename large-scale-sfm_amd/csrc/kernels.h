@@ -118,11 +118,9 @@ void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const 
                      const double *f_fixed, double *cam_lin);
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
-                     const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
+                     const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full /* or nullptr */,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
-                     double *E, double *cam_part, double *stage, double *scal);
-void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Linv, double *scal);
-void launch_scale_blocks(hipStream_t st, int nb, const int *bsr_rowidx, const int *bsr_col, const double *S_full, const double *Linv, double *S_pcg);
+                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg);
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one launch
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . M^-1 r_it

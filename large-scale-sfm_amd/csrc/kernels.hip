@@ -940,30 +940,43 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const doubl
 // identity on the padding row/column and on the rows of the mcon fixed cameras.
 // one thread per matrix element, 64 threads = one block.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(int cnp, int nb, const unsigned char *__restrict__ fixed, double mu, const int *__restrict__ rowidx,
-                                                 const int *__restrict__ col, const int *__restrict__ src,
-                                                 const unsigned char *__restrict__ trans, const double *__restrict__ S_up,
-                                                 const double *__restrict__ cam_cw, const CamLinks lk, double *__restrict__ S_full)
+struct FinalizeArgs {
+    int cnp;
+    double mu;
+    const unsigned char *fixed, *trans;
+    const int *rowidx, *col, *src;
+    const double *S_up, *cam_cw;
+    CamLinks lk;
+};
+
+__device__ __forceinline__ double finalized_element(const FinalizeArgs &f, int blk, int el)
+{
+    const int r = el >> 3, c = el & 7, j = f.rowidx[blk], k = f.col[blk];
+    const double *sb = f.S_up + (size_t)f.src[blk] * 64;
+    double v;
+    if (j == k) {
+        v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
+        if (r == c && r < f.cnp && f.lk.row)                           // shared-intrinsics links: U_jj += sum w
+            for (int q = f.lk.row[j]; q < f.lk.row[j + 1]; ++q) v += f.lk.w[(size_t)q * kCP + r];
+        if (r == c) v = (r < f.cnp) ? v + f.mu + f.cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
+        if (f.fixed[j]) v = (r == c) ? 1.0 : 0.0;
+    } else {
+        v = f.trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
+        if (r == c && f.lk.row) { const int pq = f.lk.blk_pair[blk]; if (pq >= 0) v -= f.lk.pair_w[(size_t)pq * kCP + r]; } // U_jk = -w
+        if (f.fixed[j] || f.fixed[k]) v = 0.0;
+    }
+    if (r >= f.cnp || c >= f.cnp) v = (j == k && r == c) ? 1.0 : 0.0;
+    return v;
+}
+
+// the full matrix in HBM: only for the parity hooks (mi_ba_debug_linearize) -- the solve reads the elements straight from
+// the upper blocks (k_block_inv, k_scale_blocks)
+__global__ __launch_bounds__(256) void k_finalize(int nb, const FinalizeArgs f, double *__restrict__ S_full)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int blk = (int)(gid >> 6), el = (int)(gid & 63);
     if (blk >= nb) return;
-    const int r = el >> 3, c = el & 7, j = rowidx[blk], k = col[blk];
-    const double *sb = S_up + (size_t)src[blk] * 64;
-    double v;
-    if (j == k) {
-        v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
-        if (r == c && r < cnp && lk.row)                               // shared-intrinsics links: U_jj += sum w
-            for (int q = lk.row[j]; q < lk.row[j + 1]; ++q) v += lk.w[(size_t)q * kCP + r];
-        if (r == c) v = (r < cnp) ? v + mu + cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
-        if (fixed[j]) v = (r == c) ? 1.0 : 0.0;
-    } else {
-        v = trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
-        if (r == c && lk.row) { const int pq = lk.blk_pair[blk]; if (pq >= 0) v -= lk.pair_w[(size_t)pq * kCP + r]; } // U_jk = -w
-        if (fixed[j] || fixed[k]) v = 0.0;
-    }
-    if (r >= cnp || c >= cnp) v = (j == k && r == c) ? 1.0 : 0.0;
-    S_full[(size_t)blk * 64 + el] = v;
+    S_full[(size_t)blk * 64 + el] = finalized_element(f, blk, el);
 }
 
 // right-hand side E_j = ea_j - sum_i Y_ij eb_i (already folded: E = sum A^T (e - B h)), ||ea||_inf,
@@ -1013,19 +1026,19 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
 // E~ = L^-1 E, and da = L^-T x~.  Same iterates as block-Jacobi PCG on S (r~ = L^-1 r, so r~.r~ = r.M^-1 r, the quantity
 // the stopping rule looks at).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_block_inv(int m, const int *__restrict__ bsr_diag, const double *__restrict__ S_full,
+__global__ __launch_bounds__(64) void k_block_inv(int m, const int *__restrict__ bsr_diag, const FinalizeArgs f,
                                                  double *__restrict__ Linv, double *__restrict__ scal)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    const double *sb = S_full + (size_t)bsr_diag[j] * 64;
+    const int blk = bsr_diag[j];
     double L[8][8];
     bool ok = true;
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
-            double s = sb[r * 8 + c];
+            double s = finalized_element(f, blk, r * 8 + c);
 #pragma unroll
             for (int k = 0; k < c; ++k) s -= L[r][k] * L[c][k];
             if (r == c) { if (!(s > 0.0)) { ok = false; s = 1.0; } L[r][r] = sqrt(s); }
@@ -1049,17 +1062,15 @@ __global__ __launch_bounds__(64) void k_block_inv(int m, const int *__restrict__
 }
 
 // S~_jk = Linv_j S_jk Linv_k^T, one wavefront per block, lane (r,c)
-__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const int *__restrict__ rowidx, const int *__restrict__ col,
-                                                     const double *__restrict__ S_full, const double *__restrict__ Linv,
-                                                     double *__restrict__ S_pcg)
+__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg)
 {
     __shared__ double sh[4][2][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
     const int b = blockIdx.x * 4 + wv;
     const bool live = b < nb;
     const int bb = live ? b : 0;
-    const int j = rowidx[bb], k = col[bb];
-    sh[wv][0][lane] = S_full[(size_t)bb * 64 + lane];
+    const int j = f.rowidx[bb], k = f.col[bb];
+    sh[wv][0][lane] = finalized_element(f, bb, lane);
     const double lj[8] = { Linv[(size_t)j * 64 + r * 8], Linv[(size_t)j * 64 + r * 8 + 1], Linv[(size_t)j * 64 + r * 8 + 2], Linv[(size_t)j * 64 + r * 8 + 3],
                            Linv[(size_t)j * 64 + r * 8 + 4], Linv[(size_t)j * 64 + r * 8 + 5], Linv[(size_t)j * 64 + r * 8 + 6], Linv[(size_t)j * 64 + r * 8 + 7] };
     const double lk[8] = { Linv[(size_t)k * 64 + c * 8], Linv[(size_t)k * 64 + c * 8 + 1], Linv[(size_t)k * 64 + c * 8 + 2], Linv[(size_t)k * 64 + c * 8 + 3],
@@ -1494,27 +1505,23 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
     else { if (full) launch_build_t<6, true>(st, lds_mode, ntiles, a); else launch_build_t<6, false>(st, lds_mode, ntiles, a); }
 }
 
+// camera-side finish of the linearisation: right-hand side and norms, L^-1 of the diagonal blocks, the scaled matrix; the
+// full unscaled matrix only when S_full != nullptr (parity hooks)
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
-                     const int *bsr_src, const unsigned char *bsr_trans, const double *S_up, double *S_full,
+                     const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
-                     double *E, double *cam_part, double *stage, double *scal)
+                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg)
 {
+    FinalizeArgs f;
+    f.cnp = cnp; f.mu = mu; f.fixed = fixed; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
+    f.S_up = S_up; f.cam_cw = cam_cw; f.lk = links;
     const long long total = (long long)nb * 64;
-    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cnp, nb, fixed, mu, bsr_rowidx,
-                       bsr_col, bsr_src, bsr_trans, S_up, cam_cw, links, S_full);
+    if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, camvec, cam_a, cam_cw, cam_cv,
                        links, E, cam_part);
     launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);
-}
-
-void launch_block_inv(hipStream_t st, int m, const int *bsr_diag, const double *S_full, double *Minv, double *scal)
-{
-    hipLaunchKernelGGL(k_block_inv, dim3((m + 63) / 64), dim3(64), 0, st, m, bsr_diag, S_full, Minv, scal);
-}
-
-void launch_scale_blocks(hipStream_t st, int nb, const int *bsr_rowidx, const int *bsr_col, const double *S_full, const double *Linv, double *S_pcg)
-{
-    hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, bsr_rowidx, bsr_col, S_full, Linv, S_pcg);
+    hipLaunchKernelGGL(k_block_inv, dim3((m + 63) / 64), dim3(64), 0, st, m, bsr_diag, f, Linv, scal);
+    hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg);
 }
 
 void launch_pcg_init(hipStream_t st, const PcgArgs &a)
