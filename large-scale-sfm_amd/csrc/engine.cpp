@@ -414,6 +414,7 @@ LongArgs Engine::long_args(double mu, bool want_diag, double *dB_dev, int part_r
     a.scratch = d_long_scratch_.p; a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p;
     a.pts_new = d_pts_[cur_ ^ 1].p; a.dB = dB_dev; a.mu = mu; a.eps5 = cfg.opts[5]; a.max_pairs = long_max_pairs_;
     a.nlong = (int)plan_.long_pts.size(); a.m = m_; a.want_diag = want_diag ? 1 : 0; a.part_row0 = part_row0; a.cfg = model();
+    a.scal = scal_();
     return a;
 }
 
@@ -464,7 +465,7 @@ PcgArgs Engine::pcg_args()
     return p;
 }
 
-// PCG iterations [it0, pcg_maxit) in chunks with a host check after each (device-side convergence is sticky)
+// CG iterations [it0, pcg_maxit) in chunks with a host look after each (device-side convergence is sticky)
 bool Engine::pcg_chunks(int it0)
 {
     PcgArgs p = pcg_args();
@@ -473,42 +474,43 @@ bool Engine::pcg_chunks(int it0)
         const int chunk = std::min(kPcgChunk, cfg.pcg_maxit - it);
         for (int c = 0; c < chunk; ++c) { p.it = it + c; launch_pcg_iter(st_, p); }
         it += chunk;
-        p.it = it; launch_pcg_tail(st_, p); // rz_hist[it] and the converged flag after the chunk's last update
-        if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
-        if (!hipok(hipStreamSynchronize(st_), "sync (pcg)")) return false;
-        if (h_scal_[SC_PCG_STATUS] != 0.0 || h_scal_[SC_PCG_DONE] != 0.0) break;
+        p.it = it; p.last = it >= cfg.pcg_maxit; launch_pcg_tail(st_, p); // rz_hist[it] and the flags after the chunk's last update
+        if (!read_scalars()) return false;
+        if (h_scal_[SC_PCG_FINAL] != 0.0) break;
     }
     return true;
 }
 
-// PCG on S da = E.  A host check costs a round trip during which the GPU idles, so after the first solve the
-// iteration count of the previous solve (+ slack) is enqueued in one go, checked once, and only a guess that fell
-// short continues in checked chunks.  Iterations past convergence are no-op launches (sticky device-side flag).
+// CG on S~ x~ = E~, then the update phase, then the trial's scalars on the host (h_scal_).  A host look at the solve costs
+// a round trip during which the GPU idles (~30 us), so nothing here waits for one: the expected number of iterations is
+// enqueued in one go -- iterations past convergence are 2 us no-op launches (sticky device-side flag) -- followed by the
+// camera update and the back-substitution, which look at SC_PCG_FINAL themselves: when the guess fell short (the flag is
+// still down) the back-substitution does nothing, and the host, which sees the flag with the trial's scalars, continues the
+// iterations in checked chunks and launches the update phase again.
 bool Engine::solve_phase(double mu, double *dB_dev)
 {
     PcgArgs p = pcg_args();
     // (histories and partials need no reset: every slot a launch reads was written by an earlier launch of this solve)
     (void)hipEventRecord(ev_[2], st_);
     launch_pcg_init(st_, p);
-    int it0 = 0;
-    if (pcg_pred_ > kPcgChunk) {
-        // the count grows geometrically from trial to trial while the damping falls by 1/3 (measured on C3: 9, 14, 20, 33,
-        // 54, 93, then the cap): extrapolate the last ratio
-        const double ratio = pcg_pred_prev_ > 0 ? std::min(2.0, std::max(1.0, (double)pcg_pred_ / pcg_pred_prev_)) : 1.0;
-        it0 = std::min(cfg.pcg_maxit, (int)std::ceil(pcg_pred_ * ratio) + 2);
-        for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
-        p.it = it0; launch_pcg_tail(st_, p);
-        if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
-        if (!hipok(hipStreamSynchronize(st_), "sync (pcg)")) return false;
-        if (h_scal_[SC_PCG_STATUS] != 0.0 || h_scal_[SC_PCG_DONE] != 0.0) it0 = cfg.pcg_maxit;   // nothing left to do
-        else timing.pcg_resumes += 1;
-    }
-    if (it0 < cfg.pcg_maxit && !pcg_chunks(it0)) return false;
-    pcg_pred_prev_ = pcg_pred_ > 0 ? pcg_pred_ : (int)h_scal_[SC_PCG_ITERS];
-    pcg_pred_ = (int)h_scal_[SC_PCG_ITERS];
+    // the count grows geometrically from trial to trial while the damping falls by 1/3 (measured on C3: 9, 14, 20, 33, 54, 93,
+    // then the cap): extrapolate the last ratio, with a margin -- an iteration too many costs 2 us, one too few a round trip
+    const double ratio = pcg_pred_prev_ > 0 ? std::min(2.0, std::max(1.0, (double)pcg_pred_ / pcg_pred_prev_)) : 1.0;
+    const int it0 = std::min(cfg.pcg_maxit, std::max(kPcgChunk, (int)std::ceil(pcg_pred_ * ratio * 1.25) + 3));
+    for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
+    p.it = it0; p.last = it0 >= cfg.pcg_maxit; launch_pcg_tail(st_, p);
     launch_pcg_finish(st_, p);
     (void)hipEventRecord(ev_[3], st_);
-    return update_phase(mu, dB_dev);
+    if (!update_phase(mu, dB_dev) || !read_scalars()) return false;
+    if (h_scal_[SC_PCG_FINAL] == 0.0) { // the guess fell short
+        timing.pcg_resumes += 1;
+        if (!pcg_chunks(it0)) return false;
+        launch_pcg_finish(st_, p);
+        if (!update_phase(mu, dB_dev) || !read_scalars()) return false;
+    }
+    pcg_pred_prev_ = pcg_pred_ > 0 ? pcg_pred_ : (int)h_scal_[SC_PCG_ITERS];
+    pcg_pred_ = (int)h_scal_[SC_PCG_ITERS];
+    return true;
 }
 
 // camera update, back-substitution, cost at the trial point
@@ -522,7 +524,7 @@ bool Engine::update_phase(double mu, double *dB_dev)
     b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
-    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, kBacksubGrid); b.cfg = mc;
+    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, kBacksubGrid); b.cfg = mc; b.scal = scal_();
     (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, false, dB_dev, b.ngrid));
@@ -578,7 +580,7 @@ int Engine::step()
     const bool stops = !cfg.disable_stops;
     if (new_outer_) { ++njev_; new_outer_ = false; }
     const double mu = mu_;
-    if (!linear_phase(mu, false) || !solve_phase(mu, nullptr) || !read_scalars()) return MI_BA_ERROR;
+    if (!linear_phase(mu, false) || !solve_phase(mu, nullptr)) return MI_BA_ERROR;   // h_scal_ holds the trial's scalars
     float ms = 0;
     if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) { timing.build_ms += ms; timing.build_launches += 1; }
     if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) { timing.pcg_ms += ms; timing.pcg_solves += 1; }
@@ -782,7 +784,7 @@ int Engine::debug_solve(double mu, double *da, double *db, double *cost_new)
 {
     if (!prepared_) { err = "debug_solve: prepare first"; return MI_BA_ERROR; }
     if (cfg.world > 1 && db) { err = "debug_solve: point outputs need world == 1"; return MI_BA_ERROR; }
-    if (!solve_phase(mu, d_dB_.p) || !read_scalars()) return MI_BA_ERROR;
+    if (!solve_phase(mu, d_dB_.p)) return MI_BA_ERROR;
     const Plan &pl = plan_;
     if (cost_new) *cost_new = h_scal_[SC_COST_NEW];
     if (da) {

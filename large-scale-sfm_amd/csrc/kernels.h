@@ -36,6 +36,8 @@ enum Scal {
     SC_COST = 0, SC_PL2_PTS = 1, SC_CONS_PTS = 2,   // CONS_PTS: soft point-constraint penalty at p
     // [8,16) k_build maxima                                            (all-reduce #1, MAX)
     SC_EB_INF = 8, SC_MAXDIAG_V = 9, SC_SINGULAR = 10,
+    SC_PCG_FINAL = 12,   // (not a maximum: zero through all-reduce #1, set by k_pcg_tail afterwards) the solve is over: converged,
+                         // broken down or out of iterations -- what the back-substitution waits for
     // [16,32) camera-side values, computed redundantly on every rank: every sum is folded in a FIXED order
     // (per-wave partial rows + k_reduce_partials), so all ranks hold the same bits and take the same LM decisions
     SC_PL2_CAMS = 16, SC_CONS_CAM = 17, SC_LINK = 18,   // k_finalize_vec sums  [16,20)
@@ -89,6 +91,7 @@ struct BacksubArgs {
     double mu, eps5;
     int nbatch, ngrid;
     ModelCfg cfg;
+    const double *scal;                     // SC_PCG_FINAL == 0: the reduced solve has not finished, nothing to do yet
 };
 
 // long tracks (> 64 views): one workgroup per point, HBM scratch row per observation
@@ -102,6 +105,7 @@ struct LongArgs {
     long long max_pairs;
     int nlong, m, want_diag, part_row0;
     ModelCfg cfg;
+    const double *scal;
 };
 
 struct PcgArgs {
@@ -110,6 +114,7 @@ struct PcgArgs {
     double *x, *da, *p, *r0, *r1, *w0, *w1, *s0, *s1;  // r, w, s alternate by iteration parity (read by the neighbours' rows)
     double *gp, *dp, *rz_hist, *alpha_hist, *scal;     // gp, dp [2][nwg]: partials of r.r and w.r per workgroup; histories [maxit+2]
     double tol;
+    int last;                                          // k_pcg_tail: no iteration will follow this one
     int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init / k_pcg_finish); product kernels: nwg = m (one block row per
                                                        // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
 };

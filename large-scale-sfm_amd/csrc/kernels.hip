@@ -841,6 +841,7 @@ template <int CNP>
 __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
 {
     __shared__ double sh[4], sX[3];
+    if (g.scal[SC_PCG_FINAL] == 0.0) return;   // launched ahead of the host's look at the reduced solve (engine.cpp solve_phase)
     const int l = blockIdx.x, ip = g.long_pts[l], tid = threadIdx.x;
     const int os = g.pt_obs[ip], oe = g.pt_obs[ip + 1];
     const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
@@ -1237,16 +1238,20 @@ __global__ __launch_bounds__(256) void k_pcg_start(const PcgArgs a)
     publish_partials(a, 0, g, d, sh);
 }
 
-// rz_hist[it] = gamma_it, and the sticky converged flag; one wavefront.  Launched at the end of every chunk so the host
-// sees the state AFTER the chunk's last update.
+// rz_hist[it] = gamma_it, the sticky converged flag, and SC_PCG_FINAL when the solve is over (converged, broken down, or
+// a.last: no iteration will follow); one wavefront, launched after a run of iterations.
 __global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a)
 {
-    if (a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0) return;
-    const double g = wave_total(a.gp + (size_t)(a.it & 1) * a.nwg, a.nwg, threadIdx.x);
-    if (threadIdx.x == 0) {
-        a.rz_hist[a.it] = g;
-        if (a.it == 0 ? !(g > 0.0) : pcg_converged(a, g)) a.scal[SC_PCG_DONE] = 1.0;
+    bool over = a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0;
+    if (!over) {
+        const double g = wave_total(a.gp + (size_t)(a.it & 1) * a.nwg, a.nwg, threadIdx.x);
+        if (threadIdx.x == 0) a.rz_hist[a.it] = g;
+        if (a.it == 0 ? !(g > 0.0) : pcg_converged(a, g)) {
+            if (threadIdx.x == 0) a.scal[SC_PCG_DONE] = 1.0;
+            over = true;
+        }
     }
+    if (threadIdx.x == 0 && (over || a.last)) a.scal[SC_PCG_FINAL] = 1.0;
 }
 
 // iteration a.it.  The product w_{it+1} = S~ r_{it+1} needs r_{it+1} = r_it - alpha (w_it + beta s_{it-1}) of the neighbouring block
@@ -1355,6 +1360,7 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
 {
     __shared__ double sT[kWave * 3], sX[kMaxPtsBatch * 3];
     __shared__ int sStart[kMaxPtsBatch + 1];
+    if (g.scal[SC_PCG_FINAL] == 0.0) return;   // launched ahead of the host's look at the reduced solve (engine.cpp solve_phase)
     const int lane = threadIdx.x;
     const ModelCfg cfg = g.cfg;
     double cn = 0.0, pct = 0.0, dl = 0.0, dp2 = 0.0;
