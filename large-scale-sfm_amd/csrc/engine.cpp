@@ -496,7 +496,8 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     // the count grows geometrically from trial to trial while the damping falls by 1/3 (measured on C3: 9, 14, 20, 33, 54, 93,
     // then the cap): extrapolate the last ratio, with a margin -- an iteration too many costs 2 us, one too few a round trip
     const double ratio = pcg_pred_prev_ > 0 ? std::min(2.0, std::max(1.0, (double)pcg_pred_ / pcg_pred_prev_)) : 1.0;
-    const int it0 = std::min(cfg.pcg_maxit, std::max(kPcgChunk, (int)std::ceil(pcg_pred_ * ratio * 1.25) + 3));
+    int it0 = std::min(cfg.pcg_maxit, std::max(kPcgChunk, (int)std::ceil(pcg_pred_ * ratio * 1.25) + 3));
+    if (const char *force = std::getenv("MI_BA_PCG_FIRST_RUN")) it0 = std::min(cfg.pcg_maxit, std::max(1, std::atoi(force)));   // test hook: make the guess fall short
     for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
     p.it = it0; p.last = it0 >= cfg.pcg_maxit; launch_pcg_tail(st_, p);
     launch_pcg_finish(st_, p);

@@ -415,6 +415,26 @@ def test_rccl_exchange_on_a_one_rank_communicator(oracle, monkeypatch):
     assert abs(np.sqrt(info[1] / sc.nobs) - np.sqrt(z["info_final"][1] / sc.nobs)) < 1e-6
 
 
+@pytest.mark.parametrize("first_run", ["1", "3"])
+def test_a_short_first_run_of_the_reduced_solve_resumes_to_the_same_answer(monkeypatch, first_run):
+    """the camera update and the back-substitution are enqueued behind a guessed number of CG iterations; when the guess falls
+    short (forced here) the device-side flag keeps them idle, the host continues the iterations and launches them again:
+    the same iterates (two runs agree to rounding only: the Schur blocks are accumulated with floating-point atomics)"""
+    sc, z = scene_from_golden("C1")
+    eng = make_engine(sc, pcg_tol=1e-10, pcg_maxit=200)
+    ret0, info0 = eng.run()
+    p0, tr0, resumes0 = eng.packed_params(), eng.trace(), eng.timing()["pcg_resumes"]
+    eng.close()
+    monkeypatch.setenv("MI_BA_PCG_FIRST_RUN", first_run)
+    eng = make_engine(sc, pcg_tol=1e-10, pcg_maxit=200)
+    ret1, info1 = eng.run()
+    assert eng.timing()["pcg_resumes"] > max(resumes0, 5)
+    assert ret1 == ret0 and np.array_equal(info1[5:], info0[5:]) and np.allclose(info1[:5], info0[:5], rtol=1e-5, atol=0)
+    tr1 = eng.trace()
+    assert tr1.shape == tr0.shape and np.array_equal(tr1[:, [0, 4, 5]], tr0[:, [0, 4, 5]])      # trial by trial: same decisions, same CG counts
+    assert np.allclose(tr1[:, 1:4], tr0[:, 1:4], rtol=1e-9, atol=0) and np.abs(eng.packed_params() - p0).max() < 1e-9
+
+
 def test_error_paths():
     capi = pkg("capi")
     sc, _ = scene_from_golden("micro")
