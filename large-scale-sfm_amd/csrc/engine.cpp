@@ -350,7 +350,7 @@ int Engine::set_params(const double *a, const double *xyz)
     for (int t = pl.n_active; t < n_; ++t)
         for (int r = 0; r < 3; ++r) { double v = xyz[3 * (size_t)pl.perm[t] + r]; pl2_inactive_ += v * v; }
     if (xyz != h_xyz_.data()) h_xyz_.assign(xyz, xyz + (size_t)n_ * 3);
-    cur_ = 0;
+    cur_ = 0; cam_lin_valid_ = false;
     if (!hipok(hipMemcpy(d_cam_a_[0].p, ap.data(), ap.size() * sizeof(double), hipMemcpyHostToDevice), "upload cam_a")) return MI_BA_ERROR;
     if (npl && !hipok(hipMemcpy(d_pts_[0].p, pp.data(), pp.size() * sizeof(double), hipMemcpyHostToDevice), "upload pts")) return MI_BA_ERROR;
     // a device-resident copy of the starting point, for restart()
@@ -365,7 +365,7 @@ int Engine::set_params(const double *a, const double *xyz)
 int Engine::restart()
 {
     if (!prepared_ || !d_cam_a_init_.p) { err = "restart: prepare first"; return MI_BA_ERROR; }
-    cur_ = 0;
+    cur_ = 0; cam_lin_valid_ = false;
     if (!hipok(hipMemcpyAsync(d_cam_a_[0].p, d_cam_a_init_.p, d_cam_a_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore cam_a")) return MI_BA_ERROR;
     if (d_pts_init_.n && !hipok(hipMemcpyAsync(d_pts_[0].p, d_pts_init_.p, d_pts_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore pts")) return MI_BA_ERROR;
     return begin();
@@ -424,7 +424,8 @@ bool Engine::linear_phase(double mu, bool want_diag)
     const Plan &pl = plan_;
     const ModelCfg mc = model();
     if (!hipok(hipMemsetAsync(d_acc_.p, 0, d_acc_.n * sizeof(double), st_), "memset acc")) return false;
-    launch_cam_prep(st_, m_, cnp, mc, d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p);
+    // the camera records of the current estimate: after an accepted trial they are the ones k_cam_update wrote for the trial point
+    if (!cam_lin_valid_) { launch_cam_prep(st_, m_, cnp, mc, d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p); cam_lin_valid_ = true; }
     BuildArgs a{};
     a.tile_batch = d_tile_batch_.p; a.tile_slot = d_tile_slot_.p; a.tile_cslot = d_tile_cslot_.p;
     a.tile_mode = d_tile_mode_.p; a.has_table = pl.ntile_table > 0;

@@ -131,6 +131,7 @@ private:
     DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_S_pcg_, d_Linv_, d_E_, d_dA_, d_dB_,
         d_pcg_, d_rzpq_, d_full_pts_, d_part_, d_stage_;
     int cur_ = 0; // index of the current estimate in the [2] buffers
+    bool cam_lin_valid_ = false; // d_cam_lin_[cur_] holds the records of d_cam_a_[cur_]
     double *h_scal_ = nullptr; // pinned, kScalCount
     double *S_up_() { return d_acc_.p; }
     double *camvec_() { return d_acc_.p + (size_t)plan_.nb_up() * 64; }
