@@ -432,7 +432,7 @@ def test_a_short_first_run_of_the_reduced_solve_resumes_to_the_same_answer(monke
     assert ret1 == ret0 and np.array_equal(info1[5:], info0[5:]) and np.allclose(info1[:5], info0[:5], rtol=1e-5, atol=0)
     tr1 = eng.trace()
     assert tr1.shape == tr0.shape and np.array_equal(tr1[:, [0, 4]], tr0[:, [0, 4]])          # trial by trial: the same decisions
-    assert np.abs(tr1[:, 5] - tr0[:, 5]).max() <= 1                                              # and CG counts (a threshold crossing can move by one)
+    assert np.abs(tr1[:, 5] - tr0[:, 5]).max() <= 3                                              # and CG counts (at 1e-10 a threshold crossing moves by an iteration or two)
     assert np.allclose(tr1[:, 1:4], tr0[:, 1:4], rtol=1e-9, atol=0) and np.abs(eng.packed_params() - p0).max() < 1e-9
 
 
