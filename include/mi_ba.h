@@ -85,6 +85,11 @@ int mi_ba_set_cameras(mi_ba_engine *e, int m, const double *a0 /* m*cnp */, cons
 /* optional: cameras held constant beyond the leading mcon (CameraT::constant_camera, DataInterface.h:72);
  * mask[j] != 0 fixes camera j; NULL clears.  Call after mi_ba_set_cameras. */
 int mi_ba_set_fixed_cameras(mi_ba_engine *e, const unsigned char *mask /* m */);
+/* optional: single camera parameters held constant -- mask[j*cnp + r] != 0 keeps parameter r of camera j at its initial
+ * value while the rest of the camera moves (its row and column leave the reduced system).  What PBA does with the distortion
+ * coefficient under SetFixedIntrinsics(true): applied, not estimated (JacobianOne, SparseBundleCPU.cpp:1362-1363).  NULL
+ * clears.  Call after mi_ba_set_cameras and before prepare. */
+int mi_ba_set_fixed_params(mi_ba_engine *e, const unsigned char *mask /* m*cnp */);
 int mi_ba_set_points(mi_ba_engine *e, int n, const double *xyz /* n*3 */);
 /* observations sorted by point (pt_idx non-decreasing, like pba's driver.cpp:158-161 requires) */
 int mi_ba_set_observations(mi_ba_engine *e, int64_t nobs, const double *xy /* nobs*2 */,

@@ -74,7 +74,7 @@ def lib() -> C.CDLL:
             "mi_ba_set_observations": [vp, i64, dp, ip, ip], "mi_ba_set_camera_constraints": [vp, dp, dp],
             "mi_ba_set_camera_links": [vp, C.c_int, ip, ip, dp],
             "mi_ba_comm_set_host_allreduce": [vp, HOST_ALLREDUCE, vp],
-            "mi_ba_set_point_constraints": [vp, dp, dp], "mi_ba_set_fixed_cameras": [vp, C.c_void_p], "mi_ba_run": [vp, dp], "mi_ba_get_info": [vp, dp],
+            "mi_ba_set_point_constraints": [vp, dp, dp], "mi_ba_set_fixed_cameras": [vp, C.c_void_p], "mi_ba_set_fixed_params": [vp, C.c_void_p], "mi_ba_run": [vp, dp], "mi_ba_get_info": [vp, dp],
             "mi_ba_get_trace": [vp, dp, i32], "mi_ba_get_params": [vp, dp, dp], "mi_ba_set_params": [vp, dp, dp],
             "mi_ba_get_rotations": [vp, dp], "mi_ba_debug_linearize": [vp, dbl, dp, dp, dp, dp, dp, dp, dp],
             "mi_ba_debug_solve": [vp, dbl, dp, dp, dp], "mi_ba_get_timing": [vp, C.POINTER(Timing)],
@@ -163,6 +163,15 @@ class Engine:
         w = np.ascontiguousarray(weights, np.float64)
         self._keep_links = (a, b, w)
         self._chk(self.L.mi_ba_set_camera_links(self.h, len(a), a.ctypes.data_as(_ip), b.ctypes.data_as(_ip), _d(w)), "set_camera_links")
+
+    def set_fixed_params(self, mask):
+        """mask[j, r] != 0: parameter r of camera j is held at its initial value (None clears)"""
+        if mask is None:
+            self._chk(self.L.mi_ba_set_fixed_params(self.h, None), "set_fixed_params")
+            return
+        mk = np.ascontiguousarray(mask, np.uint8)
+        assert mk.size == self.m * self.cnp if hasattr(self, "m") else True
+        self._chk(self.L.mi_ba_set_fixed_params(self.h, mk.ctypes.data_as(C.c_void_p)), "set_fixed_params")
 
     def set_constraints(self, cam_w=None, cam_v=None, pt_w=None, pt_v=None):
         c = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)

@@ -55,6 +55,7 @@ int mi_ba_cnp(const mi_ba_engine *h) { return h ? h->e->cnp : MI_BA_ERROR; }
 int mi_ba_set_cameras(mi_ba_engine *h, int m, const double *a0, const double *R0, const double *f_fixed)
 { return h ? h->e->set_cameras(m, a0, R0, f_fixed) : MI_BA_ERROR; }
 int mi_ba_set_fixed_cameras(mi_ba_engine *h, const unsigned char *mask) { return h ? h->e->set_fixed_cameras(mask) : MI_BA_ERROR; }
+int mi_ba_set_fixed_params(mi_ba_engine *h, const unsigned char *mask) { return h ? h->e->set_fixed_params(mask) : MI_BA_ERROR; }
 int mi_ba_set_camera_constraints(mi_ba_engine *h, const double *w, const double *v) { return h ? h->e->set_camera_constraints(w, v) : MI_BA_ERROR; }
 int mi_ba_comm_set_host_allreduce(mi_ba_engine *h, mi_ba_host_allreduce_fn fn, void *user) { return h ? h->e->set_host_allreduce(fn, user) : MI_BA_ERROR; }
 int mi_ba_set_camera_links(mi_ba_engine *h, int nlink, const int *a, const int *b, const double *w) { return h ? h->e->set_camera_links(nlink, a, b, w) : MI_BA_ERROR; }

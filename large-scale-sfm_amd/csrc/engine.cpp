@@ -99,6 +99,18 @@ int Engine::set_fixed_cameras(const unsigned char *mask)
     return 0;
 }
 
+int Engine::set_fixed_params(const unsigned char *mask)
+{
+    if (!m_) { err = "set_fixed_params: set_cameras first"; return MI_BA_ERROR; }
+    h_pfix_.assign(m_, 0);
+    if (mask)
+        for (int j = 0; j < m_; ++j)
+            for (int r = 0; r < cnp; ++r)
+                if (mask[(size_t)j * cnp + r]) h_pfix_[j] |= (unsigned char)(1u << r);
+    prepared_ = begun_ = false;
+    return 0;
+}
+
 int Engine::set_camera_constraints(const double *weights, const double *values)
 {
     if (!m_) { err = "set_camera_constraints: set_cameras first"; return MI_BA_ERROR; }
@@ -291,6 +303,8 @@ int Engine::prepare()
         if (cfg.mode == 2) std::fill(fx.begin(), fx.end(), (unsigned char)1); // structure-only: A_ij := 0 everywhere
         UP(d_fixed_, fx);
         h_fixed_eff_ = fx;
+        if ((int)h_pfix_.size() != m_) h_pfix_.assign(m_, 0);
+        UP(d_pfix_, h_pfix_);
         nfree_cams_ = 0;
         for (unsigned char f : fx) nfree_cams_ += f ? 0 : 1;
     }
@@ -446,7 +460,7 @@ bool Engine::linear_phase(double mu, bool want_diag)
     (void)hipEventRecord(ev_[1], st_);
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
-    launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
+    launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
                     d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p);
     return hipok(hipGetLastError(), "launch (linear phase)");

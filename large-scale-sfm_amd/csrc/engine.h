@@ -45,6 +45,7 @@ public:
 
     int set_cameras(int m, const double *a0, const double *R0, const double *f_fixed);
     int set_fixed_cameras(const unsigned char *mask);
+    int set_fixed_params(const unsigned char *mask);
     int set_host_allreduce(mi_ba_host_allreduce_fn fn, void *user) { host_ar_ = fn; host_ar_user_ = user; return 0; }
     int set_camera_constraints(const double *weights, const double *values);
     int set_camera_links(int nlink, const int *cam_a, const int *cam_b, const double *weights);
@@ -100,7 +101,7 @@ private:
     int64_t nobs_ = 0;
     std::vector<double> h_a0_, h_R0_, h_ff_, h_xyz_, h_xy_;
     std::vector<int> h_pt_, h_cam_;
-    std::vector<unsigned char> h_fixed_, h_fixed_eff_;
+    std::vector<unsigned char> h_fixed_, h_fixed_eff_, h_pfix_;
     std::vector<double> h_cam_cw_, h_cam_cv_, h_pt_cw_, h_pt_cv_; // soft constraints (empty = none)
     std::vector<int> h_link_cam_;                                 // camera links: 2 ints per link
     std::vector<double> h_link_w_;                                // cnp weights per link
@@ -114,7 +115,7 @@ private:
     DevBuf<int> d_tile_batch_, d_tile_slot_, d_tile_cslot_, d_slot_gblk_, d_cslot_cam_, d_batch_obs_, d_batch_pt_, d_pt_obs_,
         d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_;
     DevBuf<long long> d_batch_pair_;
-    DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_;
+    DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_, d_pfix_;   // d_pfix_: per camera, bit r = parameter r held constant
     DevBuf<unsigned> d_pair_, d_pair_gblk_;
     DevBuf<unsigned long long> d_dbg_;
     DevBuf<int> d_long_pts_, d_long_scr_, d_up_row_, d_up_col_;

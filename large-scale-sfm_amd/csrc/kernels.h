@@ -122,7 +122,7 @@ struct PcgArgs {
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
                      const double *f_fixed, double *cam_lin);
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);
-void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
+void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full /* or nullptr */,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg);

@@ -944,7 +944,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const doubl
 struct FinalizeArgs {
     int cnp;
     double mu;
-    const unsigned char *fixed, *trans;
+    const unsigned char *fixed, *trans, *pfix;      // pfix[j] bit r: parameter r of camera j is held constant
     const int *rowidx, *col, *src;
     const double *S_up, *cam_cw;
     CamLinks lk;
@@ -966,7 +966,7 @@ __device__ __forceinline__ double finalized_element(const FinalizeArgs &f, int b
         if (r == c && f.lk.row) { const int pq = f.lk.blk_pair[blk]; if (pq >= 0) v -= f.lk.pair_w[(size_t)pq * kCP + r]; } // U_jk = -w
         if (f.fixed[j] || f.fixed[k]) v = 0.0;
     }
-    if (r >= f.cnp || c >= f.cnp) v = (j == k && r == c) ? 1.0 : 0.0;
+    if (r >= f.cnp || c >= f.cnp || ((f.pfix[j] >> r) & 1) || ((f.pfix[k] >> c) & 1)) v = (j == k && r == c) ? 1.0 : 0.0;   // padding, constant parameters
     return v;
 }
 
@@ -982,7 +982,8 @@ __global__ __launch_bounds__(256) void k_finalize(int nb, const FinalizeArgs f, 
 
 // right-hand side E_j = ea_j - sum_i Y_ij eb_i (already folded: E = sum A^T (e - B h)), ||ea||_inf,
 // max diag U, ||a||^2   (sba_levmar.c:1085-1088, 1124-1128)
-__global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsigned char *__restrict__ fixed, double *__restrict__ camvec,
+__global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsigned char *__restrict__ fixed, const unsigned char *__restrict__ pfix,
+                                                     double *__restrict__ camvec,
                                                      const double *__restrict__ cam_a, const double *__restrict__ cam_cw,
                                                      const double *__restrict__ cam_cv, const CamLinks lk, double *__restrict__ E,
                                                      double *__restrict__ part)
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
     double eainf = 0.0, maxdu = 0.0, pl2 = 0.0, cc = 0.0, lc = 0.0;
     if (gid < m * kCP) {
         const int j = gid >> 3, r = gid & 7;
-        const bool live = (r < cnp) && !fixed[j];
+        const bool live = (r < cnp) && !fixed[j] && !((pfix[j] >> r) & 1);
         double ea = camvec[gid], Ev = camvec[(size_t)m * kCP + gid], du = camvec[2 * (size_t)m * kCP + gid];
         if (r < cnp) {
             const double a = cam_a[gid], w = cam_cw[gid], d = cam_cv[gid] - a;
@@ -1513,17 +1514,17 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 
 // camera-side finish of the linearisation: right-hand side and norms, L^-1 of the diagonal blocks, the scaled matrix; the
 // full unscaled matrix only when S_full != nullptr (parity hooks)
-void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, double mu, const int *bsr_rowidx, const int *bsr_col,
+void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg)
 {
     FinalizeArgs f;
-    f.cnp = cnp; f.mu = mu; f.fixed = fixed; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
+    f.cnp = cnp; f.mu = mu; f.fixed = fixed; f.pfix = pfix; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
     f.S_up = S_up; f.cam_cw = cam_cw; f.lk = links;
     const long long total = (long long)nb * 64;
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
-    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, camvec, cam_a, cam_cw, cam_cv,
+    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, pfix, camvec, cam_a, cam_cw, cam_cv,
                        links, E, cam_part);
     launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);
     hipLaunchKernelGGL(k_block_inv, dim3((m + 63) / 64), dim3(64), 0, st, m, bsr_diag, f, Linv, scal);

@@ -99,18 +99,13 @@ int ParallelBA::RunBundleAdjustment()
     // EnableRadialDistortion: +1 distorts the projection, -1 the measurement (pba.h:73-84); with fixed intrinsics the
     // coefficient is applied but not estimated (JacobianOne, SparseBundleCPU.cpp:1362-1363, 1427)
     const int dist = c.__use_radial_distortion;
-    if (dist > 0 && c.__fixed_intrinsics) {
-        for (size_t j = 0; j < o.ncam; ++j)
-            if (o.cams[j].radial != 0) {
-                std::fprintf(stderr, "[mi_pba] fixed non-zero projection distortion is not supported\n");
-                c.__bundle_return_code = 'E';
-                return 0;
-            }
-    }
+    bool fixed_projection_distortion = false;   // fixed intrinsics with a projection distortion that is not zero: the coefficient is a
+    if (dist > 0 && c.__fixed_intrinsics)       // parameter the engine holds constant (mi_ba_set_fixed_params)
+        for (size_t j = 0; j < o.ncam; ++j) fixed_projection_distortion |= o.cams[j].radial != 0;
     mi_ba_config cfg;
     mi_ba_default_config(&cfg);
     cfg.est_focal = c.__fixed_intrinsics ? 0 : 1;
-    cfg.undistort = (dist != 0 && !c.__fixed_intrinsics) ? (dist > 0 ? 1 : 2) : 0;
+    cfg.undistort = (dist != 0 && !c.__fixed_intrinsics) ? (dist > 0 ? 1 : 2) : fixed_projection_distortion ? 1 : 0;
     if (cfg.undistort == 2) { // the coefficient of |x|^2 (pixels^2) is ~1e-7: scale its parameter by f^2 so that the additive damping sees a balanced column
         std::vector<float> fv(o.ncam);
         for (size_t j = 0; j < o.ncam; ++j) fv[j] = o.cams[j].f;
@@ -143,7 +138,7 @@ int ParallelBA::RunBundleAdjustment()
     }
     mi_ba_engine *e = mi_ba_create(&cfg);
     if (!e) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(nullptr)); c.__bundle_return_code = 'E'; return 0; }
-    const int m = (int)o.ncam, n = (int)o.npt, cnp = mi_ba_cnp(e);
+    const int m = (int)o.ncam, n = (int)o.npt, cnp = mi_ba_cnp(e), kslot = 6 + cfg.est_focal;
     std::vector<double> a0((size_t)m * cnp, 0.0), R0((size_t)m * 9), ff(m), xyz((size_t)n * 3), xy(o.nproj * 2);
     std::vector<unsigned char> fixed(m, 0);
     bool some_fixed_intrinsics = false;
@@ -151,7 +146,7 @@ int ParallelBA::RunBundleAdjustment()
         const CameraT &cam = o.cams[j];
         for (int r = 0; r < 3; ++r) a0[(size_t)j * cnp + r] = cam.t[r];
         if (cfg.est_focal) a0[(size_t)j * cnp + 6] = (double)cam.f * cfg.f_scale;
-        if (cfg.undistort) a0[(size_t)j * cnp + 7] = (double)cam.radial * cfg.k_scale;   // PBA reads c[13] whatever its type tag
+        if (cfg.undistort) a0[(size_t)j * cnp + kslot] = (double)cam.radial * cfg.k_scale;   // PBA reads c[13] whatever its type tag
         for (int r = 0; r < 9; ++r) R0[(size_t)j * 9 + r] = cam.m[r / 3][r % 3];
         ff[j] = cam.f;
         fixed[j] = cam.constant_camera == 1.0f;
@@ -173,9 +168,12 @@ int ParallelBA::RunBundleAdjustment()
     std::vector<double> link_w(fl.a.size() * (size_t)cnp, 0.0);
     for (size_t q = 0; q < fl.a.size(); ++q) {   // internal units: a6 = f * f_scale, a7 = k * k_scale
         link_w[q * cnp + 6] = fl.w[q] * fl.w[q] / (cfg.f_scale * cfg.f_scale);
-        if (cfg.undistort) link_w[q * cnp + 7] = link_wr[q] * link_wr[q] / (cfg.k_scale * cfg.k_scale);
+        if (cfg.undistort && cfg.est_focal) link_w[q * cnp + 7] = link_wr[q] * link_wr[q] / (cfg.k_scale * cfg.k_scale);
     }
+    std::vector<unsigned char> frozen;
+    if (fixed_projection_distortion) { frozen.assign((size_t)m * cnp, 0); for (int j = 0; j < m; ++j) frozen[(size_t)j * cnp + kslot] = 1; }
     if (mi_ba_set_cameras(e, m, a0.data(), R0.data(), ff.data()) || mi_ba_set_fixed_cameras(e, fixed.data()) ||
+        mi_ba_set_fixed_params(e, frozen.empty() ? nullptr : frozen.data()) ||
         mi_ba_set_camera_links(e, (int)fl.a.size(), fl.a.data(), fl.b.data(), link_w.data()) ||
         mi_ba_set_points(e, n, xyz.data()) || mi_ba_set_observations(e, (int64_t)o.nproj, xy.data(), o.ptidx, o.camidx) ||
         mi_ba_prepare(e) || mi_ba_begin(e)) {
@@ -223,8 +221,8 @@ int ParallelBA::RunBundleAdjustment()
             for (int r = 0; r < 3; ++r) cam.t[r] = (float)a[(size_t)j * cnp + r];
             for (int r = 0; r < 9; ++r) cam.m[r / 3][r % 3] = (float)R[(size_t)j * 9 + r];
             if (cfg.est_focal) cam.f = (float)(a[(size_t)j * cnp + 6] / cfg.f_scale);
-            if (cfg.undistort == 1) cam.SetProjectionDistortion(a[(size_t)j * cnp + 7] / cfg.k_scale);
-            if (cfg.undistort == 2) cam.SetMeasumentDistortion(a[(size_t)j * cnp + 7] / cfg.k_scale);
+            if (cfg.undistort == 1 && !fixed_projection_distortion) cam.SetProjectionDistortion(a[(size_t)j * cnp + kslot] / cfg.k_scale);
+            if (cfg.undistort == 2) cam.SetMeasumentDistortion(a[(size_t)j * cnp + kslot] / cfg.k_scale);
         }
         for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) o.pts[i].xyz[r] = (float)xyz[(size_t)i * 3 + r];
         ret = c.__num_lm_success;

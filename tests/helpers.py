@@ -153,7 +153,7 @@ def run_pba_client(exe, problem, workdir, device, m, n):
                 radial=cams[:, 13], pts=pts, stdout=out.stdout)
 
 
-PBA_CASES = ("plain", "early_stop", "proj_dist", "meas_dist", "fixed_intr_md", "motion_only", "structure_only",
+PBA_CASES = ("plain", "early_stop", "proj_dist", "meas_dist", "fixed_intr_md", "fixed_intr_pd", "motion_only", "structure_only",
              "shared_focal", "shared_focal_groups_pd")
 
 
@@ -172,6 +172,12 @@ def pba_case(name):
         sc = vsfm_scene(m=16, n=1500, d=5, seed=34, undistort=2, est_focal=0, f_noise=0.0)
         kw.update(distortion=-1, fixed_intr=1, radial=np.full(16, -1.25e-7))
         # the scene generator put the distortion parameter into p0; the fixed-intrinsics problem has no such column
+        m, cnp = sc.m, sc.cnp
+        a = sc.p0[:m * cnp].reshape(m, cnp)[:, :6]
+        sc.p0 = np.concatenate([a.reshape(-1), sc.p0[m * cnp:]]); sc.cnp = 6; sc.undistort = 0
+    elif name == "fixed_intr_pd":                    # calibrated cameras with a known projection distortion: applied, not estimated
+        sc = vsfm_scene(m=16, n=1500, d=5, seed=39, undistort=1, nk=1, k_true=(-0.12, 0.0), est_focal=0, f_noise=0.0)
+        kw.update(distortion=1, fixed_intr=1, radial=np.full(16, -0.12))
         m, cnp = sc.m, sc.cnp
         a = sc.p0[:m * cnp].reshape(m, cnp)[:, :6]
         sc.p0 = np.concatenate([a.reshape(-1), sc.p0[m * cnp:]]); sc.cnp = 6; sc.undistort = 0

@@ -208,6 +208,8 @@ def test_parallelba_against_the_references_own_parallelba(name, pba_mi_client):
             assert np.abs(r["f"] - ref["f"]).max() < 0.5
     if kw.get("mode", 0) != 1:
         assert np.abs(r["pts"] - ref["pts"]).max() < 5e-4
+    if kw.get("distortion") and kw.get("fixed_intr"):  # applied, not estimated: handed back as it came
+        assert np.array_equal(r["radial"], ref["radial"]) and np.array_equal(r["f"], ref["f"])
     if kw.get("distortion") and not kw.get("fixed_intr"):
         scale = np.abs(ref["radial"]).max()
         assert np.abs(r["radial"] - ref["radial"])[nc:].max() < 0.03 * scale

@@ -415,6 +415,58 @@ def test_rccl_exchange_on_a_one_rank_communicator(oracle, monkeypatch):
     assert abs(np.sqrt(info[1] / sc.nobs) - np.sqrt(z["info_final"][1] / sc.nobs)) < 1e-6
 
 
+def test_parameters_held_constant(oracle):
+    """mi_ba_set_fixed_params: a constant parameter's row and column leave the reduced system (identity row, zero right-hand
+    side), the rest of the camera moves.  (1) against numpy on the oracle's blocks for a mixed mask; (2) every focal length
+    held in a 7-parameter engine is the 6-parameter problem -- the engine the oracle pins -- trial for trial"""
+    sc, z = scene_from_golden("C1")
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    assert cnp == 7
+    mask = np.zeros((m, cnp), np.uint8)
+    mask[:, 6] = np.arange(m) % 3 == 0                       # some focal lengths
+    mask[4, 0:3] = 1                                          # one camera's position (its rotation stays free)
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    eng.set_fixed_params(mask)
+    eng.prepare()
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    g = eng.debug_linearize(mu)
+    S, E, _ = reduced_system(lin, sc, mu)
+    frozen = mask.reshape(-1).astype(bool)
+    S[frozen, :] = 0; S[:, frozen] = 0; S[frozen, frozen] = 1.0; E[frozen] = 0
+    assert np.abs(g["S"] - S).max() < 1e-10 * np.abs(lin["U"]).max() and rel(g["E"].reshape(-1), E) < 1e-9
+    sol = eng.debug_solve(mu)
+    da = np.linalg.solve(S, E)
+    assert np.abs(sol["da"].reshape(-1) - da).max() < 1e-7 * np.abs(da).max() and np.all(sol["da"].reshape(-1)[frozen] == 0)
+    ret, info = eng.run()
+    a1 = eng.packed_params()[:m * cnp].reshape(m, cnp); a0 = sc.p0[:m * cnp].reshape(m, cnp)
+    assert np.array_equal(a1[mask.astype(bool)], a0[mask.astype(bool)]) and np.all(a1[~mask.astype(bool)] != a0[~mask.astype(bool)])
+    assert info[1] < 1.1 * z["info_final"][1]                 # still a good minimum
+    eng.close()
+    # (2)
+    mask = np.zeros((m, cnp), np.uint8); mask[:, 6] = 1
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    eng.set_fixed_params(mask); eng.prepare()
+    ret7, info7 = eng.run()
+    tr7, p7 = eng.trace(), eng.packed_params()
+    eng.close()
+    scene = pkg("scene")
+    p6 = np.concatenate([a0[:, :6].reshape(-1), sc.p0[m * cnp:]])
+    sc6 = scene.Scene(n=n, m=m, cnp=6, est_focal=0, undistort=0, explicit_centers=sc.explicit_centers, proj_sign=sc.proj_sign, pt_ptr=sc.pt_ptr,
+                      obs_cam=sc.obs_cam, x=sc.x, R0=sc.R0, f_fixed=a0[:, 6] / 0.001, p0=p6, p_true=p6, name="C1f")
+    eng = make_engine(sc6, pcg_tol=1e-12, pcg_maxit=400)
+    ret6, info6 = eng.run()
+    o = oracle.run(sc6, itmax=150, fd_jacobian=0)
+    assert ret6 == o["ret"] and abs(info6[1] - o["info"][1]) < 1e-8 * o["info"][1]       # the 6-parameter engine is the oracle's
+    tr6, q6 = eng.trace(), eng.packed_params()
+    assert ret7 == ret6 and info7[6] == info6[6] and np.allclose(info7[:5], info6[:5], rtol=1e-6, atol=0)
+    assert tr7.shape == tr6.shape and np.array_equal(tr7[:, [0, 4]], tr6[:, [0, 4]]) and np.allclose(tr7[:, 1:4], tr6[:, 1:4], rtol=1e-8, atol=0)
+    a7 = p7[:m * cnp].reshape(m, cnp)
+    assert np.abs(a7[:, :6] - q6[:m * 6].reshape(m, 6)).max() < 1e-8 and np.abs(p7[m * cnp:] - q6[m * 6:]).max() < 1e-8
+    # a mask of the wrong camera count is refused by the binding's size check, a cleared mask frees everything again
+    eng.close()
+
+
 @pytest.mark.parametrize("first_run", ["1", "3"])
 def test_a_short_first_run_of_the_reduced_solve_resumes_to_the_same_answer(monkeypatch, first_run):
     """the camera update and the back-substitution are enqueued behind a guessed number of CG iterations; when the guess falls
