@@ -78,12 +78,19 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # MI_BA_BENCH_ONE_GPU=1: a rehearsal of the N > 1 control flow on a box with ONE GPU -- every rank on device 0, the
+    # exchanges through the engine's host transport and gloo instead of RCCL.  Marked in the output; never a measurement.
+    rehearsal = world > 1 and os.environ.get("MI_BA_BENCH_ONE_GPU") == "1"
+    device = 0 if rehearsal else local_rank
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     capi = importlib.import_module("large-scale-sfm_amd.capi")
     scene_mod = importlib.import_module("large-scale-sfm_amd.scene")
@@ -91,9 +98,13 @@ def main():
     t0 = time.time()
     sc = scene_mod.make_scene(args.config)
     t_gen = time.time() - t0
-    cfg = capi.default_config(device=local_rank, rank=rank, world=world, pcg_tol=args.pcg_tol, pcg_maxit=args.pcg_maxit)
+    cfg = capi.default_config(device=device, rank=rank, world=world, pcg_tol=args.pcg_tol, pcg_maxit=args.pcg_maxit)
     eng = capi.Engine(cfg)
-    if world > 1:
+    if rehearsal:
+        def host_allreduce(buf, op):
+            dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
+        eng.set_host_allreduce(host_allreduce)
+    elif world > 1:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
@@ -133,7 +144,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     tm = eng.timing()
@@ -154,6 +165,7 @@ def main():
             "value": args.steps / dt, "unit": "LM iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            **({"rehearsal": "ranks share one GPU, host transport: control flow only, not a measurement"} if rehearsal else {}),
             "config": {"workload": f"{args.config}: {sc.m} cams / {sc.n} pts / {sc.nobs} obs, cnp 7 (pose + focal), "
                        "point-sharded Schur + block-Jacobi PCG", "parallelism": f"points/{world}",
                        "pcg_tol": args.pcg_tol, "pcg_maxit": args.pcg_maxit},

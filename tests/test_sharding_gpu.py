@@ -85,3 +85,22 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_rank_solve(tmp_path, world, 
     assert abs(int(res[0]["ret"]) - ret) <= 1 and res[0]["info"][6] == info[6]
     assert abs(res[0]["info"][1] - info[1]) < 1e-9 * info[1]
     assert np.abs(res[0]["p"] - eng.packed_params()).max() < 1e-6
+
+
+def test_bench_with_two_ranks_rehearsed_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed here with both ranks on
+    the one GPU of the box (MI_BA_BENCH_ONE_GPU: gloo + the engine's host transport instead of RCCL): the sharded engine, the
+    barrier / max-over-ranks timing and the one JSON line of rank 0"""
+    import json
+    import subprocess
+    env = dict(os.environ, MI_BA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    port = 29500 + (os.getpid() % 400)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--config", "C1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                              # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and "rehearsal" in d and d["config"]["parallelism"] == "points/2"
+    assert d["rmse_px"]["after_timed_steps"] < 0.5 * d["rmse_px"]["initial"] and d["kernel_ms_per_step"]["allreduce_host"] > 0
