@@ -168,6 +168,80 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
     }
 }
 
+// What the back-substitution needs of an observation: the residual e, and t = B^T (A da) -- the camera block A only
+// through its product with the camera's update.  With the per-camera vectors v0 = dq/d(centre or translation) . dC
+// (= -R dC with explicit centres, dt otherwise) and u = J_l(w) dw, A da = Pq (v0 - qr x u) + the intrinsics columns,
+// so neither A nor M = -[qr]x J_l is formed (a third of linearize_obs' arithmetic).
+struct CamDelta { double v0[3], u[3], df, dk; };   // df, dk: the updates of the focal-length and distortion parameters (internal units)
+
+__device__ __forceinline__ CamDelta cam_delta(const ModelCfg &cfg, const double *__restrict__ cl, const double *__restrict__ da, bool fixed_cam, bool full)
+{
+    CamDelta d;
+    if (fixed_cam) { d.v0[0] = d.v0[1] = d.v0[2] = d.u[0] = d.u[1] = d.u[2] = d.df = d.dk = 0.0; return d; }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        d.v0[r] = cfg.explicit_centers ? -(cl[3 * r] * da[0] + cl[3 * r + 1] * da[1] + cl[3 * r + 2] * da[2]) : da[r];
+        d.u[r] = cl[9 + 3 * r] * da[3] + cl[9 + 3 * r + 1] * da[4] + cl[9 + 3 * r + 2] * da[5];
+    }
+    const bool has_f = !full || cfg.est_focal;
+    d.df = has_f ? da[6] : 0.0;
+    d.dk = (full && cfg.undistort) ? da[has_f ? 7 : 6] : 0.0;
+    return d;
+}
+
+template <int CNP, bool FULL>
+__device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *__restrict__ cl, const CamDelta &cd, const double X[3], double2 xy,
+                                            double e[2], double t[3])
+{
+    double q[3], qr[3];
+    const bool md = FULL && cfg.undistort == 2;
+    const double m2k = md ? (xy.x * xy.x + xy.y * xy.y) : 0.0;
+    const double f = cl[21];
+    const double k1 = (FULL && !md) ? cl[22] : 0.0, k2 = FULL ? cl[23] : 0.0;
+    if (cfg.explicit_centers) {
+        const double d0 = X[0] - cl[18], d1 = X[1] - cl[19], d2 = X[2] - cl[20];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { qr[r] = cl[3 * r] * d0 + cl[3 * r + 1] * d1 + cl[3 * r + 2] * d2; q[r] = qr[r]; }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { qr[r] = cl[3 * r] * X[0] + cl[3 * r + 1] * X[1] + cl[3 * r + 2] * X[2]; q[r] = qr[r] + cl[18 + r]; }
+    }
+    const double s = cfg.proj_sign, iz = 1.0 / q[2];
+    const double mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
+    const double D = FULL ? 1.0 + k1 * r2 + k2 * r2 * r2 : 1.0, Dp = FULL ? k1 + 2.0 * k2 * r2 : 0.0;
+    e[0] = xy.x - s * f * mx * D;
+    e[1] = xy.y - s * f * my * D;
+    if (md) { const double kk = cl[22] * m2k; e[0] = fma(kk, xy.x, e[0]); e[1] = fma(kk, xy.y, e[1]); }
+    const double dmx[3] = { iz, 0.0, -mx * iz }, dmy[3] = { 0.0, iz, -my * iz };
+    double Pq[2][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double dr2 = 2.0 * (mx * dmx[c] + my * dmy[c]);
+        Pq[0][c] = s * f * (D * dmx[c] + mx * Dp * dr2);
+        Pq[1][c] = s * f * (D * dmy[c] + my * Dp * dr2);
+    }
+    // dq = v0 + M u with M u = -(qr x u)
+    const double dq[3] = { cd.v0[0] - (qr[1] * cd.u[2] - qr[2] * cd.u[1]), cd.v0[1] - (qr[2] * cd.u[0] - qr[0] * cd.u[2]),
+                           cd.v0[2] - (qr[0] * cd.u[1] - qr[1] * cd.u[0]) };
+    double w[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double mr = (r == 0) ? mx : my;
+        w[r] = Pq[r][0] * dq[0] + Pq[r][1] * dq[1] + Pq[r][2] * dq[2];
+        if constexpr (CNP >= 7) {
+            w[r] = fma(s * mr * D / cfg.f_scale, cd.df, w[r]);       // zero update when the focal length is not a parameter
+            if (FULL) w[r] = fma(md ? -m2k * (r == 0 ? xy.x : xy.y) / cfg.k_scale : s * f * mr * r2 / cfg.k_scale, cd.dk, w[r]);
+        }
+    }
+    if (cfg.points_fixed) { t[0] = t[1] = t[2] = 0.0; return; }      // a motion-only bundle has no structure block
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double B0 = Pq[0][0] * cl[c] + Pq[0][1] * cl[3 + c] + Pq[0][2] * cl[6 + c];
+        const double B1 = Pq[1][0] * cl[c] + Pq[1][1] * cl[3 + c] + Pq[1][2] * cl[6 + c];
+        t[c] = B0 * w[0] + B1 * w[1];
+    }
+}
+
 // exp([w]x) R0 exactly as rot_update (sfm.c:78-117), and the left Jacobian of SO(3) at w
 __device__ __forceinline__ void cam_record(const ModelCfg &cfg, int cnp, const double *__restrict__ a,
                                            const double *__restrict__ R0, double f_fix, double *__restrict__ cl)
@@ -1373,7 +1447,8 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
     // of the head lane) is requested at its top, so no load sits behind an LDS hand-off.
     const int chunk = (g.nbatch + gridDim.x - 1) / gridDim.x;
     const int b0 = blockIdx.x * chunk, b1 = min(g.nbatch, b0 + chunk);
-    double cl[kCamLin], cln[16], da[kCP];
+    double cl[kCamLin], cln[16];
+    CamDelta cd;
     int jc = -1;
     // software pipeline registers: the next batch's descriptor and observation stream
     int n_o0 = 0, n_nob = 0, n_p0 = 0, n_npt = 0, n_j = 0, n_ip = 0;
@@ -1415,17 +1490,16 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
                 for (int k = 0; k < 5; ++k) { const double2 v = s1[k]; cln[2 * k] = v.x; cln[2 * k + 1] = v.y; }       // R (9)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { const double2 v = s1[9 + k]; cln[10 + 2 * k] = v.x; cln[11 + 2 * k] = v.y; } // c f k1 k2
+                double da[kCP];
 #pragma unroll
                 for (int k = 0; k < kCP / 2; ++k) { const double2 v = s2[k]; da[2 * k] = v.x; da[2 * k + 1] = v.y; }
+                cd = cam_delta(cfg, cl, da, g.cam_fixed[j] != 0, FULL);
                 jc = j;
             }
-            double A[2][CNP], B[2][3];
-            linearize_obs<CNP, FULL>(cfg, cl, X, xy, g.cam_fixed[j] != 0, e, A, B);
-            double w0 = 0.0, w1 = 0.0;
+            double t[3];
+            backsub_obs<CNP, FULL>(cfg, cl, cd, X, xy, e, t);
 #pragma unroll
-            for (int t = 0; t < CNP; ++t) { w0 = fma(A[0][t], da[t], w0); w1 = fma(A[1][t], da[t], w1); }
-#pragma unroll
-            for (int t = 0; t < 3; ++t) sT[lane * 3 + t] = B[0][t] * w0 + B[1][t] * w1;
+            for (int c = 0; c < 3; ++c) sT[lane * 3 + c] = t[c];
         }
         wave_lds_sync();
         if (head) { // the head lane of a point owns the point: it already holds X and the ptout row
