@@ -1097,69 +1097,74 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
 
 // ------------------------------------------------------------------------------------------
 // block-Jacobi preconditioning, applied to the matrix once per trial instead of to a vector twice per iteration:
-// with S_jj = L_j L_j^T (unrolled 8x8 Cholesky, one thread per camera; PBA: ComputeDiagonalBlockC +
+// with S_jj = L_j L_j^T (unrolled 8x8 Cholesky per camera; PBA: ComputeDiagonalBlockC +
 // InvertSymmetricMatrix, SparseBundleCPU.cpp:1604-1734) the solve runs on  S~ = L^-1 S L^-T  (unit diagonal blocks),
 // E~ = L^-1 E, and da = L^-T x~.  Same iterates as block-Jacobi PCG on S (r~ = L^-1 r, so r~.r~ = r.M^-1 r, the quantity
 // the stopping rule looks at).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_block_inv(int m, const int *__restrict__ bsr_diag, const FinalizeArgs f,
-                                                 double *__restrict__ Linv, double *__restrict__ scal)
+// one wavefront per camera: the 64 lanes fetch the diagonal block's 64 finalised elements at once (one round of memory
+// latency instead of 36 dependent ones), lane 0 factors it from LDS and writes L^-1
+__global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict__ bsr_diag, const FinalizeArgs f,
+                                                  double *__restrict__ Linv, double *__restrict__ scal)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= m) return;
-    const int blk = bsr_diag[j];
-    double L[8][8];
-    bool ok = true;
+    __shared__ double sb[4][64], so[4][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv;
+    const bool live = j < m;
+    sb[wv][lane] = live ? finalized_element(f, bsr_diag[j], lane) : 0.0;
+    wave_lds_sync();
+    if (live && lane == 0) {
+        double L[8][8];
+        bool ok = true;
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
+        for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int c = 0; c <= r; ++c) {
-            double s = finalized_element(f, blk, r * 8 + c);
+            for (int c = 0; c <= r; ++c) {
+                double s = sb[wv][r * 8 + c];
 #pragma unroll
-            for (int k = 0; k < c; ++k) s -= L[r][k] * L[c][k];
-            if (r == c) { if (!(s > 0.0)) { ok = false; s = 1.0; } L[r][r] = sqrt(s); }
-            else L[r][c] = s / L[c][c];
-        }
-    if (!ok) atomic_max_pos(&scal[SC_NOT_PD], 1.0);
-    double *out = Linv + (size_t)j * 64;
+                for (int k = 0; k < c; ++k) s -= L[r][k] * L[c][k];
+                if (r == c) { if (!(s > 0.0)) { ok = false; s = 1.0; } L[r][r] = sqrt(s); }
+                else L[r][c] = s / L[c][c];
+            }
+        if (!ok) atomic_max_pos(&scal[SC_NOT_PD], 1.0);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        double col[8];
+        for (int c = 0; c < 8; ++c) {
+            double col[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (r < c) { col[r] = 0.0; out[r * 8 + c] = 0.0; continue; }
-            double s = (r == c) ? 1.0 : 0.0;
+            for (int r = 0; r < 8; ++r) {
+                if (r < c) { col[r] = 0.0; so[wv][r * 8 + c] = 0.0; continue; }
+                double s = (r == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = 0; k < r; ++k) if (k >= c) s -= L[r][k] * col[k];
-            col[r] = s / L[r][r];
-            out[r * 8 + c] = col[r];
+                for (int k = 0; k < r; ++k) if (k >= c) s -= L[r][k] * col[k];
+                col[r] = s / L[r][r];
+                so[wv][r * 8 + c] = col[r];
+            }
         }
     }
+    wave_lds_sync();
+    if (live) Linv[(size_t)j * 64 + lane] = so[wv][lane];
 }
 
-// S~_jk = Linv_j S_jk Linv_k^T, one wavefront per block, lane (r,c)
+// S~_jk = Linv_j S_jk Linv_k^T, one wavefront per block, lane (r,c); the block and the two factors go through LDS
 __global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg)
 {
-    __shared__ double sh[4][2][64];
+    __shared__ double sh[4][4][64];   // per wavefront: S, T = Linv_j S, Linv_j, Linv_k
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
     const int b = blockIdx.x * 4 + wv;
     const bool live = b < nb;
     const int bb = live ? b : 0;
     const int j = f.rowidx[bb], k = f.col[bb];
     sh[wv][0][lane] = finalized_element(f, bb, lane);
-    const double lj[8] = { Linv[(size_t)j * 64 + r * 8], Linv[(size_t)j * 64 + r * 8 + 1], Linv[(size_t)j * 64 + r * 8 + 2], Linv[(size_t)j * 64 + r * 8 + 3],
-                           Linv[(size_t)j * 64 + r * 8 + 4], Linv[(size_t)j * 64 + r * 8 + 5], Linv[(size_t)j * 64 + r * 8 + 6], Linv[(size_t)j * 64 + r * 8 + 7] };
-    const double lk[8] = { Linv[(size_t)k * 64 + c * 8], Linv[(size_t)k * 64 + c * 8 + 1], Linv[(size_t)k * 64 + c * 8 + 2], Linv[(size_t)k * 64 + c * 8 + 3],
-                           Linv[(size_t)k * 64 + c * 8 + 4], Linv[(size_t)k * 64 + c * 8 + 5], Linv[(size_t)k * 64 + c * 8 + 6], Linv[(size_t)k * 64 + c * 8 + 7] };
-    __syncthreads();
+    sh[wv][2][lane] = Linv[(size_t)j * 64 + lane];
+    sh[wv][3][lane] = Linv[(size_t)k * 64 + lane];
+    wave_lds_sync();
     double t = 0.0;                                   // T = Linv_j S
 #pragma unroll
-    for (int a = 0; a < 8; ++a) t = fma(lj[a], sh[wv][0][a * 8 + c], t);
+    for (int a = 0; a < 8; ++a) t = fma(sh[wv][2][r * 8 + a], sh[wv][0][a * 8 + c], t);
     sh[wv][1][lane] = t;
-    __syncthreads();
+    wave_lds_sync();
     double o = 0.0;                                   // T Linv_k^T
 #pragma unroll
-    for (int a = 0; a < 8; ++a) o = fma(sh[wv][1][r * 8 + a], lk[a], o);
+    for (int a = 0; a < 8; ++a) o = fma(sh[wv][1][r * 8 + a], sh[wv][3][c * 8 + a], o);
     if (live) S_pcg[(size_t)b * 64 + lane] = (j == k) ? (r == c ? 1.0 : 0.0) : o;   // the diagonal blocks are the identity by construction
 }
 
@@ -1601,7 +1606,7 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, pfix, camvec, cam_a, cam_cw, cam_cv,
                        links, E, cam_part);
     launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);
-    hipLaunchKernelGGL(k_block_inv, dim3((m + 63) / 64), dim3(64), 0, st, m, bsr_diag, f, Linv, scal);
+    hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal);
     hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg);
 }
 
