@@ -154,10 +154,15 @@ typedef struct {
     double pcg_resumes;                    /* solves whose unchecked first run of PCG iterations fell short (engine.cpp solve_phase) */
     double build_flops;                    /* algorithmic f64 flops of one build launch: 400 per observation (residual, Jacobian,
                                             * V / e_b / E terms), 2 x 138 per pair block, 120 per point (3x3 inverse, h) */
-    double reserved[3];
+    double pcg_timed;                      /* solves that pcg_ms covers (mi_ba_set_timing_detail >= 2) */
+    double reserved[2];
 } mi_ba_timing;
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_reset_timing(mi_ba_engine *e);
+/* which phases are bracketed by HIP events: 0 none, 1 (default) the build kernels only, 2 also the reduced solve and the
+ * back-substitution.  An event on the stream costs ~5 us of idle GPU, so the per-phase breakdown is something to ask for
+ * (bench.py takes it in a second, untimed pass), not something every trial pays. */
+int mi_ba_set_timing_detail(mi_ba_engine *e, int level);
 
 /* ---- multi-GPU: one process per GPU, points sharded, RCCL all-reduce of the Schur partials */
 #define MI_BA_UNIQUE_ID_BYTES 128

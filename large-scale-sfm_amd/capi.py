@@ -35,7 +35,7 @@ class Config(C.Structure):
 class Timing(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("build_ms", "build_launches", "pcg_ms", "pcg_solves", "pcg_iters", "backsub_ms", "backsub_launches",
-                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes", "pcg_resumes", "build_flops")] + [("reserved", C.c_double * 3)]
+                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes", "pcg_resumes", "build_flops", "pcg_timed")] + [("reserved", C.c_double * 2)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -70,7 +70,7 @@ def lib() -> C.CDLL:
         vp, dp, ip, dbl, i32, i64 = C.c_void_p, _dp, _ip, C.c_double, C.c_int, C.c_int64
         sig = {
             "mi_ba_destroy": [vp], "mi_ba_cnp": [vp], "mi_ba_prepare": [vp], "mi_ba_begin": [vp], "mi_ba_step": [vp], "mi_ba_restart": [vp],
-            "mi_ba_reset_timing": [vp], "mi_ba_set_cameras": [vp, i32, dp, dp, dp], "mi_ba_set_points": [vp, i32, dp],
+            "mi_ba_reset_timing": [vp], "mi_ba_set_timing_detail": [vp, i32], "mi_ba_set_cameras": [vp, i32, dp, dp, dp], "mi_ba_set_points": [vp, i32, dp],
             "mi_ba_set_observations": [vp, i64, dp, ip, ip], "mi_ba_set_camera_constraints": [vp, dp, dp],
             "mi_ba_set_camera_links": [vp, C.c_int, ip, ip, dp],
             "mi_ba_comm_set_host_allreduce": [vp, HOST_ALLREDUCE, vp],
@@ -257,6 +257,10 @@ class Engine:
 
     def reset_timing(self):
         self.L.mi_ba_reset_timing(self.h)
+
+    def set_timing_detail(self, level: int):
+        """0 no HIP events, 1 (default) around the build kernels, 2 also around the reduced solve and the back-substitution"""
+        self.L.mi_ba_set_timing_detail(self.h, int(level))
 
 
 def comm_unique_id() -> bytes:

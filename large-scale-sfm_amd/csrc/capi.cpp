@@ -84,6 +84,7 @@ int mi_ba_debug_linearize(mi_ba_engine *h, double mu, double *S, double *E, doub
 int mi_ba_debug_solve(mi_ba_engine *h, double mu, double *da, double *db, double *cost_new)
 { return h ? h->e->debug_solve(mu, da, db, cost_new) : MI_BA_ERROR; }
 int mi_ba_get_timing(const mi_ba_engine *h, mi_ba_timing *t) { if (!h || !t) return MI_BA_ERROR; *t = h->e->timing; return 0; }
+int mi_ba_set_timing_detail(mi_ba_engine *h, int level) { if (!h) return MI_BA_ERROR; h->e->timing_detail = level; return 0; }
 int mi_ba_reset_timing(mi_ba_engine *h)
 {
     if (!h) return MI_BA_ERROR;

@@ -451,13 +451,13 @@ bool Engine::linear_phase(double mu, bool want_diag)
     a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc;
     a.dbg = d_dbg_.p; a.want_diag = want_diag ? 1 : 0;
     a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
-    (void)hipEventRecord(ev_[0], st_);
+    if (timing_detail >= 1) (void)hipEventRecord(ev_[0], st_);
     a.tile0 = 0;
     launch_build(st_, cnp, true, pl.ntile_lds, a);
     a.tile0 = pl.ntile_lds;
     launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
     launch_long_build(st_, cnp, long_args(mu, want_diag, nullptr, pl.ntile()));
-    (void)hipEventRecord(ev_[1], st_);
+    if (timing_detail >= 1) (void)hipEventRecord(ev_[1], st_);
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
@@ -506,7 +506,7 @@ bool Engine::solve_phase(double mu, double *dB_dev)
 {
     PcgArgs p = pcg_args();
     // (histories and partials need no reset: every slot a launch reads was written by an earlier launch of this solve)
-    (void)hipEventRecord(ev_[2], st_);
+    if (timing_detail >= 2) (void)hipEventRecord(ev_[2], st_);
     launch_pcg_init(st_, p);
     // the count grows geometrically from trial to trial while the damping falls by 1/3 (measured on C3: 9, 14, 20, 33, 54, 93,
     // then the cap): extrapolate the last ratio, with a margin -- an iteration too many costs 2 us, one too few a round trip
@@ -516,7 +516,7 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
     p.it = it0; p.last = it0 >= cfg.pcg_maxit; launch_pcg_tail(st_, p);
     launch_pcg_finish(st_, p);
-    (void)hipEventRecord(ev_[3], st_);
+    if (timing_detail >= 2) (void)hipEventRecord(ev_[3], st_);
     if (!update_phase(mu, dB_dev) || !read_scalars()) return false;
     if (h_scal_[SC_PCG_FINAL] == 0.0) { // the guess fell short
         timing.pcg_resumes += 1;
@@ -541,10 +541,10 @@ bool Engine::update_phase(double mu, double *dB_dev)
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
     b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, kBacksubGrid); b.cfg = mc; b.scal = scal_();
-    (void)hipEventRecord(ev_[4], st_);
+    if (timing_detail >= 2) (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, false, dB_dev, b.ngrid));
-    (void)hipEventRecord(ev_[5], st_);
+    if (timing_detail >= 2) (void)hipEventRecord(ev_[5], st_);
     launch_reduce_partials(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW, scal_() + SC_MAX_PCT);
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
@@ -598,9 +598,10 @@ int Engine::step()
     const double mu = mu_;
     if (!linear_phase(mu, false) || !solve_phase(mu, nullptr)) return MI_BA_ERROR;   // h_scal_ holds the trial's scalars
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) { timing.build_ms += ms; timing.build_launches += 1; }
-    if (hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) { timing.pcg_ms += ms; timing.pcg_solves += 1; }
-    if (hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) { timing.backsub_ms += ms; timing.backsub_launches += 1; }
+    if (timing_detail >= 1 && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) { timing.build_ms += ms; timing.build_launches += 1; }
+    if (timing_detail >= 2 && hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) { timing.pcg_ms += ms; timing.pcg_timed += 1; }
+    if (timing_detail >= 2 && hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) { timing.backsub_ms += ms; timing.backsub_launches += 1; }
+    timing.pcg_solves += 1;
     const double *s = h_scal_;
     timing.pcg_iters += s[SC_PCG_ITERS];
     // cost carried by the reference = residuals at p + the constraint penalty of the previous accepted iterate

@@ -6,6 +6,7 @@ capi = importlib.import_module("large-scale-sfm_amd.capi"); scene = importlib.im
 m, n, d = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 t0 = time.time(); sc = scene.make_scene("x", m=m, n=n, d=d, seed=5); t1 = time.time()
 eng = capi.Engine(capi.default_config(itmax=1 << 30, disable_stops=1))
+eng.set_timing_detail(2)
 eng.load_scene(sc); eng.prepare(); t2 = time.time()
 eng.begin(); r0 = np.sqrt(eng.info()[0] / sc.nobs)
 for _ in range(3): eng.step()

@@ -22,6 +22,7 @@ else:   # every point: d cameras drawn from a window of 3d neighbouring cameras
     sc.x = np.take_along_axis(sc.x.reshape(n, d, 2), order[:, :, None], 1).reshape(-1, 2)
 t1 = time.time()
 eng = capi.Engine(capi.default_config(itmax=1 << 30, disable_stops=1))
+eng.set_timing_detail(2)
 eng.load_scene(sc); eng.prepare(); t2 = time.time()
 st = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).stats()
 eng.begin(); r0 = np.sqrt(eng.info()[0] / sc.nobs)
