@@ -388,3 +388,36 @@ def test_mergeclusters_process_takes_the_best_candidate_and_refines(tmp_path, go
     # an index past the list does nothing; a missing directory is an error
     assert subprocess.run([exe, str(tmp_path), "7"], capture_output=True, text=True, timeout=60).returncode == 0
     assert subprocess.run([exe, str(tmp_path / "nowhere"), "0"], capture_output=True, text=True, timeout=60).returncode == 1
+
+
+@pytest.mark.gpu
+def test_config_c5_eight_clusters_through_the_stage_programs(tmp_path):
+    """BASELINE config C5 as the pipeline does it: 8 sub-reconstructions of one scene, each in its own similarity frame, fused
+    pairwise up the dendrogram by Merge3D3D (7 alignments on the GPU, 7 bundles by its optimizer_all children), then the merged
+    model refined once more with the points sharded over 3 ranks (MI_BA_GPUS; on this one-GPU box through the host transport)"""
+    L = merge_lib()
+    sc = vsfm_scene(m=160, n=12000, d=6, seed=55, strides=(1, 2, 3), cam_noise=0.002, pt_noise=0.004, f_noise=0.002)
+    rng = np.random.default_rng(8)
+    frames = [FRAMES[0]] + [(float(np.exp(rng.normal(0, 0.4))), rodrigues(rng.normal(0, 0.6, (1, 3)))[0], rng.normal(0, 2.0, 3)) for _ in range(7)]
+    cls = clusters_of(sc, [(20 * c, 20 * c + 20) for c in range(8)], frames, rng)
+    den = tmp_path / "dendogram"
+    for name, cl in zip("ABCDEFGH", cls):
+        (den / ("cluster" + name)).mkdir(parents=True)
+        write_cluster(str(den / ("cluster" + name) / "outputVSFM_GB.nvm"), cl)
+    (den / "fullclustermergeinfo.txt").write_text("I A B\nJ C D\nK E F\nL G H\nM I J\nN K L\nO M N\n")
+    exe = os.path.join(ROOT, "large-scale-sfm_amd", "bin", "Merge3D3D")
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert out.stdout.count("#Correspondences") == 7 and out.stdout.count("LM iterations") == 7
+    nvm = str(den / "clusterO" / "outputVSFM_GB.nvm")
+    h = L.mi_model_load_nvm(nvm.encode()); mdl = read_model(L, h); rmse1 = L.mi_model_rmse(h); L.mi_model_free(h)
+    assert len(mdl["f"]) == 160 and rmse1 < 0.25 and np.all(np.abs(mdl["f"] - 800) < 40)
+    names = [l.split()[1] for l in open(den / "clusterO" / "Invmap.txt").read().split("\n")[:160]]
+    assert sorted(names) == sorted("%d" % (500 + j) for j in range(160))
+    # the global refine on "the node": one process spawned as ever, three ranks behind it
+    opt = os.path.join(ROOT, "large-scale-sfm_amd", "bin", "optimizer_all")
+    out3 = subprocess.run([opt, str(den / "clusterO") + "/", "0", "100", "16", "32", "0", "0"], capture_output=True, text=True, timeout=600,
+                          env={**os.environ, "MI_BA_GPUS": "3", "MI_BA_TRANSPORT": "host"})
+    assert out3.returncode == 0 and "3 ranks" in out3.stdout, out3.stderr
+    h = L.mi_model_load_nvm(nvm.encode()); rmse2 = L.mi_model_rmse(h); L.mi_model_free(h)
+    assert rmse2 <= rmse1 + 1e-6 and rmse2 < 0.21
