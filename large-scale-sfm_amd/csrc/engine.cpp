@@ -315,7 +315,7 @@ int Engine::prepare()
         if (!hipok(d_cam_lin_[b].alloc((size_t)m_ * kCamLin), "alloc cam_lin")) return MI_BA_ERROR;
         if (!hipok(d_pts_[b].alloc(npl * 3), "alloc pts")) return MI_BA_ERROR;
     }
-    const size_t acc_n = (size_t)pl.nb_up() * 64 + (size_t)3 * m_ * kCP + kScalCount;
+    const size_t acc_n = 2 * nslot_() + (size_t)pl.nb_up() * 64 + (size_t)3 * m_ * kCP + kScalCount;
     if (!hipok(d_ptout_.alloc(npl * kPtOut), "alloc ptout") || !hipok(d_acc_.alloc(acc_n), "alloc acc") ||
         !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Linv_.alloc((size_t)m_ * 64), "alloc Linv") || !hipok(d_S_pcg_.alloc((size_t)pl.nb_full() * 64), "alloc S~") ||
         !hipok(d_E_.alloc((size_t)m_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)m_ * kCP), "alloc dA") ||
@@ -406,8 +406,9 @@ bool Engine::allreduce1()
 {
     if (!comm_ && !host_ar_) return true;
     double t0 = now_ms();
-    const size_t nsum = (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP + 8;
-    if (!exchange(d_acc_.p, nsum, 0) || !exchange(scal_() + 8, 8, 1)) return false;
+    const size_t nsum = nslot_() + (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP + 8;   // slots1, S_up, camvec, scal[0, 8)
+    if (!exchange(d_acc_.p, nsum, 0)) return false;
+    if (cfg.world > 1) launch_fold_max(st_, slots1_(), cfg.world, scal_() + 8);
     timing.allreduce_ms += now_ms() - t0; timing.allreduces += 1;
     return true;
 }
@@ -415,7 +416,9 @@ bool Engine::allreduce1()
 bool Engine::allreduce2()
 {
     if (!comm_ && !host_ar_) return true;
-    return exchange(scal_() + 32, 8, 0) && exchange(scal_() + 40, 8, 1);
+    if (!exchange(scal_() + 32, 16 + nslot_(), 0)) return false;                              // scal[32, 48), slots2
+    if (cfg.world > 1) launch_fold_max(st_, slots2_(), cfg.world, scal_() + 40);
+    return true;
 }
 
 LongArgs Engine::long_args(double mu, bool want_diag, double *dB_dev, int part_row0)
@@ -458,7 +461,8 @@ bool Engine::linear_phase(double mu, bool want_diag)
     launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
     launch_long_build(st_, cnp, long_args(mu, want_diag, nullptr, pl.ntile()));
     if (timing_detail >= 1) (void)hipEventRecord(ev_[1], st_);
-    launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
+    launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST,
+                           cfg.world > 1 ? slots1_() + (size_t)cfg.rank * 8 : scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
@@ -545,7 +549,8 @@ bool Engine::update_phase(double mu, double *dB_dev)
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, false, dB_dev, b.ngrid));
     if (timing_detail >= 2) (void)hipEventRecord(ev_[5], st_);
-    launch_reduce_partials(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW, scal_() + SC_MAX_PCT);
+    launch_reduce_partials(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
+                           cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT);
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }

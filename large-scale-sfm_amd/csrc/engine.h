@@ -135,9 +135,15 @@ private:
     int cur_ = 0; // index of the current estimate in the [2] buffers
     bool cam_lin_valid_ = false; // d_cam_lin_[cur_] holds the records of d_cam_a_[cur_]
     double *h_scal_ = nullptr; // pinned, kScalCount
-    double *S_up_() { return d_acc_.p; }
-    double *camvec_() { return d_acc_.p + (size_t)plan_.nb_up() * 64; }
-    double *scal_() { return d_acc_.p + (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP; }
+    // d_acc_ = [slots1 | S_up | camvec | scal | slots2].  With several ranks the maxima travel inside the SUM all-reduces:
+    // every rank puts its 8 maxima into its own slot of a world x 8 block of zeros next to the summed range, and
+    // k_fold_max takes the maximum over the slots afterwards -- one collective per exchange instead of two.
+    size_t nslot_() const { return cfg.world > 1 ? (size_t)cfg.world * 8 : 0; }
+    double *slots1_() { return d_acc_.p; }
+    double *S_up_() { return d_acc_.p + nslot_(); }
+    double *camvec_() { return S_up_() + (size_t)plan_.nb_up() * 64; }
+    double *scal_() { return camvec_() + (size_t)3 * m_ * kCP; }
+    double *slots2_() { return scal_() + kScalCount; }
 
     // LM state (names follow sba_levmar.c:596-613)
     double mu_ = 0, p_eL2_ = 0, init_p_eL2_ = 0, eab_inf_ = 0, dp_L2_ = 0, p_L2_ = 0, maxdiag_ = 0;

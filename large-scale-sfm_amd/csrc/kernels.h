@@ -131,6 +131,7 @@ void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one l
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . M^-1 r_it
 void launch_pcg_finish(hipStream_t st, const PcgArgs &a); // da = Linv^T x~
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max);
+void launch_fold_max(hipStream_t st, double *slots, int world, double *out8); // out8[c] = max over the ranks' slots, which are zeroed
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
                        const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
                        double *cam_lin_new, double *cam_part, double *stage, double *scal);

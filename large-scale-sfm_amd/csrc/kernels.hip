@@ -1627,6 +1627,19 @@ void launch_pcg_finish(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_
 
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_tail, dim3(1), dim3(64), 0, st, a); }
 
+// after a SUM all-reduce over a block of world x 8 slots in which every rank had filled only its own: the maximum over the
+// ranks (the values are norms and flags, >= 0); the slots are cleared for the next use
+__global__ void k_fold_max(double *__restrict__ slots, int world, double *__restrict__ out8)
+{
+    const int c = threadIdx.x;
+    if (c >= 8) return;
+    double v = 0.0;
+    for (int r = 0; r < world; ++r) { v = fmax(v, slots[r * 8 + c]); slots[r * 8 + c] = 0.0; }
+    out8[c] = v;
+}
+
+void launch_fold_max(hipStream_t st, double *slots, int world, double *out8) { hipLaunchKernelGGL(k_fold_max, dim3(1), dim3(64), 0, st, slots, world, out8); }
+
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max)
 {
     if (nrows > 4096) { // two stages: kReduceStage workgroups, then one

@@ -22,6 +22,9 @@ def _case(kind):
     if kind == "long":
         from helpers import ladybug_like_scene
         return ladybug_like_scene(m=120, n=3000, dmax=90, seed=9), {}, lambda eng: None
+    if kind == "resume":   # every trial's first run of CG iterations falls short (engine.cpp solve_phase): the update phase -- and with
+        os.environ["MI_BA_PCG_FIRST_RUN"] = "2"   # it the second exchange and its per-rank maxima slots -- runs twice per trial
+        return scene.make_scene("x", m=40, n=6000, d=6, seed=77), {}, lambda eng: None
     if kind == "extras":   # radial coefficient, links between cameras, soft constraints on cameras and points: the camera-side
         sc = scene.make_scene("x", m=40, n=6000, d=6, seed=78, undistort=1, nk=1)   # terms are replicated, the point-side sharded
         rng = np.random.default_rng(4)
@@ -65,7 +68,7 @@ def _worker(rank, world, port, outdir, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "plain"), (3, "long"), (2, "extras")])
+@pytest.mark.parametrize("world,kind", [(2, "plain"), (3, "long"), (2, "extras"), (2, "resume")])
 def test_ranks_sharing_one_gpu_reproduce_the_single_rank_solve(tmp_path, world, kind):
     import torch.multiprocessing as mp
     from conftest import pkg
@@ -79,6 +82,7 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_rank_solve(tmp_path, world, 
     # and it is the single-rank answer (the partial sums are added in another order: rounding-level differences)
     capi = pkg("capi")
     sc, kw, extras = _case(kind)
+    os.environ.pop("MI_BA_PCG_FIRST_RUN", None)          # the single-rank solve it is compared with runs as usual
     eng = capi.Engine(capi.default_config(pcg_tol=1e-12, pcg_maxit=400, mcon=1, **kw))
     eng.load_scene(sc); extras(eng); eng.prepare()
     ret, info = eng.run()
