@@ -183,6 +183,7 @@ def main():
             "rmse_px": {"initial": rmse0, "after_timed_steps": rmse_after, "final_of_last_completed_solve": done["rmse"]},
             "accepted_steps": int(done["accepted"]), "completed_solves": done["solves"], "lm_iterations_of_last_completed_solve": done["iters"],
             "pcg_iters_per_step": tm["pcg_iters"] / max(tm["pcg_solves"], 1), "pcg_resumes": int(tm["pcg_resumes"]),
+            "trials_linearised_ahead": int(tm["spec_adopted"]),
             "kernel_ms_per_step": {"build": build_ms, "pcg": tm2["pcg_ms"] / max(tm2["pcg_timed"], 1),
                                    "backsub": tm2["backsub_ms"] / max(tm2["backsub_launches"], 1),
                                    "note": "build: HIP events in the timed steps; pcg, backsub: the same trials repeated untimed with events around them",

@@ -155,7 +155,8 @@ typedef struct {
     double build_flops;                    /* algorithmic f64 flops of one build launch: 400 per observation (residual, Jacobian,
                                             * V / e_b / E terms), 2 x 138 per pair block, 120 per point (3x3 inverse, h) */
     double pcg_timed;                      /* solves that pcg_ms covers (mi_ba_set_timing_detail >= 2) */
-    double reserved[2];
+    double spec_adopted;                   /* trials whose linear phase had been enqueued behind the previous trial (engine.cpp solve_phase) */
+    double reserved[1];
 } mi_ba_timing;
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_reset_timing(mi_ba_engine *e);

@@ -50,6 +50,7 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
     if (!hipok(hipSetDevice(cfg.device), "hipSetDevice")) return;
     if (!hipok(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking), "hipStreamCreate")) return;
     for (auto &ev : ev_) if (!hipok(hipEventCreate(&ev), "hipEventCreate")) return;
+    speculate_ = std::getenv("MI_BA_NO_SPECULATION") == nullptr;
     if (!hipok(hipHostMalloc((void **)&h_scal_, sizeof(double) * 1024, hipHostMallocDefault), "hipHostMalloc")) return;
     created_ = true;
 }
@@ -327,6 +328,7 @@ int Engine::prepare()
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (!hipok(hipMemset(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double)), "memset rz/pq")) return MI_BA_ERROR;
+    if (!hipok(d_spec_.alloc(2), "alloc spec") || !hipok(hipMemset(d_spec_.p, 0, 2 * sizeof(double)), "memset spec")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
     if (std::getenv("MI_BA_STAMPS")) {
         if (!hipok(d_dbg_.alloc(8), "alloc dbg") || !hipok(hipMemset(d_dbg_.p, 0, 64), "memset dbg")) return MI_BA_ERROR;
@@ -436,7 +438,7 @@ LongArgs Engine::long_args(double mu, bool want_diag, double *dB_dev, int part_r
 }
 
 // linearise at the current estimate with damping mu and build the reduced camera system
-bool Engine::linear_phase(double mu, bool want_diag)
+bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
 {
     const Plan &pl = plan_;
     const ModelCfg mc = model();
@@ -451,20 +453,25 @@ bool Engine::linear_phase(double mu, bool want_diag)
     a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p; a.cam_fixed = d_fixed_.p;
     a.pair = d_pair_.p; a.pair_gblk = d_pair_gblk_.p; a.pair_gblk_base = pl.npair_lds;
     a.m = m_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
-    a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc;
+    a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc; a.spec = spec;
     a.dbg = d_dbg_.p; a.want_diag = want_diag ? 1 : 0;
     a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
-    if (timing_detail >= 1) (void)hipEventRecord(ev_[0], st_);
+    lin_pair_ = (lin_count_++ & 1) ? 6 : 0;
+    if (timing_detail >= 1) (void)hipEventRecord(ev_[lin_pair_], st_);
     a.tile0 = 0;
     launch_build(st_, cnp, true, pl.ntile_lds, a);
     a.tile0 = pl.ntile_lds;
     launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
-    launch_long_build(st_, cnp, long_args(mu, want_diag, nullptr, pl.ntile()));
-    if (timing_detail >= 1) (void)hipEventRecord(ev_[1], st_);
+    {
+        LongArgs la = long_args(mu, want_diag, nullptr, pl.ntile());
+        la.spec = spec;
+        launch_long_build(st_, cnp, la);
+    }
+    if (timing_detail >= 1) (void)hipEventRecord(ev_[lin_pair_ + 1], st_);
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST,
                            cfg.world > 1 ? slots1_() + (size_t)cfg.rank * 8 : scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
-    launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
+    launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
                     d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p);
     return hipok(hipGetLastError(), "launch (linear phase)");
@@ -506,7 +513,7 @@ bool Engine::pcg_chunks(int it0)
 // camera update and the back-substitution, which look at SC_PCG_FINAL themselves: when the guess fell short (the flag is
 // still down) the back-substitution does nothing, and the host, which sees the flag with the trial's scalars, continues the
 // iterations in checked chunks and launches the update phase again.
-bool Engine::solve_phase(double mu, double *dB_dev)
+bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
 {
     PcgArgs p = pcg_args();
     // (histories and partials need no reset: every slot a launch reads was written by an earlier launch of this solve)
@@ -521,9 +528,35 @@ bool Engine::solve_phase(double mu, double *dB_dev)
     p.it = it0; p.last = it0 >= cfg.pcg_maxit; launch_pcg_tail(st_, p);
     launch_pcg_finish(st_, p);
     if (timing_detail >= 2) (void)hipEventRecord(ev_[3], st_);
-    if (!update_phase(mu, dB_dev) || !read_scalars()) return false;
+    if (!update_phase(mu, dB_dev)) return false;
+    spec_enqueued_ = false;
+    if (may_speculate && speculate_) {
+        // The host needs this trial's scalars to decide (accept? which damping next? stop?), and until it has decided the GPU
+        // would idle: ~35 us per trial, a fifth of a trial on a 20-camera scene.  So the common decision is taken on the
+        // device as well (k_lm_peek: the controller's accept test and damping update, operation for operation) and the
+        // next trial's linear phase is enqueued behind it at once, reading its damping from HBM; the host waits only for the
+        // copy of the scalars, runs the controller as ever, and adopts what was built when its own decision -- accepted,
+        // no stop, the same damping bit for bit -- is the one the device acted on.  Otherwise (rejected: k_build saw the
+        // flag and did nothing; stopped; a reduced solve that needs more iterations) it linearises again as before.
+        launch_lm_peek(st_, scal_(), c_lag_, mu, d_spec_.p);
+        if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
+        (void)hipEventRecord(ev_[8], st_);
+        cur_ ^= 1;                                   // the trial point, where an accepted trial continues
+        const bool ok = linear_phase(0.0, false, d_spec_.p);
+        cur_ ^= 1;
+        spec_pair_ = lin_pair_;
+        if (!ok) return false;
+        spec_enqueued_ = true;
+        if (!hipok(hipEventSynchronize(ev_[8]), "sync (scalars)")) return false;
+    } else if (!read_scalars()) return false;
     if (h_scal_[SC_PCG_FINAL] == 0.0) { // the guess fell short
         timing.pcg_resumes += 1;
+        if (spec_enqueued_) {           // the linear phase enqueued behind it has overwritten this trial's system: build it again
+            spec_enqueued_ = false;
+            if (!linear_phase(mu, false)) return false;
+            launch_pcg_init(st_, p);
+            it0 = 0;
+        }
         if (!pcg_chunks(it0)) return false;
         launch_pcg_finish(st_, p);
         if (!update_phase(mu, dB_dev) || !read_scalars()) return false;
@@ -566,6 +599,7 @@ int Engine::begin()
     if (!prepared_) { err = "begin: prepare first"; return MI_BA_ERROR; }
     mu_ = 0; nu_ = 2; itno_ = 0; stop_ = 0; nfev_ = 1; njev_ = 0; nlss_ = 0; dp_L2_ = DBL_MAX; new_outer_ = true;
     pcg_pred_ = pcg_pred_prev_ = 0;      // a new solve: nothing to extrapolate from
+    spec_ready_ = spec_enqueued_ = false;
     trace.clear();
     // probe pass: cost at p0 and the largest diagonal entry of U, V -> mu0 = tau * max (sba_levmar.c:1124-1128)
     if (!linear_phase(1.0, true) || !read_scalars()) return MI_BA_ERROR;
@@ -601,9 +635,12 @@ int Engine::step()
     const bool stops = !cfg.disable_stops;
     if (new_outer_) { ++njev_; new_outer_ = false; }
     const double mu = mu_;
-    if (!linear_phase(mu, false) || !solve_phase(mu, nullptr)) return MI_BA_ERROR;   // h_scal_ holds the trial's scalars
+    int pair = spec_pair_;
+    if (spec_ready_) { spec_ready_ = false; timing.spec_adopted += 1; }   // this trial's linear phase was enqueued behind the previous trial (solve_phase)
+    else { if (!linear_phase(mu, false)) return MI_BA_ERROR; pair = lin_pair_; }
+    if (!solve_phase(mu, nullptr, true)) return MI_BA_ERROR;   // h_scal_ holds the trial's scalars
     float ms = 0;
-    if (timing_detail >= 1 && hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) { timing.build_ms += ms; timing.build_launches += 1; }
+    if (timing_detail >= 1 && hipEventElapsedTime(&ms, ev_[pair], ev_[pair + 1]) == hipSuccess) { timing.build_ms += ms; timing.build_launches += 1; }
     if (timing_detail >= 2 && hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) { timing.pcg_ms += ms; timing.pcg_timed += 1; }
     if (timing_detail >= 2 && hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) { timing.backsub_ms += ms; timing.backsub_launches += 1; }
     timing.pcg_solves += 1;
@@ -661,6 +698,8 @@ int Engine::step()
                 if (!discard) { accept_trial(); p_eL2_ = pdp_eL2; c_lag_ = c_cur; }
                 end_outer();
                 ret = stop_ ? 2 : 1;
+                // the linear phase enqueued behind this trial is the next trial's if the device acted on this very decision
+                spec_ready_ = ret == 1 && spec_enqueued_ && s[SC_SPEC_GO] == 1.0 && s[SC_SPEC_MU] == mu_;
                 break;
             }
             push_trace(pdp_eL2, 0);
@@ -751,6 +790,7 @@ int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double 
 {
     if (!prepared_) { err = "debug_linearize: prepare first"; return MI_BA_ERROR; }
     if (cfg.world > 1 && (eb || V)) { err = "debug_linearize: point outputs need world == 1"; return MI_BA_ERROR; }
+    spec_ready_ = false;   // whatever was enqueued for the next trial is overwritten here
     if (!linear_phase(mu, true) || !read_scalars()) return MI_BA_ERROR;
     const Plan &pl = plan_;
     if (cost) *cost = h_scal_[SC_COST];
@@ -806,6 +846,7 @@ int Engine::debug_solve(double mu, double *da, double *db, double *cost_new)
 {
     if (!prepared_) { err = "debug_solve: prepare first"; return MI_BA_ERROR; }
     if (cfg.world > 1 && db) { err = "debug_solve: point outputs need world == 1"; return MI_BA_ERROR; }
+    spec_ready_ = false;
     if (!solve_phase(mu, d_dB_.p)) return MI_BA_ERROR;
     const Plan &pl = plan_;
     if (cost_new) *cost_new = h_scal_[SC_COST_NEW];

@@ -75,8 +75,8 @@ public:
 private:
     bool fail(const std::string &msg) { err = msg; return false; }
     bool hipok(hipError_t e, const char *what);
-    bool linear_phase(double mu, bool want_diag);                 // cam_prep .. build .. all-reduce .. finalize .. block_inv
-    bool solve_phase(double mu, double *dB_dev);  // pcg .. cam_update .. backsub .. all-reduce
+    bool linear_phase(double mu, bool want_diag, const double *spec = nullptr); // cam_prep .. build .. all-reduce .. finalize .. block_inv
+    bool solve_phase(double mu, double *dB_dev, bool may_speculate = false);    // pcg .. cam_update .. backsub .. all-reduce .. scalars on the host
     bool update_phase(double mu, double *dB_dev);
     bool pcg_chunks(int it0);
     PcgArgs pcg_args();
@@ -90,7 +90,11 @@ private:
 
     bool created_ = false, prepared_ = false, begun_ = false;
     hipStream_t st_ = nullptr;
-    hipEvent_t ev_[8] = {};
+    hipEvent_t ev_[10] = {};      // build bracket: [0],[1] and [6],[7] alternate from one linear phase to the next (the next trial's
+                                  // may be enqueued before this trial's is read); [2..5] reduced solve, back-substitution; [8] scalars copied
+    int lin_count_ = 0, lin_pair_ = 0, spec_pair_ = 0;
+    // the next trial's linear phase enqueued before the host has seen this trial's outcome (solve_phase)
+    bool speculate_ = true, spec_enqueued_ = false, spec_ready_ = false;
     void *comm_ = nullptr; // ncclComm_t
     mi_ba_host_allreduce_fn host_ar_ = nullptr;   // test transport: the exchange through a host callback instead of RCCL
     void *host_ar_user_ = nullptr;
@@ -131,7 +135,7 @@ private:
     DevBuf<double2> d_obs_xy_;
     // device: state
     DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_S_pcg_, d_Linv_, d_E_, d_dA_, d_dB_,
-        d_pcg_, d_rzpq_, d_full_pts_, d_part_, d_stage_;
+        d_pcg_, d_rzpq_, d_full_pts_, d_part_, d_stage_, d_spec_;
     int cur_ = 0; // index of the current estimate in the [2] buffers
     bool cam_lin_valid_ = false; // d_cam_lin_[cur_] holds the records of d_cam_a_[cur_]
     double *h_scal_ = nullptr; // pinned, kScalCount

@@ -36,6 +36,7 @@ enum Scal {
     SC_COST = 0, SC_PL2_PTS = 1, SC_CONS_PTS = 2,   // CONS_PTS: soft point-constraint penalty at p
     // [8,16) k_build maxima                                            (all-reduce #1, MAX)
     SC_EB_INF = 8, SC_MAXDIAG_V = 9, SC_SINGULAR = 10,
+    SC_SPEC_GO = 13, SC_SPEC_MU = 14,   // k_lm_peek's verdict, copied here so that it travels to the host with the rest
     SC_PCG_FINAL = 12,   // (not a maximum: zero through all-reduce #1, set by k_pcg_tail afterwards) the solve is over: converged,
                          // broken down or out of iterations -- what the back-substitution waits for
     // [16,32) camera-side values, computed redundantly on every rank: every sum is folded in a FIXED order
@@ -77,6 +78,7 @@ struct BuildArgs {
     const double *cam_lin, *pts;
     const double *pt_cw, *pt_cv;            // soft point constraints (weight already x nvis), internal order; NULL = none
     double mu;
+    const double *spec;                     // speculative launch (engine.cpp solve_phase): spec[0] == 0 -> do nothing, else mu = spec[1]; nullptr: mu above
     unsigned long long *dbg;                // diagnostic stamp sums (MIBA_STAMPS build), else NULL
     double *S_up, *camvec, *ptout, *part;   // part: [ntile][kPartW] cost, |X|^2, -, -, |eb|inf, max diag V, singular
     ModelCfg cfg;
@@ -106,6 +108,7 @@ struct LongArgs {
     int nlong, m, want_diag, part_row0;
     ModelCfg cfg;
     const double *scal;
+    const double *spec;                     // as in BuildArgs (the linear-phase kernels)
 };
 
 struct PcgArgs {
@@ -122,7 +125,7 @@ struct PcgArgs {
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
                      const double *f_fixed, double *cam_lin);
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);
-void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const int *bsr_rowidx, const int *bsr_col,
+void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const double *spec, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full /* or nullptr */,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg);
@@ -131,7 +134,10 @@ void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one l
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . M^-1 r_it
 void launch_pcg_finish(hipStream_t st, const PcgArgs &a); // da = Linv^T x~
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max);
-void launch_fold_max(hipStream_t st, double *slots, int world, double *out8); // out8[c] = max over the ranks' slots, which are zeroed
+void launch_fold_max(hipStream_t st, double *slots, int world, double *out8);
+// the LM controller's accept test and damping update on the device (sba_levmar.c:1543-1552), from the trial's scalars:
+// spec[0] = 1 when the trial will be accepted, spec[1] = the damping of the next trial
+void launch_lm_peek(hipStream_t st, double *scal, double c_lag, double mu, double *spec); // out8[c] = max over the ranks' slots, which are zeroed
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
                        const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
                        double *cam_lin_new, double *cam_part, double *stage, double *scal);

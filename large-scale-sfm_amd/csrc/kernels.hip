@@ -416,6 +416,8 @@ template <int CNP, bool LDS, bool FULL, bool TABLE>
 __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_build(const BuildArgs g) // 8x8 blocks: 128 accumulator VGPRs, one wave per SIMD
 {
     if constexpr (LDS) { if (g.tile_mode[g.tile0 + blockIdx.x] != (TABLE ? 2 : 1)) return; }
+    if (g.spec && g.spec[0] == 0.0) return;   // enqueued ahead of the host's decision, and the trial was not accepted
+    const double mu_lin = g.spec ? g.spec[1] : g.mu;
 #ifdef MIBA_STAMPS
     unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
             }
             maxdv = fmax(maxdv, fmax(v00, fmax(v11, v22)));
             ebinf = fmax(ebinf, fmax(fabs(eb0), fmax(fabs(eb1), fabs(eb2))));
-            v00 += g.mu; v11 += g.mu; v22 += g.mu;
+            v00 += mu_lin; v11 += mu_lin; v22 += mu_lin;
             const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
             const double det = v00 * c00 + v01 * c01 + v02 * c02;
             double i00 = 0, i01 = 0, i02 = 0, i11 = 0, i12 = 0, i22 = 0;
@@ -768,6 +770,8 @@ template <int CNP>
 __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
 {
     __shared__ double sh[4], sVh[9];
+    if (g.spec && g.spec[0] == 0.0) return;
+    const double mu_lin = g.spec ? g.spec[1] : g.mu;
     const int l = blockIdx.x, ip = g.long_pts[l], tid = threadIdx.x;
     const int os = g.pt_obs[ip], oe = g.pt_obs[ip + 1];
     const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
         }
         double v00 = v[0], v01 = v[1], v02 = v[2], v11 = v[3], v12 = v[4], v22 = v[5];
         const double maxdv = fmax(v00, fmax(v11, v22)), ebinf = fmax(fabs(v[6]), fmax(fabs(v[7]), fabs(v[8])));
-        v00 += g.mu; v11 += g.mu; v22 += g.mu;
+        v00 += mu_lin; v11 += mu_lin; v22 += mu_lin;
         const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
         const double det = v00 * c00 + v01 * c01 + v02 * c02;
         double inv[6] = { 0, 0, 0, 0, 0, 0 }, sing = 0.0;
@@ -857,6 +861,7 @@ __global__ __launch_bounds__(256) void k_long_pairs(const LongArgs g)
     // 64 different blocks was measured ~6x slower)
     constexpr int BLK = CNP * CNP, kStage = 8;
     __shared__ double sStage[4][kStage * BLK];
+    if (g.spec && g.spec[0] == 0.0) return;
     const int l = blockIdx.y, ip = g.long_pts[l], lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int os = g.pt_obs[ip], d = g.pt_obs[ip + 1] - os;
     const long long np = (long long)d * (d + 1) / 2, t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1021,6 +1026,7 @@ struct FinalizeArgs {
     const unsigned char *fixed, *trans, *pfix;      // pfix[j] bit r: parameter r of camera j is held constant
     const int *rowidx, *col, *src;
     const double *S_up, *cam_cw;
+    const double *spec;                             // speculative launch: the damping is spec[1]
     CamLinks lk;
 };
 
@@ -1033,7 +1039,7 @@ __device__ __forceinline__ double finalized_element(const FinalizeArgs &f, int b
         v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
         if (r == c && r < f.cnp && f.lk.row)                           // shared-intrinsics links: U_jj += sum w
             for (int q = f.lk.row[j]; q < f.lk.row[j + 1]; ++q) v += f.lk.w[(size_t)q * kCP + r];
-        if (r == c) v = (r < f.cnp) ? v + f.mu + f.cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
+        if (r == c) v = (r < f.cnp) ? v + (f.spec ? f.spec[1] : f.mu) + f.cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
         if (f.fixed[j]) v = (r == c) ? 1.0 : 0.0;
     } else {
         v = f.trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
@@ -1593,13 +1599,13 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 
 // camera-side finish of the linearisation: right-hand side and norms, L^-1 of the diagonal blocks, the scaled matrix; the
 // full unscaled matrix only when S_full != nullptr (parity hooks)
-void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const int *bsr_rowidx, const int *bsr_col,
+void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const double *spec, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg)
 {
     FinalizeArgs f;
-    f.cnp = cnp; f.mu = mu; f.fixed = fixed; f.pfix = pfix; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
+    f.cnp = cnp; f.mu = mu; f.spec = spec; f.fixed = fixed; f.pfix = pfix; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
     f.S_up = S_up; f.cam_cw = cam_cw; f.lk = links;
     const long long total = (long long)nb * 64;
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
@@ -1637,6 +1643,32 @@ __global__ void k_fold_max(double *__restrict__ slots, int world, double *__rest
     for (int r = 0; r < world; ++r) { v = fmax(v, slots[r * 8 + c]); slots[r * 8 + c] = 0.0; }
     out8[c] = v;
 }
+
+// The accept test and the damping update of the LM controller (engine.cpp step(); sba_levmar.c:1498-1552) on the trial's
+// scalars, with the host's expressions operation for operation (no contraction: the host compares its own damping with
+// spec[1] bit for bit before it uses what was built with it).
+#pragma clang fp contract(off)
+__global__ void k_lm_peek(double *__restrict__ s, double c_lag, double mu, double *__restrict__ spec)
+{
+    if (threadIdx.x != 0) return;
+    const double c_cur = s[SC_CONS_CAM] + s[SC_CONS_PTS];
+    const double p_eL2 = s[SC_COST] + c_lag + s[SC_LINK];
+    const double pdp_eL2 = s[SC_COST_NEW] + c_cur + s[SC_LINK_NEW];
+    const double dL = s[SC_DL_CAMS] + s[SC_DL_PTS], dF = p_eL2 - pdp_eL2;
+    const bool solved = s[SC_PCG_FINAL] != 0.0 && s[SC_PCG_STATUS] == 0.0 && s[SC_NOT_PD] == 0.0 && s[SC_SINGULAR] == 0.0;
+    double go = 0.0, mu_next = mu;
+    if (solved && isfinite(pdp_eL2) && dL > 0.0 && dF > 0.0) {
+        double tmp = 2.0 * dF / dL - 1.0;
+        tmp = 1.0 - tmp * tmp * tmp;
+        mu_next = mu * ((tmp >= 0.3333333334) ? tmp : 0.3333333334);
+        go = 1.0;
+    }
+    spec[0] = go; spec[1] = mu_next;
+    s[SC_SPEC_GO] = go; s[SC_SPEC_MU] = mu_next;
+}
+#pragma clang fp contract(fast)
+
+void launch_lm_peek(hipStream_t st, double *scal, double c_lag, double mu, double *spec) { hipLaunchKernelGGL(k_lm_peek, dim3(1), dim3(64), 0, st, scal, c_lag, mu, spec); }
 
 void launch_fold_max(hipStream_t st, double *slots, int world, double *out8) { hipLaunchKernelGGL(k_fold_max, dim3(1), dim3(64), 0, st, slots, world, out8); }
 

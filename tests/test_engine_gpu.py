@@ -488,6 +488,43 @@ def test_a_short_first_run_of_the_reduced_solve_resumes_to_the_same_answer(monke
     assert np.allclose(tr1[:, 1:4], tr0[:, 1:4], rtol=1e-9, atol=0) and np.abs(eng.packed_params() - p0).max() < 1e-9
 
 
+@pytest.mark.parametrize("name", ["C1", "C1t"])
+def test_linearising_ahead_of_the_host_changes_nothing(monkeypatch, name):
+    """the next trial's linear phase is enqueued behind the current trial with the accept decision and the damping taken on the
+    device (k_lm_peek), and adopted when the host's own controller decides the same, bit for bit; with MI_BA_NO_SPECULATION the
+    host linearises after it has decided.  Same decisions, same damping sequence, same answer.  A second start -- far off, next
+    to no damping, tolerances at rounding level -- ends in a tail of rejected trials whose length is not reproducible from run
+    to run in either mode (floating-point atomics), so there only the common prefix and the minimum are compared"""
+    sc, z = scene_from_golden(name)
+    rng = np.random.default_rng(2)
+    p_far = sc.p0.copy()
+    p_far[sc.m * sc.cnp:] += rng.normal(0, 0.5, sc.n * 3)
+    far_opts = (1e-12, 1e-12, 1e-12, 1e-12, 0.0, 0.0)
+    out = {}
+    for mode in ("ahead", "behind"):
+        if mode == "behind":
+            monkeypatch.setenv("MI_BA_NO_SPECULATION", "1")
+        res = []
+        for p0 in (None, p_far):
+            eng = make_engine(sc, pcg_tol=1e-10, pcg_maxit=200, **({} if p0 is None else dict(opts=far_opts, itmax=40)))
+            if p0 is not None:
+                m, cnp = sc.m, sc.cnp
+                eng.set_params(p0[:m * cnp].reshape(m, cnp), p0[m * cnp:].reshape(sc.n, 3))
+            ret, info = eng.run()
+            res.append((ret, info, eng.trace(), eng.packed_params(), eng.timing()["spec_adopted"]))
+            eng.close()
+        out[mode] = res
+    (r1, i1, t1, p1, a1), (r0, i0, t0, p0_, a0) = out["ahead"][0], out["behind"][0]
+    assert a0 == 0 and a1 >= 0.6 * r1                                     # most trials were linearised ahead
+    assert r1 == r0 and np.array_equal(i1[5:], i0[5:]) and np.allclose(i1[:5], i0[:5], rtol=1e-5, atol=0)
+    assert t1.shape == t0.shape and np.array_equal(t1[:, [0, 4]], t0[:, [0, 4]]) and np.allclose(t1[:, 1:4], t0[:, 1:4], rtol=1e-8, atol=0)
+    assert np.abs(p1 - p0_).max() < 1e-8
+    (r1, i1, t1, p1, a1), (r0, i0, t0, p0_, a0) = out["ahead"][1], out["behind"][1]
+    assert a0 == 0 and a1 >= 3
+    assert np.array_equal(t1[:5, [0, 4]], t0[:5, [0, 4]]) and np.allclose(t1[:5, 1:4], t0[:5, 1:4], rtol=1e-5, atol=0)    # ill-conditioned: the trial costs agree to ~1e-7
+    assert abs(i1[1] - i0[1]) < 1e-9 * i0[1] and abs(np.sqrt(i1[1] / sc.nobs) - np.sqrt(z["info_final"][1] / sc.nobs)) < 1e-6
+
+
 def test_error_paths():
     capi = pkg("capi")
     sc, _ = scene_from_golden("micro")
