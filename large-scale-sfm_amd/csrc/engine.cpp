@@ -324,7 +324,8 @@ int Engine::prepare()
         !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)m_), "alloc rz/pq") ||
         !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGrid) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
         !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage") ||
-        !hipok(d_cam_part_.alloc((size_t)((m_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials"))
+        !hipok(d_cam_part_.alloc((size_t)((m_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
+        !hipok(d_cam_part2_.alloc((size_t)((m_ + 63) / 64 + 1) * kPartW), "alloc camera partials"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (!hipok(hipMemset(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double)), "memset rz/pq")) return MI_BA_ERROR;
@@ -473,7 +474,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
-                    d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p);
+                    d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag);   // want_diag: a linear phase on its own (begin, parity hooks)
     return hipok(hipGetLastError(), "launch (linear phase)");
 }
 
@@ -528,9 +529,10 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
     p.it = it0; p.last = it0 >= cfg.pcg_maxit; launch_pcg_tail(st_, p);
     launch_pcg_finish(st_, p);
     if (timing_detail >= 2) (void)hipEventRecord(ev_[3], st_);
-    if (!update_phase(mu, dB_dev)) return false;
+    const bool spec = may_speculate && speculate_;
+    if (!update_phase(mu, dB_dev, spec && cfg.world == 1)) return false;
     spec_enqueued_ = false;
-    if (may_speculate && speculate_) {
+    if (spec) {
         // The host needs this trial's scalars to decide (accept? which damping next? stop?), and until it has decided the GPU
         // would idle: ~35 us per trial, a fifth of a trial on a 20-camera scene.  So the common decision is taken on the
         // device as well (k_lm_peek: the controller's accept test and damping update, operation for operation) and the
@@ -538,7 +540,7 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
         // copy of the scalars, runs the controller as ever, and adopts what was built when its own decision -- accepted,
         // no stop, the same damping bit for bit -- is the one the device acted on.  Otherwise (rejected: k_build saw the
         // flag and did nothing; stopped; a reduced solve that needs more iterations) it linearises again as before.
-        launch_lm_peek(st_, scal_(), c_lag_, mu, d_spec_.p);
+        if (cfg.world > 1) launch_lm_peek(st_, scal_(), c_lag_, mu, d_spec_.p);   // after the exchange; on one rank k_reduce_final has done it
         if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
         (void)hipEventRecord(ev_[8], st_);
         cur_ ^= 1;                                   // the trial point, where an accepted trial continues
@@ -567,12 +569,12 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
 }
 
 // camera update, back-substitution, cost at the trial point
-bool Engine::update_phase(double mu, double *dB_dev)
+bool Engine::update_phase(double mu, double *dB_dev, bool peek)
 {
     const Plan &pl = plan_;
     const ModelCfg mc = model();
     launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, links_,
-                      d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part_.p, d_stage_.p, scal_());
+                      d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part2_.p, d_stage_.p, scal_());
     BacksubArgs b{};
     b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
@@ -582,8 +584,9 @@ bool Engine::update_phase(double mu, double *dB_dev)
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, false, dB_dev, b.ngrid));
     if (timing_detail >= 2) (void)hipEventRecord(ev_[5], st_);
-    launch_reduce_partials(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
-                           cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT);
+    launch_reduce_final(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
+                        cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT,
+                        m_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, c_lag_, mu);
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }

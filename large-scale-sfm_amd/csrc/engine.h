@@ -77,7 +77,7 @@ private:
     bool hipok(hipError_t e, const char *what);
     bool linear_phase(double mu, bool want_diag, const double *spec = nullptr); // cam_prep .. build .. all-reduce .. finalize .. block_inv
     bool solve_phase(double mu, double *dB_dev, bool may_speculate = false);    // pcg .. cam_update .. backsub .. all-reduce .. scalars on the host
-    bool update_phase(double mu, double *dB_dev);
+    bool update_phase(double mu, double *dB_dev, bool peek = false);   // peek: k_reduce_final also takes the controller's decision (one rank)
     bool pcg_chunks(int it0);
     PcgArgs pcg_args();
     int pcg_pred_ = 0, pcg_pred_prev_ = 0;        // iterations of the previous two solves of this LM run
@@ -129,7 +129,7 @@ private:
     DevBuf<unsigned char> d_tile_mode_;
     DevBuf<int> d_bs_batch_obs_, d_bs_batch_pt_;
     DevBuf<double> d_cam_a_init_, d_pts_init_;
-    DevBuf<double> d_link_w_, d_link_pair_w_, d_cam_part_;
+    DevBuf<double> d_link_w_, d_link_pair_w_, d_cam_part_, d_cam_part2_;   // partial rows of k_finalize_vec / of k_cam_update
     long long long_max_pairs_ = 0;
     LongArgs long_args(double mu, bool want_diag, double *dB_dev, int part_row0);
     DevBuf<double2> d_obs_xy_;

@@ -128,13 +128,16 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const double *spec, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full /* or nullptr */,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
-                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg);
+                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg,
+                     bool reduce_now /* false: the camera-side sums are taken by launch_reduce_final at the end of the trial */);
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one launch
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . M^-1 r_it
 void launch_pcg_finish(hipStream_t st, const PcgArgs &a); // da = Linv^T x~
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max);
 void launch_fold_max(hipStream_t st, double *slots, int world, double *out8);
+void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
+                         int m, const double *fv_part, const double *cu_part, double *scal, double *spec /* or nullptr */, double c_lag, double mu);
 // the LM controller's accept test and damping update on the device (sba_levmar.c:1543-1552), from the trial's scalars:
 // spec[0] = 1 when the trial will be accepted, spec[1] = the damping of the next trial
 void launch_lm_peek(hipStream_t st, double *scal, double c_lag, double mu, double *spec); // out8[c] = max over the ranks' slots, which are zeroed

@@ -979,12 +979,9 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
 // folds per-workgroup partial rows: columns [0,4) are sums, [4,8) maxima.  Two stages when there are many
 // rows: gridDim.x workgroups each fold a contiguous chunk into one row of `stage`, then one workgroup
 // folds those (deterministic: fixed chunking and order).
-__global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const double *__restrict__ part, double *__restrict__ stage,
-                                                        double *__restrict__ out_sum, double *__restrict__ out_max)
+// columns 0..3 of the rows [r0, r1) summed, 4..7 maximised, by one 1024-thread workgroup; thread c < 8 ends up with column c
+__device__ __forceinline__ double reduce_rows(const double *__restrict__ part, int r0, int r1, double (*sh)[kPartW])
 {
-    __shared__ double sh[16][kPartW];
-    const int chunk = (nrows + gridDim.x - 1) / gridDim.x;
-    const int r0 = blockIdx.x * chunk, r1 = min(nrows, r0 + chunk);
     double acc[kPartW];
 #pragma unroll
     for (int c = 0; c < kPartW; ++c) acc[c] = 0.0;
@@ -1000,17 +997,61 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const doubl
 #pragma unroll
     for (int c = 4; c < kPartW; ++c) acc[c] = wave_max(acc[c]);
     const int w = threadIdx.x >> 6;
+    __syncthreads();                                   // sh may still be read from a previous call
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
         for (int c = 0; c < kPartW; ++c) sh[w][c] = acc[c];
     __syncthreads();
+    double v = 0.0;
     if (threadIdx.x < kPartW) {
         const int c = threadIdx.x, nw = blockDim.x >> 6;
-        double v = 0.0;
         for (int k = 0; k < nw; ++k) v = (c < 4) ? v + sh[k][c] : fmax(v, sh[k][c]);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const double *__restrict__ part, double *__restrict__ stage,
+                                                        double *__restrict__ out_sum, double *__restrict__ out_max)
+{
+    __shared__ double sh[16][kPartW];
+    const int chunk = (nrows + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * chunk, r1 = min(nrows, r0 + chunk);
+    const double v = reduce_rows(part, r0, r1, sh);
+    if (threadIdx.x < kPartW) {
+        const int c = threadIdx.x;
         if (gridDim.x > 1) stage[(size_t)blockIdx.x * kPartW + c] = v;
         else if (c < 4) out_sum[c] = v;
         else out_max[c - 4] = v;
+    }
+}
+
+// The end of a trial in one launch: the last stage of the back-substitution's sums, the camera-side sums k_finalize_vec and
+// k_cam_update left as partial rows (nothing on the device needs them earlier), and -- on one rank, where no exchange
+// comes in between -- the controller's accept test and damping update (k_lm_peek below).
+struct FinalReduceArgs {
+    const double *bs_part; int bs_rows; double *bs_sum, *bs_max;       // back-substitution (or its first stage's output)
+    const double *fv_part; int fv_rows;                                 // k_finalize_vec  -> scal[16, 24)
+    const double *cu_part; int cu_rows;                                 // k_cam_update    -> scal[24, 28)
+    double *scal;
+    double *spec; double c_lag, mu;                                     // spec != nullptr: peek
+};
+
+__device__ __forceinline__ void lm_peek(double *__restrict__ s, double c_lag, double mu, double *__restrict__ spec);
+
+__global__ __launch_bounds__(1024) void k_reduce_final(const FinalReduceArgs a)
+{
+    __shared__ double sh[16][kPartW];
+    const int c = threadIdx.x;
+    double v = reduce_rows(a.fv_part, 0, a.fv_rows, sh);
+    if (c < 4) a.scal[SC_PL2_CAMS + c] = v; else if (c < kPartW) a.scal[SC_EA_INF + c - 4] = v;
+    v = reduce_rows(a.cu_part, 0, a.cu_rows, sh);
+    if (c < 4) a.scal[SC_DL_CAMS + c] = v;
+    v = reduce_rows(a.bs_part, 0, a.bs_rows, sh);
+    if (c < 4) a.bs_sum[c] = v; else if (c < kPartW) a.bs_max[c - 4] = v;
+    if (a.spec) {
+        __threadfence_block();
+        __syncthreads();
+        if (c == 0) lm_peek(a.scal, a.c_lag, a.mu, a.spec);
     }
 }
 
@@ -1602,7 +1643,7 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const double *spec, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
-                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg)
+                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg, bool reduce_now)
 {
     FinalizeArgs f;
     f.cnp = cnp; f.mu = mu; f.spec = spec; f.fixed = fixed; f.pfix = pfix; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
@@ -1611,7 +1652,7 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, pfix, camvec, cam_a, cam_cw, cam_cv,
                        links, E, cam_part);
-    launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);
+    if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
     hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal);
     hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg);
 }
@@ -1648,9 +1689,8 @@ __global__ void k_fold_max(double *__restrict__ slots, int world, double *__rest
 // scalars, with the host's expressions operation for operation (no contraction: the host compares its own damping with
 // spec[1] bit for bit before it uses what was built with it).
 #pragma clang fp contract(off)
-__global__ void k_lm_peek(double *__restrict__ s, double c_lag, double mu, double *__restrict__ spec)
+__device__ __forceinline__ void lm_peek(double *__restrict__ s, double c_lag, double mu, double *__restrict__ spec)
 {
-    if (threadIdx.x != 0) return;
     const double c_cur = s[SC_CONS_CAM] + s[SC_CONS_PTS];
     const double p_eL2 = s[SC_COST] + c_lag + s[SC_LINK];
     const double pdp_eL2 = s[SC_COST_NEW] + c_cur + s[SC_LINK_NEW];
@@ -1667,6 +1707,11 @@ __global__ void k_lm_peek(double *__restrict__ s, double c_lag, double mu, doubl
     s[SC_SPEC_GO] = go; s[SC_SPEC_MU] = mu_next;
 }
 #pragma clang fp contract(fast)
+
+__global__ void k_lm_peek(double *__restrict__ s, double c_lag, double mu, double *__restrict__ spec)
+{
+    if (threadIdx.x == 0) lm_peek(s, c_lag, mu, spec);
+}
 
 void launch_lm_peek(hipStream_t st, double *scal, double c_lag, double mu, double *spec) { hipLaunchKernelGGL(k_lm_peek, dim3(1), dim3(64), 0, st, scal, c_lag, mu, spec); }
 
@@ -1687,7 +1732,23 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, cons
 {
     hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, dA, camvec, R0, f_fixed,
                        links, cam_a_new, cam_lin_new, cam_part);
-    launch_reduce_partials(st, (m + 63) / 64, cam_part, stage, scal + SC_DL_CAMS, scal + SC_SPARE_MAX);
+}
+
+// last stage of the back-substitution's reduction (its first stage first when there are many rows) + the camera-side sums + peek
+void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
+                         int m, const double *fv_part, const double *cu_part, double *scal, double *spec, double c_lag, double mu)
+{
+    FinalReduceArgs a;
+    a.bs_part = bs_part; a.bs_rows = bs_rows;
+    if (bs_rows > 4096) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3(kReduceStage), dim3(1024), 0, st, bs_rows, bs_part, stage, bs_sum, bs_max);
+        a.bs_part = stage; a.bs_rows = kReduceStage;
+    }
+    a.bs_sum = bs_sum; a.bs_max = bs_max;
+    a.fv_part = fv_part; a.fv_rows = (m * kCP + 63) / 64;
+    a.cu_part = cu_part; a.cu_rows = (m + 63) / 64;
+    a.scal = scal; a.spec = spec; a.c_lag = c_lag; a.mu = mu;
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, st, a);
 }
 
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
