@@ -474,8 +474,25 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     if (!allreduce1()) return false;
     launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
-                    d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag);   // want_diag: a linear phase on its own (begin, parity hooks)
+                    d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag /* a linear phase on its own (begin, parity hooks) */, pcg_start());
+    cg_start_fresh_ = true;
     return hipok(hipGetLastError(), "launch (linear phase)");
+}
+
+PeekArgs Engine::peek_args(double mu) const
+{
+    PeekArgs k{};
+    k.c_lag = c_lag_; k.mu = mu;
+    k.eps2_sq = cfg.opts[2] * cfg.opts[2]; k.eps3_sq = cfg.opts[3] * cfg.opts[3]; k.eps4_sq = cfg.opts[4] * cfg.opts[4]; k.eps5 = cfg.opts[5];
+    k.pl2_inactive = pl2_inactive_; k.itno = itno_; k.mode = cfg.mode; k.stops = cfg.disable_stops ? 0 : 1;
+    k.last = itno_ + 1 >= cfg.itmax ? 1 : 0;
+    return k;
+}
+
+PcgStart Engine::pcg_start()
+{
+    const PcgArgs p = pcg_args();
+    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1 };
 }
 
 PcgArgs Engine::pcg_args()
@@ -519,6 +536,8 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
     PcgArgs p = pcg_args();
     // (histories and partials need no reset: every slot a launch reads was written by an earlier launch of this solve)
     if (timing_detail >= 2) (void)hipEventRecord(ev_[2], st_);
+    if (!cg_start_fresh_) launch_pcg_reinit(st_, p);   // a second solve on the same linearisation (parity hooks)
+    cg_start_fresh_ = false;
     launch_pcg_init(st_, p);
     // the count grows geometrically from trial to trial while the damping falls by 1/3 (measured on C3: 9, 14, 20, 33, 54, 93,
     // then the cap): extrapolate the last ratio, with a margin -- an iteration too many costs 2 us, one too few a round trip
@@ -526,8 +545,9 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
     int it0 = std::min(cfg.pcg_maxit, std::max(kPcgChunk, (int)std::ceil(pcg_pred_ * ratio * 1.25) + 3));
     if (const char *force = std::getenv("MI_BA_PCG_FIRST_RUN")) it0 = std::min(cfg.pcg_maxit, std::max(1, std::atoi(force)));   // test hook: make the guess fall short
     for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
-    p.it = it0; p.last = it0 >= cfg.pcg_maxit; launch_pcg_tail(st_, p);
-    launch_pcg_finish(st_, p);
+    p.it = it0; p.last = it0 >= cfg.pcg_maxit; p.tail = 1;
+    launch_pcg_finish(st_, p);   // + what k_pcg_tail does
+    p.tail = 0;
     if (timing_detail >= 2) (void)hipEventRecord(ev_[3], st_);
     const bool spec = may_speculate && speculate_;
     if (!update_phase(mu, dB_dev, spec && cfg.world == 1)) return false;
@@ -540,7 +560,7 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
         // copy of the scalars, runs the controller as ever, and adopts what was built when its own decision -- accepted,
         // no stop, the same damping bit for bit -- is the one the device acted on.  Otherwise (rejected: k_build saw the
         // flag and did nothing; stopped; a reduced solve that needs more iterations) it linearises again as before.
-        if (cfg.world > 1) launch_lm_peek(st_, scal_(), c_lag_, mu, d_spec_.p);   // after the exchange; on one rank k_reduce_final has done it
+        if (cfg.world > 1) launch_lm_peek(st_, scal_(), peek_args(mu), d_spec_.p);   // after the exchange; on one rank k_reduce_final has done it
         if (!hipok(hipMemcpyAsync(h_scal_, scal_(), sizeof(double) * kScalCount, hipMemcpyDeviceToHost, st_), "copy scal")) return false;
         (void)hipEventRecord(ev_[8], st_);
         cur_ ^= 1;                                   // the trial point, where an accepted trial continues
@@ -556,6 +576,7 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
         if (spec_enqueued_) {           // the linear phase enqueued behind it has overwritten this trial's system: build it again
             spec_enqueued_ = false;
             if (!linear_phase(mu, false)) return false;
+            cg_start_fresh_ = false;
             launch_pcg_init(st_, p);
             it0 = 0;
         }
@@ -586,7 +607,7 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     if (timing_detail >= 2) (void)hipEventRecord(ev_[5], st_);
     launch_reduce_final(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
                         cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT,
-                        m_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, c_lag_, mu);
+                        m_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, peek_args(mu));
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }

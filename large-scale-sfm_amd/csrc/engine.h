@@ -80,6 +80,8 @@ private:
     bool update_phase(double mu, double *dB_dev, bool peek = false);   // peek: k_reduce_final also takes the controller's decision (one rank)
     bool pcg_chunks(int it0);
     PcgArgs pcg_args();
+    PcgStart pcg_start();
+    PeekArgs peek_args(double mu) const;
     int pcg_pred_ = 0, pcg_pred_prev_ = 0;        // iterations of the previous two solves of this LM run
     bool read_scalars();
     bool allreduce1();
@@ -95,6 +97,7 @@ private:
     int lin_count_ = 0, lin_pair_ = 0, spec_pair_ = 0;
     // the next trial's linear phase enqueued before the host has seen this trial's outcome (solve_phase)
     bool speculate_ = true, spec_enqueued_ = false, spec_ready_ = false;
+    bool cg_start_fresh_ = false;   // the last linear phase's k_block_inv has set up the CG start and no solve has used it yet
     void *comm_ = nullptr; // ncclComm_t
     mi_ba_host_allreduce_fn host_ar_ = nullptr;   // test transport: the exchange through a host callback instead of RCCL
     void *host_ar_user_ = nullptr;

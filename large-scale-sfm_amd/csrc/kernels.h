@@ -111,6 +111,9 @@ struct LongArgs {
     const double *spec;                     // as in BuildArgs (the linear-phase kernels)
 };
 
+// where the CG starts: written by k_block_inv, which holds L^-1 of every camera's diagonal block anyway
+struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; };
+
 struct PcgArgs {
     const int *bsr_row, *bsr_col;
     const double *S, *Linv, *E;                        // S = the scaled matrix S~ (k_scale_blocks)
@@ -118,6 +121,7 @@ struct PcgArgs {
     double *gp, *dp, *rz_hist, *alpha_hist, *scal;     // gp, dp [2][nwg]: partials of r.r and w.r per workgroup; histories [maxit+2]
     double tol;
     int last;                                          // k_pcg_tail: no iteration will follow this one
+    int tail;                                          // k_pcg_finish: do k_pcg_tail's work as well
     int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init / k_pcg_finish); product kernels: nwg = m (one block row per
                                                        // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
 };
@@ -129,18 +133,26 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full /* or nullptr */,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg,
-                     bool reduce_now /* false: the camera-side sums are taken by launch_reduce_final at the end of the trial */);
-void launch_pcg_init(hipStream_t st, const PcgArgs &a);
+                     bool reduce_now /* false: the camera-side sums are taken by launch_reduce_final at the end of the trial */,
+                     const PcgStart &ps);
+void launch_pcg_init(hipStream_t st, const PcgArgs &a);  // w_0 = S~ r_0 and the first partials (r_0: k_block_inv)
+void launch_pcg_reinit(hipStream_t st, const PcgArgs &a); // r_0, x~_0 again, for a second solve on the same linearisation
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one launch
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . M^-1 r_it
 void launch_pcg_finish(hipStream_t st, const PcgArgs &a); // da = Linv^T x~
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max);
 void launch_fold_max(hipStream_t st, double *slots, int world, double *out8);
-void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
-                         int m, const double *fv_part, const double *cu_part, double *scal, double *spec /* or nullptr */, double c_lag, double mu);
 // the LM controller's accept test and damping update on the device (sba_levmar.c:1543-1552), from the trial's scalars:
-// spec[0] = 1 when the trial will be accepted, spec[1] = the damping of the next trial
-void launch_lm_peek(hipStream_t st, double *scal, double c_lag, double mu, double *spec); // out8[c] = max over the ranks' slots, which are zeroed
+// spec[0] = 1 when the trial will be accepted and the solve goes on, spec[1] = the damping of the next trial
+struct PeekArgs {
+    double c_lag, mu;                                  // the controller's state the scalars do not hold
+    double eps2_sq, eps3_sq, eps4_sq, eps5, pl2_inactive;
+    int itno, mode, stops, last;                       // last: the iteration cap ends the solve with this trial
+};
+void launch_lm_peek(hipStream_t st, double *scal, const PeekArgs &pk, double *spec);
+void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
+                         int m, const double *fv_part, const double *cu_part, double *scal, double *spec /* or nullptr */, const PeekArgs &pk);
+ // out8[c] = max over the ranks' slots, which are zeroed
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
                        const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
                        double *cam_lin_new, double *cam_part, double *stage, double *scal);

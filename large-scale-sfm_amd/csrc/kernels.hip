@@ -1033,10 +1033,10 @@ struct FinalReduceArgs {
     const double *fv_part; int fv_rows;                                 // k_finalize_vec  -> scal[16, 24)
     const double *cu_part; int cu_rows;                                 // k_cam_update    -> scal[24, 28)
     double *scal;
-    double *spec; double c_lag, mu;                                     // spec != nullptr: peek
+    double *spec; PeekArgs pk;                                          // spec != nullptr: peek
 };
 
-__device__ __forceinline__ void lm_peek(double *__restrict__ s, double c_lag, double mu, double *__restrict__ spec);
+__device__ __forceinline__ void lm_peek(double *__restrict__ s, const PeekArgs &k, double *__restrict__ spec);
 
 __global__ __launch_bounds__(1024) void k_reduce_final(const FinalReduceArgs a)
 {
@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const FinalReduceArgs a)
     if (a.spec) {
         __threadfence_block();
         __syncthreads();
-        if (c == 0) lm_peek(a.scal, a.c_lag, a.mu, a.spec);
+        if (c == 0) lm_peek(a.scal, a.pk, a.spec);
     }
 }
 
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
 // one wavefront per camera: the 64 lanes fetch the diagonal block's 64 finalised elements at once (one round of memory
 // latency instead of 36 dependent ones), lane 0 factors it from LDS and writes L^-1
 __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict__ bsr_diag, const FinalizeArgs f,
-                                                  double *__restrict__ Linv, double *__restrict__ scal)
+                                                  double *__restrict__ Linv, double *__restrict__ scal, const PcgStart ps)
 {
     __shared__ double sb[4][64], so[4][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv;
@@ -1188,7 +1188,17 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
         }
     }
     wave_lds_sync();
-    if (live) Linv[(size_t)j * 64 + lane] = so[wv][lane];
+    if (live) {
+        Linv[(size_t)j * 64 + lane] = so[wv][lane];
+        if (lane < 8) { // the start of the CG on the scaled system: r_0 = E~ = L^-1 E, x~_0 = 0 (this camera's rows)
+            const double *Ej = ps.E + (size_t)j * 8;
+            double rr = 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) rr += so[wv][lane * 8 + c] * Ej[c];
+            const int idx = j * 8 + lane;
+            ps.x[idx] = 0.0; ps.r0[idx] = rr; ps.p[idx] = 0.0; ps.s0[idx] = 0.0; ps.s1[idx] = 0.0;
+        }
+    }
 }
 
 // S~_jk = Linv_j S_jk Linv_k^T, one wavefront per block, lane (r,c); the block and the two factors go through LDS
@@ -1244,7 +1254,8 @@ __device__ __forceinline__ bool pcg_converged(const PcgArgs &a, double rz_it)
     return sqrt(fabs(rz_it) / rz0) < a.tol;
 }
 
-// 8 cameras per 64-lane group: lane = (camera, row).  r_0 = E~ = Linv E, x~_0 = 0.
+// r_0 = E~ = Linv E, x~_0 = 0 on its own (k_block_inv does this as part of a linear phase; a second solve on the same
+// linearisation -- the parity hooks -- starts here).  8 cameras per 64-lane group: lane = (camera, row).
 __global__ __launch_bounds__(64) void k_pcg_init(const PcgArgs a)
 {
     const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
@@ -1257,9 +1268,11 @@ __global__ __launch_bounds__(64) void k_pcg_init(const PcgArgs a)
     a.x[idx] = 0.0; a.r0[idx] = rr; a.p[idx] = 0.0; a.s0[idx] = 0.0; a.s1[idx] = 0.0;
 }
 
-// da = Linv^T x~
+// da = Linv^T x~; with a.tail the first workgroup also does what k_pcg_tail does (the end of a run of iterations)
+__device__ __forceinline__ void pcg_tail(const PcgArgs &a);
 __global__ __launch_bounds__(64) void k_pcg_finish(const PcgArgs a)
 {
+    if (a.tail && blockIdx.x == 0) pcg_tail(a);
     const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
     if (j >= a.m) return;
     const double *Li = a.Linv + (size_t)j * 64, *xj = a.x + (size_t)j * 8;
@@ -1366,8 +1379,8 @@ __global__ __launch_bounds__(256) void k_pcg_start(const PcgArgs a)
 }
 
 // rz_hist[it] = gamma_it, the sticky converged flag, and SC_PCG_FINAL when the solve is over (converged, broken down, or
-// a.last: no iteration will follow); one wavefront, launched after a run of iterations.
-__global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a)
+// a.last: no iteration will follow); one wavefront, after a run of iterations.
+__device__ __forceinline__ void pcg_tail(const PcgArgs &a)
 {
     bool over = a.scal[SC_PCG_STATUS] != 0.0 || a.scal[SC_PCG_DONE] != 0.0;
     if (!over) {
@@ -1380,6 +1393,8 @@ __global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a)
     }
     if (threadIdx.x == 0 && (over || a.last)) a.scal[SC_PCG_FINAL] = 1.0;
 }
+
+__global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a) { pcg_tail(a); }
 
 // iteration a.it.  The product w_{it+1} = S~ r_{it+1} needs r_{it+1} = r_it - alpha (w_it + beta s_{it-1}) of the neighbouring block
 // rows, which their owners are only writing in this same launch, and alpha, beta, which every wavefront first has to sum up:
@@ -1643,7 +1658,7 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const double *spec, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
-                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg, bool reduce_now)
+                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg, bool reduce_now, const PcgStart &ps)
 {
     FinalizeArgs f;
     f.cnp = cnp; f.mu = mu; f.spec = spec; f.fixed = fixed; f.pfix = pfix; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
@@ -1653,13 +1668,14 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, pfix, camvec, cam_a, cam_cw, cam_cv,
                        links, E, cam_part);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
-    hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal);
+    hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps);
     hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg);
 }
 
+void launch_pcg_reinit(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_init, dim3(a.ng), dim3(64), 0, st, a); }
+
 void launch_pcg_init(hipStream_t st, const PcgArgs &a)
 {
-    hipLaunchKernelGGL(k_pcg_init, dim3(a.ng), dim3(64), 0, st, a);
     if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_start<1>, dim3(a.nwg), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_pcg_start<4>, dim3(a.nwg), dim3(256), 0, st, a);
 }
@@ -1689,10 +1705,11 @@ __global__ void k_fold_max(double *__restrict__ slots, int world, double *__rest
 // scalars, with the host's expressions operation for operation (no contraction: the host compares its own damping with
 // spec[1] bit for bit before it uses what was built with it).
 #pragma clang fp contract(off)
-__device__ __forceinline__ void lm_peek(double *__restrict__ s, double c_lag, double mu, double *__restrict__ spec)
+__device__ __forceinline__ void lm_peek(double *__restrict__ s, const PeekArgs &k, double *__restrict__ spec)
 {
+    const double mu = k.mu;
     const double c_cur = s[SC_CONS_CAM] + s[SC_CONS_PTS];
-    const double p_eL2 = s[SC_COST] + c_lag + s[SC_LINK];
+    const double p_eL2 = s[SC_COST] + k.c_lag + s[SC_LINK];
     const double pdp_eL2 = s[SC_COST_NEW] + c_cur + s[SC_LINK_NEW];
     const double dL = s[SC_DL_CAMS] + s[SC_DL_PTS], dF = p_eL2 - pdp_eL2;
     const bool solved = s[SC_PCG_FINAL] != 0.0 && s[SC_PCG_STATUS] == 0.0 && s[SC_NOT_PD] == 0.0 && s[SC_SINGULAR] == 0.0;
@@ -1702,18 +1719,29 @@ __device__ __forceinline__ void lm_peek(double *__restrict__ s, double c_lag, do
         tmp = 1.0 - tmp * tmp * tmp;
         mu_next = mu * ((tmp >= 0.3333333334) ? tmp : 0.3333333334);
         go = 1.0;
+        // the stop rules that end the solve with this trial (engine.cpp step(): stops 2, 3, 4, 5, 8): nothing to linearise
+        // ahead then.  These only decide whether the work is worth starting; the host's own tests are the ones that count.
+        if (k.last) go = 0.0;
+        if (k.stops) {
+            const double dp_L2 = s[SC_DP2_CAMS] + s[SC_DP2_PTS];
+            const double p_L2 = (k.mode == 2 ? 0.0 : s[SC_PL2_CAMS]) + (k.mode == 1 ? 0.0 : s[SC_PL2_PTS] + k.pl2_inactive);
+            if (dp_L2 <= k.eps2_sq * p_L2) go = 0.0;
+            if (pdp_eL2 - 2.0 * sqrt(p_eL2 * pdp_eL2) < (k.eps4_sq - 1.0) * p_eL2) go = 0.0;
+            if (k.mode == 0 && s[SC_MAX_PCT] < k.eps5 && k.itno >= 4) go = 0.0;
+            if (pdp_eL2 <= k.eps3_sq) go = 0.0;
+        }
     }
     spec[0] = go; spec[1] = mu_next;
     s[SC_SPEC_GO] = go; s[SC_SPEC_MU] = mu_next;
 }
 #pragma clang fp contract(fast)
 
-__global__ void k_lm_peek(double *__restrict__ s, double c_lag, double mu, double *__restrict__ spec)
+__global__ void k_lm_peek(double *__restrict__ s, const PeekArgs k, double *__restrict__ spec)
 {
-    if (threadIdx.x == 0) lm_peek(s, c_lag, mu, spec);
+    if (threadIdx.x == 0) lm_peek(s, k, spec);
 }
 
-void launch_lm_peek(hipStream_t st, double *scal, double c_lag, double mu, double *spec) { hipLaunchKernelGGL(k_lm_peek, dim3(1), dim3(64), 0, st, scal, c_lag, mu, spec); }
+void launch_lm_peek(hipStream_t st, double *scal, const PeekArgs &pk, double *spec) { hipLaunchKernelGGL(k_lm_peek, dim3(1), dim3(64), 0, st, scal, pk, spec); }
 
 void launch_fold_max(hipStream_t st, double *slots, int world, double *out8) { hipLaunchKernelGGL(k_fold_max, dim3(1), dim3(64), 0, st, slots, world, out8); }
 
@@ -1736,7 +1764,7 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, cons
 
 // last stage of the back-substitution's reduction (its first stage first when there are many rows) + the camera-side sums + peek
 void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
-                         int m, const double *fv_part, const double *cu_part, double *scal, double *spec, double c_lag, double mu)
+                         int m, const double *fv_part, const double *cu_part, double *scal, double *spec, const PeekArgs &pk)
 {
     FinalReduceArgs a;
     a.bs_part = bs_part; a.bs_rows = bs_rows;
@@ -1747,7 +1775,7 @@ void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, dou
     a.bs_sum = bs_sum; a.bs_max = bs_max;
     a.fv_part = fv_part; a.fv_rows = (m * kCP + 63) / 64;
     a.cu_part = cu_part; a.cu_rows = (m + 63) / 64;
-    a.scal = scal; a.spec = spec; a.c_lag = c_lag; a.mu = mu;
+    a.scal = scal; a.spec = spec; a.pk = pk;
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, st, a);
 }
 
