@@ -546,7 +546,7 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
     if (const char *force = std::getenv("MI_BA_PCG_FIRST_RUN")) it0 = std::min(cfg.pcg_maxit, std::max(1, std::atoi(force)));   // test hook: make the guess fall short
     for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
     p.it = it0; p.last = it0 >= cfg.pcg_maxit; p.tail = 1;
-    launch_pcg_finish(st_, p);   // + what k_pcg_tail does
+    upd_p_ = p;                  // k_cam_update: what k_pcg_tail does, then da = Linv^T x~
     p.tail = 0;
     if (timing_detail >= 2) (void)hipEventRecord(ev_[3], st_);
     const bool spec = may_speculate && speculate_;
@@ -581,7 +581,7 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
             it0 = 0;
         }
         if (!pcg_chunks(it0)) return false;
-        launch_pcg_finish(st_, p);
+        upd_p_ = p; upd_p_.tail = 0;
         if (!update_phase(mu, dB_dev) || !read_scalars()) return false;
     }
     pcg_pred_prev_ = pcg_pred_ > 0 ? pcg_pred_ : (int)h_scal_[SC_PCG_ITERS];
@@ -594,8 +594,8 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
 {
     const Plan &pl = plan_;
     const ModelCfg mc = model();
-    launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, links_,
-                      d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part2_.p, d_stage_.p, scal_());
+    launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, upd_p_, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, links_,
+                      d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part2_.p);
     BacksubArgs b{};
     b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;

@@ -97,6 +97,7 @@ private:
     int lin_count_ = 0, lin_pair_ = 0, spec_pair_ = 0;
     // the next trial's linear phase enqueued before the host has seen this trial's outcome (solve_phase)
     bool speculate_ = true, spec_enqueued_ = false, spec_ready_ = false;
+    PcgArgs upd_p_{};               // the solve k_cam_update ends (it, last, tail set by solve_phase)
     bool cg_start_fresh_ = false;   // the last linear phase's k_block_inv has set up the CG start and no solve has used it yet
     void *comm_ = nullptr; // ncclComm_t
     mi_ba_host_allreduce_fn host_ar_ = nullptr;   // test transport: the exchange through a host callback instead of RCCL

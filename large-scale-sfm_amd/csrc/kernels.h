@@ -121,7 +121,7 @@ struct PcgArgs {
     double *gp, *dp, *rz_hist, *alpha_hist, *scal;     // gp, dp [2][nwg]: partials of r.r and w.r per workgroup; histories [maxit+2]
     double tol;
     int last;                                          // k_pcg_tail: no iteration will follow this one
-    int tail;                                          // k_pcg_finish: do k_pcg_tail's work as well
+    int tail;                                          // k_cam_update: do k_pcg_tail's work as well
     int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init / k_pcg_finish); product kernels: nwg = m (one block row per
                                                        // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
 };
@@ -139,7 +139,6 @@ void launch_pcg_init(hipStream_t st, const PcgArgs &a);  // w_0 = S~ r_0 and the
 void launch_pcg_reinit(hipStream_t st, const PcgArgs &a); // r_0, x~_0 again, for a second solve on the same linearisation
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one launch
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a); // rz_hist[a.it] = r_it . M^-1 r_it
-void launch_pcg_finish(hipStream_t st, const PcgArgs &a); // da = Linv^T x~
 void launch_reduce_partials(hipStream_t st, int nrows, const double *part, double *stage, double *out_sum, double *out_max);
 void launch_fold_max(hipStream_t st, double *slots, int world, double *out8);
 // the LM controller's accept test and damping update on the device (sba_levmar.c:1543-1552), from the trial's scalars:
@@ -153,9 +152,9 @@ void launch_lm_peek(hipStream_t st, double *scal, const PeekArgs &pk, double *sp
 void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
                          int m, const double *fv_part, const double *cu_part, double *scal, double *spec /* or nullptr */, const PeekArgs &pk);
  // out8[c] = max over the ranks' slots, which are zeroed
-void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
-                       const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
-                       double *cam_lin_new, double *cam_part, double *stage, double *scal);
+void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const PcgArgs &pa,
+                       double *dA, const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
+                       double *cam_lin_new, double *cam_part);   // ends the scaled solve (da = Linv^T x~, + k_pcg_tail's work with pa.tail), then a + da
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a);
 void launch_long_build(hipStream_t st, int cnp, const LongArgs &a);   // k_long_reduce + k_long_pairs
 void launch_long_backsub(hipStream_t st, int cnp, const LongArgs &a);

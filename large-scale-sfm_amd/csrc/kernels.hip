@@ -1268,20 +1268,6 @@ __global__ __launch_bounds__(64) void k_pcg_init(const PcgArgs a)
     a.x[idx] = 0.0; a.r0[idx] = rr; a.p[idx] = 0.0; a.s0[idx] = 0.0; a.s1[idx] = 0.0;
 }
 
-// da = Linv^T x~; with a.tail the first workgroup also does what k_pcg_tail does (the end of a run of iterations)
-__device__ __forceinline__ void pcg_tail(const PcgArgs &a);
-__global__ __launch_bounds__(64) void k_pcg_finish(const PcgArgs a)
-{
-    if (a.tail && blockIdx.x == 0) pcg_tail(a);
-    const int j = blockIdx.x * 8 + (threadIdx.x >> 3), r = threadIdx.x & 7;
-    if (j >= a.m) return;
-    const double *Li = a.Linv + (size_t)j * 64, *xj = a.x + (size_t)j * 8;
-    double v = 0.0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) v += Li[c * 8 + r] * xj[c];
-    a.da[j * 8 + r] = v;
-}
-
 // the workgroup's two dot-product partials: four wavefronts, fixed order
 __device__ __forceinline__ void publish_partials(const PcgArgs &a, int slot, double g, double d, double (*sh)[2])
 {
@@ -1458,18 +1444,35 @@ __global__ __launch_bounds__(256) void k_pcg_iter(const PcgArgs a)
 // camera update: a_new = a + da, new camera record, dL and ||dp||^2 camera parts
 // (sba_levmar.c:1444-1447, 1524-1525)
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pcg_tail(const PcgArgs &a);
+
+// da_k[r] = (Linv_k^T x~_k)[r]: the end of the scaled solve for one camera parameter
+__device__ __forceinline__ double scaled_back(const PcgArgs &pa, int k, int r)
+{
+    const double *Li = pa.Linv + (size_t)k * 64, *xk = pa.x + (size_t)k * 8;
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v = fma(Li[c * 8 + r], xk[c], v);
+    return v;
+}
+
+// pa: the finished (or, launched ahead, perhaps unfinished: SC_PCG_FINAL) scaled solve -- this kernel also ends it: da = Linv^T x~
+// goes to dA for the back-substitution, and with pa.tail the first workgroup does what k_pcg_tail does
 __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *__restrict__ fixed, double mu, const double *__restrict__ cam_a,
-                             const double *__restrict__ dA, const double *__restrict__ camvec,
+                             const PcgArgs pa, double *__restrict__ dA, const double *__restrict__ camvec,
                              const double *__restrict__ R0, const double *__restrict__ f_fixed, const CamLinks lk,
                              double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ part)
 {
+    if (pa.tail && blockIdx.x == 0) pcg_tail(pa);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double dl = 0.0, dp2 = 0.0, lc = 0.0;
     if (j < m) {
         double an[kCP];
 #pragma unroll
         for (int r = 0; r < kCP; ++r) {
-            const double d = (r < cnp && !fixed[j]) ? dA[j * kCP + r] : 0.0;
+            const double dj = scaled_back(pa, j, r);
+            dA[j * kCP + r] = dj;
+            const double d = (r < cnp && !fixed[j]) ? dj : 0.0;
             an[r] = cam_a[j * kCP + r] + d;
             cam_a_new[j * kCP + r] = an[r];
             dl += d * (mu * d + camvec[j * kCP + r]);
@@ -1480,7 +1483,7 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
             for (int q = lk.row[j]; q < lk.row[j + 1]; ++q) {
                 const int k = lk.other[q];
                 for (int r = 0; r < cnp; ++r) {
-                    const double ak = cam_a[k * kCP + r] + (fixed[k] ? 0.0 : dA[k * kCP + r]), dq = ak - an[r];
+                    const double ak = cam_a[k * kCP + r] + (fixed[k] ? 0.0 : scaled_back(pa, k, r)), dq = ak - an[r];
                     lc = fma(0.5 * lk.w[(size_t)q * kCP + r], dq * dq, lc);
                 }
             }
@@ -1686,7 +1689,6 @@ void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
     else hipLaunchKernelGGL(k_pcg_iter<4>, dim3(a.nwg), dim3(256), 0, st, a);
 }
 
-void launch_pcg_finish(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_finish, dim3(a.ng), dim3(64), 0, st, a); }
 
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_tail, dim3(1), dim3(64), 0, st, a); }
 
@@ -1754,11 +1756,11 @@ void launch_reduce_partials(hipStream_t st, int nrows, const double *part, doubl
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, st, nrows, part, stage, out_sum, out_max);
 }
 
-void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const double *dA,
-                       const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
-                       double *cam_lin_new, double *cam_part, double *stage, double *scal)
+void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const PcgArgs &pa,
+                       double *dA, const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
+                       double *cam_lin_new, double *cam_part)
 {
-    hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, dA, camvec, R0, f_fixed,
+    hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, pa, dA, camvec, R0, f_fixed,
                        links, cam_a_new, cam_lin_new, cam_part);
 }
 
