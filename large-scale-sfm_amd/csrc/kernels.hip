@@ -1040,18 +1040,47 @@ __device__ __forceinline__ void lm_peek(double *__restrict__ s, const PeekArgs &
 
 __global__ __launch_bounds__(1024) void k_reduce_final(const FinalReduceArgs a)
 {
-    __shared__ double sh[16][kPartW];
-    const int c = threadIdx.x;
-    double v = reduce_rows(a.fv_part, 0, a.fv_rows, sh);
-    if (c < 4) a.scal[SC_PL2_CAMS + c] = v; else if (c < kPartW) a.scal[SC_EA_INF + c - 4] = v;
-    v = reduce_rows(a.cu_part, 0, a.cu_rows, sh);
-    if (c < 4) a.scal[SC_DL_CAMS + c] = v;
-    v = reduce_rows(a.bs_part, 0, a.bs_rows, sh);
-    if (c < 4) a.bs_sum[c] = v; else if (c < kPartW) a.bs_max[c - 4] = v;
+    // the three sets of rows are fetched together (one round of memory latency), then reduced together
+    __shared__ double sh[3][16][kPartW];
+    const double *part[3] = { a.fv_part, a.cu_part, a.bs_part };
+    const int rows[3] = { a.fv_rows, a.cu_rows, a.bs_rows };
+    double acc[3][kPartW];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int c = 0; c < kPartW; ++c) acc[k][c] = 0.0;
+        for (int r = threadIdx.x; r < rows[k]; r += blockDim.x) {
+            const double *pr = part[k] + (size_t)r * kPartW;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[k][c] += pr[c];
+#pragma unroll
+            for (int c = 4; c < kPartW; ++c) acc[k][c] = fmax(acc[k][c], pr[c]);
+        }
+    }
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[k][c] = wave_sum(acc[k][c]);
+#pragma unroll
+        for (int c = 4; c < kPartW; ++c) acc[k][c] = wave_max(acc[k][c]);
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int c = 0; c < kPartW; ++c) sh[k][w][c] = acc[k][c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * kPartW) {
+        const int k = threadIdx.x / kPartW, c = threadIdx.x % kPartW, nw = blockDim.x >> 6;
+        double v = 0.0;
+        for (int i = 0; i < nw; ++i) v = (c < 4) ? v + sh[k][i][c] : fmax(v, sh[k][i][c]);
+        if (k == 0) { if (c < 4) a.scal[SC_PL2_CAMS + c] = v; else a.scal[SC_EA_INF + c - 4] = v; }
+        else if (k == 1) { if (c < 4) a.scal[SC_DL_CAMS + c] = v; }
+        else { if (c < 4) a.bs_sum[c] = v; else a.bs_max[c - 4] = v; }
+    }
     if (a.spec) {
         __threadfence_block();
         __syncthreads();
-        if (c == 0) lm_peek(a.scal, a.pk, a.spec);
+        if (threadIdx.x == 0) lm_peek(a.scal, a.pk, a.spec);
     }
 }
 
