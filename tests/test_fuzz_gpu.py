@@ -2,6 +2,8 @@
 sets that repeat and camera sets that never do -> register tiles, table tiles, direct tiles and long points in one
 problem), every parameterisation (cnp 6 / 7 / 8, both distortion models, t or C), bundle modes, fixed cameras, soft
 constraints -- the engine against the CPU oracle (itself pinned to the reference), trial by trial."""
+import os
+
 import numpy as np
 import pytest
 
@@ -45,7 +47,7 @@ CASES = [  # est_focal, undistort, explicit_centers, proj_sign, mode, mcon, cons
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_random_ragged_scenes_match_the_oracle(oracle, case):
     est_focal, undistort, explicit_centers, proj_sign, mode, mcon, cons = CASES[case]
-    rng = np.random.default_rng(1000 + case)
+    rng = np.random.default_rng(1000 + case + int(os.environ.get("MI_FUZZ_SEED_OFFSET", "0")))   # other scenes: set the offset
     sc = ragged_scene(rng, m=90, n=1200, est_focal=est_focal, undistort=undistort, explicit_centers=explicit_centers,
                       proj_sign=proj_sign, dmax=80)
     m, n, cnp = sc.m, sc.n, sc.cnp

@@ -19,14 +19,15 @@ def _case(kind):
     """scene, config keywords and the extras applied to an engine before prepare()"""
     from conftest import pkg as _pkg
     scene = _pkg("scene")
+    off = int(os.environ.get("MI_FUZZ_SEED_OFFSET", "0"))    # other scenes: set the offset
     if kind == "long":
         from helpers import ladybug_like_scene
-        return ladybug_like_scene(m=120, n=3000, dmax=90, seed=9), {}, lambda eng: None
+        return ladybug_like_scene(m=120, n=3000, dmax=90, seed=9 + off), {}, lambda eng: None
     if kind == "resume":   # every trial's first run of CG iterations falls short (engine.cpp solve_phase): the update phase -- and with
         os.environ["MI_BA_PCG_FIRST_RUN"] = "2"   # it the second exchange and its per-rank maxima slots -- runs twice per trial
-        return scene.make_scene("x", m=40, n=6000, d=6, seed=77), {}, lambda eng: None
+        return scene.make_scene("x", m=40, n=6000, d=6, seed=77 + off), {}, lambda eng: None
     if kind == "extras":   # radial coefficient, links between cameras, soft constraints on cameras and points: the camera-side
-        sc = scene.make_scene("x", m=40, n=6000, d=6, seed=78, undistort=1, nk=1)   # terms are replicated, the point-side sharded
+        sc = scene.make_scene("x", m=40, n=6000, d=6, seed=78 + off, undistort=1, nk=1)   # terms are replicated, the point-side sharded
         rng = np.random.default_rng(4)
         la = np.arange(0, 12); lb = (la + 1) % 12
         w = np.zeros((12, sc.cnp)); w[:, 6] = 2e6
@@ -39,7 +40,7 @@ def _case(kind):
             eng.set_camera_links(la, lb, w)
             eng.set_constraints(cam_w, cam_v, pt_w, pt_v)
         return sc, dict(undistort=1), extras
-    return scene.make_scene("x", m=40, n=6000, d=6, seed=77), {}, lambda eng: None
+    return scene.make_scene("x", m=40, n=6000, d=6, seed=77 + off), {}, lambda eng: None
 
 
 def _worker(rank, world, port, outdir, kind):
