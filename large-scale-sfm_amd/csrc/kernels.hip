@@ -14,17 +14,37 @@ namespace miba {
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
+// Wave-wide sum / maximum, the result in every lane.  Inside a row of 16 lanes the partner's value comes through DPP (quad
+// permutes, then the half-row and row mirrors), the four row totals through v_readlane: ~20 short instructions.  (The
+// butterfly of six __shfl_xor = twelve dependent ds_bpermute took ~0.5 us per double; the small kernels of a trial do
+// dozens of these.)  Call with all 64 lanes active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);   // row_half_mirror
+    v += dpp_move<0x140>(v);   // row_mirror: every lane holds its row's total
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    v = fmax(v, dpp_move<0xB1>(v));
+    v = fmax(v, dpp_move<0x4E>(v));
+    v = fmax(v, dpp_move<0x141>(v));
+    v = fmax(v, dpp_move<0x140>(v));
+    return fmax(fmax(lane_value(v, 0), lane_value(v, 16)), fmax(lane_value(v, 32), lane_value(v, 48)));
 }
 // max of non-negative doubles through the monotone bit pattern; NaN compares above everything
 __device__ __forceinline__ void atomic_max_pos(double *p, double v)
@@ -1040,31 +1060,37 @@ __device__ __forceinline__ void lm_peek(double *__restrict__ s, const PeekArgs &
 
 __global__ __launch_bounds__(1024) void k_reduce_final(const FinalReduceArgs a)
 {
-    // the three sets of rows are fetched together (one round of memory latency), then reduced together
+    // three sets of rows; each thread's first row of every set is requested before anything is added up, so the three sets
+    // cost one round of memory latency (they come from other XCDs' kernels: L2 misses), not three
     __shared__ double sh[3][16][kPartW];
+    const int w = threadIdx.x >> 6, tid = threadIdx.x;
     const double *part[3] = { a.fv_part, a.cu_part, a.bs_part };
     const int rows[3] = { a.fv_rows, a.cu_rows, a.bs_rows };
     double acc[3][kPartW];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        const double *pr = part[k] + (size_t)(tid < rows[k] ? tid : 0) * kPartW;
 #pragma unroll
-        for (int c = 0; c < kPartW; ++c) acc[k][c] = 0.0;
-        for (int r = threadIdx.x; r < rows[k]; r += blockDim.x) {
+        for (int c = 0; c < kPartW; ++c) acc[k][c] = pr[c];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (tid >= rows[k]) {
+#pragma unroll
+            for (int c = 0; c < kPartW; ++c) acc[k][c] = 0.0;
+        }
+        for (int r = tid + (int)blockDim.x; r < rows[k]; r += blockDim.x) {
             const double *pr = part[k] + (size_t)r * kPartW;
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[k][c] += pr[c];
 #pragma unroll
             for (int c = 4; c < kPartW; ++c) acc[k][c] = fmax(acc[k][c], pr[c]);
         }
-    }
-    const int w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[k][c] = wave_sum(acc[k][c]);
 #pragma unroll
         for (int c = 4; c < kPartW; ++c) acc[k][c] = wave_max(acc[k][c]);
-        if ((threadIdx.x & 63) == 0)
+        if ((tid & 63) == 0)
 #pragma unroll
             for (int c = 0; c < kPartW; ++c) sh[k][w][c] = acc[k][c];
     }
@@ -1186,35 +1212,35 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
     __shared__ double sb[4][64], so[4][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv;
     const bool live = j < m;
-    sb[wv][lane] = live ? finalized_element(f, bsr_diag[j], lane) : 0.0;
+    sb[wv][lane] = live ? finalized_element(f, bsr_diag[j], lane) : (lane % 9 == 0 ? 1.0 : 0.0);
     wave_lds_sync();
-    if (live && lane == 0) {
-        double L[8][8];
-        bool ok = true;
+    // right-looking Cholesky in LDS, lane (r, c): eight steps of (pivot, column, trailing update), the lower triangle of sb
+    // becomes L; then lane c solves L x = e_c for column c of L^-1.  (One lane doing all of it serially took 7 us.)
+    const int r = lane >> 3, c = lane & 7;
+    bool ok = true;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+    for (int k = 0; k < 8; ++k) {
+        double piv = sb[wv][k * 9];
+        if (!(piv > 0.0)) { ok = false; piv = 1.0; }
+        const double lkk = sqrt(piv);
+        const double lrk = sb[wv][r * 8 + k] / lkk, lck = sb[wv][c * 8 + k] / lkk;   // column k, rows r and c (used when > k)
+        wave_lds_sync();
+        if (c == k && r >= k) sb[wv][r * 8 + k] = (r == k) ? lkk : lrk;
+        if (r > k && c > k && c <= r) sb[wv][r * 8 + c] -= lrk * lck;
+        wave_lds_sync();
+    }
+    if (live && !ok && lane == 0) atomic_max_pos(&scal[SC_NOT_PD], 1.0);
+    if (lane < 8) { // column `lane` of L^-1 by forward substitution
+        double col[8];
 #pragma unroll
-            for (int c = 0; c <= r; ++c) {
-                double s = sb[wv][r * 8 + c];
+        for (int i = 0; i < 8; ++i) {
+            double v = (i == lane) ? 1.0 : 0.0;
 #pragma unroll
-                for (int k = 0; k < c; ++k) s -= L[r][k] * L[c][k];
-                if (r == c) { if (!(s > 0.0)) { ok = false; s = 1.0; } L[r][r] = sqrt(s); }
-                else L[r][c] = s / L[c][c];
-            }
-        if (!ok) atomic_max_pos(&scal[SC_NOT_PD], 1.0);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            double col[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (r < c) { col[r] = 0.0; so[wv][r * 8 + c] = 0.0; continue; }
-                double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < r; ++k) if (k >= c) s -= L[r][k] * col[k];
-                col[r] = s / L[r][r];
-                so[wv][r * 8 + c] = col[r];
-            }
+            for (int q = 0; q < i; ++q) v -= sb[wv][i * 8 + q] * col[q];
+            col[i] = (i < lane) ? 0.0 : v / sb[wv][i * 9];
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) so[wv][i * 8 + lane] = col[i];
     }
     wave_lds_sync();
     if (live) {
