@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
                 if constexpr (!LDS) sLp[lane] = lp;
             }
             // point boundaries without touching memory: observations of a point are consecutive lanes
-            const int lp_prev = __shfl_up(active ? lp : -2, 1);
+            const int lp_prev = __builtin_amdgcn_update_dpp(-2, active ? lp : -2, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -2)
             head = active && (lane == 0 || lp != lp_prev);
             if (head) {
                 sStart[lp] = lane; pl2 += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
@@ -1340,7 +1340,7 @@ __device__ __forceinline__ void publish_partials(const PcgArgs &a, int slot, dou
 // element (r,c) of each 8x8 block (a 512-B contiguous wave load) with element c of the neighbour's vectors; eight
 // independent block loads in flight (with one at a time the MALL-resident S streams at only ~3 TB/s, and a wavefront that
 // waits out a round of memory latency per four blocks spends most of a launch waiting); the sum over c by three
-// xor-shuffles leaves row r's value in all 8 lanes of the row
+// DPP moves leaves row r's value in all 8 lanes of the row
 template <int NV>
 __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, int stride, int lane, const double *const (&vec)[NV], double (&out)[NV])
 {
@@ -1373,7 +1373,7 @@ __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, i
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         double t = (acc[v][0] + acc[v][1]) + (acc[v][2] + acc[v][3]);
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4);
+        t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t); t += dpp_move<0x141>(t);   // the 8 lanes of a row: quad permutes, half-row mirror
         out[v] = t;
     }
 }
@@ -1593,7 +1593,7 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
         if (b + 1 < b1) load_stream(b + 1);
         // everything this batch needs from HBM, requested now
         const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
-        const int lp_prev = __shfl_up(active ? lp : -2, 1);
+        const int lp_prev = __builtin_amdgcn_update_dpp(-2, active ? lp : -2, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -2)
         const bool head = active && (lane == 0 || lp != lp_prev);
         double2 po[6];
         if (head) {
