@@ -122,7 +122,7 @@ struct PcgArgs {
     double tol;
     int last;                                          // k_pcg_tail: no iteration will follow this one
     int tail;                                          // k_cam_update: do k_pcg_tail's work as well
-    int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init / k_pcg_finish); product kernels: nwg = m (one block row per
+    int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init); product kernels: nwg = m (one block row per
                                                        // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
 };
 
