@@ -110,6 +110,7 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         eng.comm_init(bytes(uid.cpu().numpy().tobytes()))
+    eng.set_timing_detail(1)            # HIP events around the build kernels: the roofline figure is measured in the timed steps
     eng.load_scene(sc)
     t0 = time.time()
     eng.prepare()

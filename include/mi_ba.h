@@ -160,9 +160,9 @@ typedef struct {
 } mi_ba_timing;
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_reset_timing(mi_ba_engine *e);
-/* which phases are bracketed by HIP events: 0 none, 1 (default) the build kernels only, 2 also the reduced solve and the
- * back-substitution.  An event on the stream costs ~5 us of idle GPU, so the per-phase breakdown is something to ask for
- * (bench.py takes it in a second, untimed pass), not something every trial pays. */
+/* which phases are bracketed by HIP events: 0 (default) none, 1 the build kernels, 2 also the reduced solve and the
+ * back-substitution.  An event on the stream costs ~6 us of idle GPU, so device-side times are something to ask for
+ * (bench.py: level 1 in its timed steps, level 2 in a second, untimed pass), not something every trial pays. */
 int mi_ba_set_timing_detail(mi_ba_engine *e, int level);
 
 /* ---- multi-GPU: one process per GPU, points sharded, RCCL all-reduce of the Schur partials */

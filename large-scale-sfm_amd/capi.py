@@ -259,7 +259,7 @@ class Engine:
         self.L.mi_ba_reset_timing(self.h)
 
     def set_timing_detail(self, level: int):
-        """0 no HIP events, 1 (default) around the build kernels, 2 also around the reduced solve and the back-substitution"""
+        """0 (default) no HIP events, 1 around the build kernels, 2 also around the reduced solve and the back-substitution"""
         self.L.mi_ba_set_timing_detail(self.h, int(level))
 
 

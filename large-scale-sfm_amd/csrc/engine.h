@@ -70,7 +70,7 @@ public:
     std::string err;
     std::vector<double> trace;   // 6 doubles per trial
     mi_ba_timing timing{};
-    int timing_detail = 1;   // mi_ba_set_timing_detail
+    int timing_detail = 0;   // mi_ba_set_timing_detail
 
 private:
     bool fail(const std::string &msg) { err = msg; return false; }
