@@ -76,7 +76,10 @@ def test_random_ragged_scenes_match_the_oracle(oracle, case):
     # trial costs and accept / reject decisions; the truncated drivers finish with a few trials whose cost changes are at
     # rounding level, where the order of the GPU's atomic sums decides the sign of dF: those are left out
     k = max(1, min(len(tr), len(to)) - 4) if mode else len(to)
-    assert np.allclose(tr[:k, 3], to[:k, 3], rtol=1e-6) and np.array_equal(tr[:k, 4], to[:k, 4])
+    assert np.allclose(tr[:k, 3], to[:k, 3], rtol=1e-6)
+    # (a trial that changes the cost by less than 1e-9 of it is accepted or rejected on rounding noise -- in the oracle too)
+    decided = np.abs(to[:k, 3] - to[:k, 2]) > 1e-9 * to[:k, 2] if mode else np.ones(k, bool)
+    assert np.array_equal(tr[:k, 4][decided], to[:k, 4][decided])
     if mcon or cons or mode:
         # (truncated drivers: a point seen once slides along its ray, a camera with a handful of views along its weak
         #  directions, at next to no cost -- where the rounding-level tail stops moves them by ~1e-4; the cost is the check)
