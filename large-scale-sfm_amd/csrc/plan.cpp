@@ -1,9 +1,14 @@
 // plan.cpp -- see plan.h.  Pure host code (no HIP); exported through mi_ba_plan_* for CPU tests.
 #include "plan.h"
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <unordered_map>
 
 namespace miba {
@@ -30,6 +35,20 @@ inline double point_weight(int d) { return (double)d + 0.5 * (double)d * (d + 1)
 
 } // namespace
 
+// fn(begin, end) over [0, n) on a few host threads (the loops below touch every observation once and are independent per point)
+template <class F>
+static void parallel_ranges(int n, F fn)
+{
+    const int nt = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (nt <= 1 || n < (1 << 16)) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    for (int k = 0; k < nt; ++k) {
+        const int b = (int)((int64_t)n * k / nt), e = (int)((int64_t)n * (k + 1) / nt);
+        th.emplace_back([=]() { fn(b, e); });
+    }
+    for (auto &t : th) t.join();
+}
+
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
                        int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs)
 {
@@ -41,6 +60,15 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     if (auto_tile || tile_max_batches > kMaxTileBatches) tile_max_batches = kMaxTileBatches;
     pl = Plan();
     pl.n = n; pl.m = m; pl.nobs = nobs; pl.rank = rank; pl.world = world;
+    // MI_BA_PLAN_TIMING=1: where the planner's time goes, stage by stage, to stderr
+    const bool timing = std::getenv("MI_BA_PLAN_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[mi_ba plan] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
 
     // ---- CSR by point, cameras ascending inside a point
     std::vector<int> pt_ptr(n + 1, 0);
@@ -55,24 +83,29 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     std::vector<int> cam(nobs);
     std::vector<int64_t> src(nobs);
     {
-        std::vector<std::pair<int, int64_t>> tmp;
-        for (int i = 0; i < n; ++i) {
-            int b = pt_ptr[i], e = pt_ptr[i + 1];
-            bool sorted = true;
-            for (int o = b + 1; o < e; ++o) if (cam_idx[o - 1] >= cam_idx[o]) { sorted = false; break; }
-            if (sorted) {
-                for (int o = b; o < e; ++o) { cam[o] = cam_idx[o]; src[o] = o; }
-            } else {
-                tmp.clear();
-                for (int o = b; o < e; ++o) tmp.emplace_back(cam_idx[o], (int64_t)o);
-                std::sort(tmp.begin(), tmp.end());
-                for (int o = b; o < e; ++o) { cam[o] = tmp[o - b].first; src[o] = tmp[o - b].second; }
-                for (int o = b + 1; o < e; ++o)
-                    if (cam[o] == cam[o - 1]) return "a point is observed twice by the same camera";
+        std::atomic<bool> twice(false);
+        parallel_ranges(n, [&](int i0, int i1) {
+            std::vector<std::pair<int, int64_t>> tmp;
+            for (int i = i0; i < i1; ++i) {
+                int b = pt_ptr[i], e = pt_ptr[i + 1];
+                bool sorted = true;
+                for (int o = b + 1; o < e; ++o) if (cam_idx[o - 1] >= cam_idx[o]) { sorted = false; break; }
+                if (sorted) {
+                    for (int o = b; o < e; ++o) { cam[o] = cam_idx[o]; src[o] = o; }
+                } else {
+                    tmp.clear();
+                    for (int o = b; o < e; ++o) tmp.emplace_back(cam_idx[o], (int64_t)o);
+                    std::sort(tmp.begin(), tmp.end());
+                    for (int o = b; o < e; ++o) { cam[o] = tmp[o - b].first; src[o] = tmp[o - b].second; }
+                    for (int o = b + 1; o < e; ++o)
+                        if (cam[o] == cam[o - 1]) twice = true;
+                }
             }
-        }
+        });
+        if (twice) return "a point is observed twice by the same camera";
     }
 
+    stage("CSR by point");
     // ---- permutation: class, then visibility signature (lexicographic camera list)
     pl.perm.resize(n);
     std::iota(pl.perm.begin(), pl.perm.end(), 0);
@@ -90,7 +123,42 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         }
         return a < b;
     };
-    std::sort(pl.perm.begin(), pl.perm.end(), by_class_then_signature);
+    // The benchmark scenes hold a few thousand distinct signatures, each shared by hundreds of points, and a comparison of
+    // two equal camera lists is the expensive kind (all of it, then the index).  So: group the points by a hash of (class,
+    // camera list), sort one representative per group with the comparator, and emit the groups' members in index order --
+    // the same permutation as sorting every point, at a fraction of the comparisons.  A hash collision (two different lists
+    // in one group) falls back to the plain sort.
+    {
+        std::vector<std::pair<uint64_t, int>> hashed(n);
+        for (int i = 0; i < n; ++i) {
+            uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(cls[i] + 1);
+            if (cls[i] == 0 || cls[i] == 1) {
+                const int *p = cam.data() + pt_ptr[i];
+                for (int t = 0, d = deg(i); t < d; ++t) { h ^= (uint64_t)(p[t] + 1); h *= 0x100000001B3ull; h ^= h >> 29; }
+            }
+            hashed[i] = { h, i };
+        }
+        std::sort(hashed.begin(), hashed.end());
+        std::vector<int> rep, first;                   // per group: representative point, start in hashed[]
+        bool collision = false;
+        for (int q = 0; q < n && !collision; ++q) {
+            if (q == 0 || hashed[q].first != hashed[q - 1].first) { rep.push_back(hashed[q].second); first.push_back(q); continue; }
+            const int a = rep.back(), b = hashed[q].second;
+            if (cls[a] != cls[b]) collision = true;
+            else if (cls[a] == 0 || cls[a] == 1)
+                collision = deg(a) != deg(b) || std::memcmp(cam.data() + pt_ptr[a], cam.data() + pt_ptr[b], sizeof(int) * (size_t)deg(a)) != 0;
+        }
+        if (collision) std::sort(pl.perm.begin(), pl.perm.end(), by_class_then_signature);
+        else {
+            first.push_back(n);
+            std::vector<int> order(rep.size());
+            std::iota(order.begin(), order.end(), 0);
+            std::sort(order.begin(), order.end(), [&](int x, int y) { return by_class_then_signature(rep[x], rep[y]); });
+            int w = 0;
+            for (int g : order)
+                for (int q = first[g]; q < first[g + 1]; ++q) pl.perm[w++] = hashed[q].second;   // index order inside a group
+        }
+    }
     if (kMinRunObs > 0) { // optional: points whose camera set hardly repeats -> direct tiles (see plan.h: measured slower, off)
         bool changed = false;
         int t0 = 0;
@@ -107,6 +175,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     pl.n_active = 0;
     for (int i = 0; i < n; ++i) if (deg(i) > 0) pl.n_active++;
 
+    stage("signature sort");
     // ---- shard cut (contiguous internal ranges, balanced by observations + pairs)
     {
         double total = 0;
@@ -188,28 +257,32 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             }
     }
 
+    stage("shard cut + pattern of S");
     // ---- local shard arrays
     const int npl = pl.pt_end - pl.pt_begin;
     pl.pt_obs.assign(npl + 1, 0);
     for (int t = 0; t < npl; ++t) pl.pt_obs[t + 1] = pl.pt_obs[t] + deg(pl.perm[pl.pt_begin + t]);
     const int nol = pl.pt_obs[npl];
     pl.obs_cam.resize(nol); pl.obs_pt.resize(nol); pl.obs_src.resize(nol); pl.obs_cslot.assign(nol, 0);
-    for (int t = 0; t < npl; ++t) {
-        int i = pl.perm[pl.pt_begin + t], d = deg(i);
-        for (int a = 0; a < d; ++a) {
-            int o = pl.pt_obs[t] + a;
-            pl.obs_cam[o] = cam[pt_ptr[i] + a];
-            pl.obs_src[o] = src[pt_ptr[i] + a];
-            pl.obs_pt[o] = t;
+    parallel_ranges(npl, [&](int t0, int t1) {
+        for (int t = t0; t < t1; ++t) {
+            int i = pl.perm[pl.pt_begin + t], d = deg(i);
+            for (int a = 0; a < d; ++a) {
+                int o = pl.pt_obs[t] + a;
+                pl.obs_cam[o] = cam[pt_ptr[i] + a];
+                pl.obs_src[o] = src[pt_ptr[i] + a];
+                pl.obs_pt[o] = t;
+            }
         }
-    }
+    });
 
     // ---- batches and tiles (as a lambda: the automatic tile length needs a first pass to see where the
     // slot / camera budgets force tiles to end)
     std::vector<std::pair<int, bool>> tile_log; // per LDS tile: batches, closed only because of the length cap
     int t = 0;
     std::string tiling_error;
-    auto do_tiling = [&](int tile_max_batches) {
+    // dry: only the shape of the LDS tiles (tile_log) is wanted -- no pair entries, no slots per observation, class 0 only
+    auto do_tiling = [&](int tile_max_batches, bool dry) {
     tile_log.clear();
     pl.pair.clear(); pl.pair_gblk.clear(); pl.slot_gblk.clear(); pl.cslot_cam.clear(); pl.tile_mode.clear();
     pl.long_pts.clear(); pl.max_slots = 0;
@@ -219,6 +292,8 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     std::unordered_map<uint64_t, int> smap;
     std::unordered_map<int, int> cmap;
     std::vector<int> sig_slots;       // slots of the previous point's pairs (signature cache)
+    std::vector<uint8_t> sig_cslots;  // camera slots of the previous point's observations (signature cache)
+    size_t round_fill = 0;            // entries in the round being filled (= round_buf.size() unless dry)
     const int *sig_cams = nullptr; int sig_d = -1;
     int cur_obs = 0, batches_in_tile = 0, sig_runs_in_tile = 0;
     t = 0;
@@ -229,8 +304,10 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     int pts_in_batch = 0;
     int rounds_in_batch = 0;
     auto flush_round = [&]() {
-        if (round_buf.empty()) return;
+        if (round_fill == 0) return;
         rounds_in_batch++;
+        round_fill = 0;
+        if (dry) return;
         round_buf.resize(kWave, kPairInvalid);
         pl.pair.insert(pl.pair.end(), round_buf.begin(), round_buf.end());
         round_buf.clear();
@@ -238,7 +315,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     auto close_batch = [&](int t_end) {
         if (cur_obs == 0) return;
         if (rounds_mode) flush_round();
-        else {
+        else if (!dry) {
             // direct tiles: the batch's pairs in block order, so that pairs of different points that land on the same
             // block sit in neighbouring lanes and the kernel merges them before the atomic (k_build, direct branch)
             const size_t q0 = (size_t)pl.batch_pair.back(), q1 = pl.pair.size(), base = (size_t)pl.npair_lds;
@@ -277,7 +354,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         const int *c = pl.obs_cam.data() + pl.pt_obs[t];
         bool same_sig = (d == sig_d && sig_cams && std::memcmp(sig_cams, c, sizeof(int) * d) == 0);
         // a point that would open a 9th pair round starts a new batch
-        const bool round_full = (int)round_buf.size() + d * (d + 1) / 2 > kWave;
+        const bool round_full = (int)round_fill + d * (d + 1) / 2 > kWave;
         if (cur_obs + d > kWave || pts_in_batch >= kMaxPtsBatch || (round_full && rounds_in_batch + 1 >= kMaxRounds)) {
             close_batch(t);
             if (batches_in_tile >= tile_max_batches) { close_tile(1); same_sig = false; }
@@ -293,13 +370,15 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                 close_tile(1);
             }
             sig_runs_in_tile++;
-            sig_slots.clear();
+            sig_slots.clear(); sig_cslots.clear();
             for (int a = 0; a < d; ++a) {
-                if (!cmap.count(c[a])) {
+                auto ic = cmap.find(c[a]);
+                if (ic == cmap.end()) {
                     int cs = (int)cmap.size();
-                    cmap[c[a]] = cs;
+                    ic = cmap.emplace(c[a], cs).first;
                     pl.cslot_cam.push_back(c[a]);
                 }
+                sig_cslots.push_back((uint8_t)ic->second);
                 for (int b = a; b < d; ++b) {
                     uint64_t key = ((uint64_t)c[a] << 32) | (uint32_t)c[b];
                     auto it = smap.find(key);
@@ -316,18 +395,22 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             }
             sig_cams = c; sig_d = d;
         }
-        if ((int)round_buf.size() + d * (d + 1) / 2 > kWave) flush_round();
-        int q = 0;
-        for (int a = 0; a < d; ++a) {
-            pl.obs_cslot[pl.pt_obs[t] + a] = (uint8_t)cmap[c[a]];
-            for (int b = a; b < d; ++b)
-                round_buf.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6) | ((uint32_t)sig_slots[q++] << 12) |
-                                    ((uint32_t)pts_in_batch << 18));
+        if ((int)round_fill + d * (d + 1) / 2 > kWave) flush_round();
+        round_fill += (size_t)d * (d + 1) / 2;
+        if (!dry) {
+            int q = 0;
+            for (int a = 0; a < d; ++a) {
+                pl.obs_cslot[pl.pt_obs[t] + a] = sig_cslots[a];
+                for (int b = a; b < d; ++b)
+                    round_buf.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6) | ((uint32_t)sig_slots[q++] << 12) |
+                                        ((uint32_t)pts_in_batch << 18));
+            }
         }
         cur_obs += d; pts_in_batch++;
     }
     close_batch(t);
     close_tile(1);
+    if (dry) return;
     pl.npair_lds = (int64_t)pl.pair.size();
     pl.ntile_lds = pl.ntile();
     pl.nbatch_lds = pl.nbatch();
@@ -358,8 +441,10 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     for (; t < npl; ++t) pl.long_pts.push_back(t);
     };
 
-    do_tiling(tile_max_batches);
+    stage("local shard arrays");
+    do_tiling(tile_max_batches, auto_tile);   // automatic tile length: a dry pass first, to see where the budgets force tiles to end
     if (!tiling_error.empty()) return tiling_error;
+    stage(auto_tile ? "tiling, dry pass" : "tiling");
     if (auto_tile) {
         // k_build runs 4 one-wave workgroups per CU = kTileSlots tiles at a time.  Natural segments = runs of
         // batches between two forced tile ends; choose the length cap whose tile count fills whole rounds of
@@ -379,7 +464,9 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             const double cost = (double)rounds * ((double)longest + 1.5);
             if (cost < best * 0.999) { best = cost; best_tmb = tmb; }
         }
-        if (best_tmb != tile_max_batches) { do_tiling(best_tmb); if (!tiling_error.empty()) return tiling_error; }
+        do_tiling(best_tmb, false);
+        if (!tiling_error.empty()) return tiling_error;
+        stage("tile length + tiling");
     }
     // batches for the back-substitution: the same points, packed 64 observations at a time whatever the tiles of the
     // build look like (a tile boundary closes a build batch; on scenes with ever-changing camera sets that leaves one
