@@ -28,6 +28,12 @@ typedef struct mi_model mi_model;
 mi_model *mi_model_load_nvm(const char *path);     /* NULL on failure, reason in mi_model_last_error() */
 mi_model *mi_model_load_bal(const char *path);
 mi_model *mi_model_load_bundler_out(const char *path);
+/* the five files the stage programs write before they start optimizer_all (SiftGPU/TriangulationMultiStep.cpp:1024-1088,
+ * MergeClusters.cpp:1009-1052): RTglobalmapped_for_optimisation.txt (R, then the camera CENTRE: t = -R C),
+ * focal_for_optimisation.txt ("ncam" / "camName focal 2"), ours_new.txt ("X Y Z r g b n {camLocalIdx pointId x y}*"),
+ * and optionally Invmap.txt ("localIdx camName": the names of the output) and Distortion.txt (one coefficient per camera).
+ * The writer is mi_model_save_merge_side_files (mi_merge.h). */
+mi_model *mi_model_load_side_files(const char *dir);
 int mi_model_save_nvm(const mi_model *mdl, const char *path);
 int mi_model_save_bal(const mi_model *mdl, const char *path);
 int mi_model_save_bundler_out(const mi_model *mdl, const char *path);   /* also writes <name>-list.txt */
@@ -71,7 +77,8 @@ int mi_model_optimize_shard(mi_model *mdl, const mi_ba_config *cfg, double info[
 double mi_model_rmse(const mi_model *mdl);
 
 /* the process ABI:  optimizer_all <dir>/ A B C D E F   (SiftGPU/MergeClusters.cpp:1099-1110).
- * Reads <dir>/outputVSFM_GB.nvm, refines, overwrites it.  Returns the process exit status.
+ * Input: the side files above when <dir> holds them (at two of the six call sites they are the only input), else
+ * <dir>/outputVSFM_GB.nvm; refines; writes <dir>/outputVSFM_GB.nvm.  Returns the process exit status.
  * MI_BA_GPUS=N in the environment: the process forks N - 1 further ranks before it touches HIP, one GPU each
  * (MI_BA_DEVICE + rank), points sharded, RCCL all-reduce per trial; rank 0 writes the file. */
 int mi_optimizer_all_main(int argc, char **argv);

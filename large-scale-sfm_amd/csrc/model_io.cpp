@@ -191,6 +191,70 @@ mi_model *mi_model_load_nvm(const char *path)
     return m;
 }
 
+// The input half of the optimizer_all file contract: what the stage programs write before system("../bin/optimizer_all ...")
+// (SiftGPU/TriangulationMultiStep.cpp:1024-1095 and :1308-1382 write ONLY these; MergeClusters.cpp:1009-1052 and
+// Merge3D3D.cpp:811-860 write them beside an NVM):
+//   RTglobalmapped_for_optimisation.txt   per camera: 9 numbers R (row-major), then 3 numbers camera CENTRE  ->  t = -R C
+//   focal_for_optimisation.txt            "ncam", then per camera "camName focal 2"
+//   Invmap.txt                            per camera "localIndex camName"     (names of the output NVM; optional)
+//   ours_new.txt                          per point "X Y Z r g b n {camLocalIdx pointId x y}*"
+//   Distortion.txt                        one radial coefficient per camera   (optional; every writer emits 0.000)
+mi_model *mi_model_load_side_files(const char *dir_c)
+{
+    if (!dir_c) { g_err = "side files: null directory"; return nullptr; }
+    std::string dir = dir_c;
+    if (!dir.empty() && dir.back() != '/') dir += '/';
+    Scanner rt, fo, pts;
+    if (!rt.open((dir + "RTglobalmapped_for_optimisation.txt").c_str())) { g_err = "cannot open " + dir + "RTglobalmapped_for_optimisation.txt"; return nullptr; }
+    if (!fo.open((dir + "focal_for_optimisation.txt").c_str())) { g_err = "cannot open " + dir + "focal_for_optimisation.txt"; return nullptr; }
+    if (!pts.open((dir + "ours_new.txt").c_str())) { g_err = "cannot open " + dir + "ours_new.txt"; return nullptr; }
+    int ncam = 0;
+    fo.get_int(ncam);
+    if (!fo.ok() || ncam <= 0) { g_err = "focal_for_optimisation.txt: bad camera count"; return nullptr; }
+    mi_model *m = new mi_model;
+    m->names.resize(ncam); m->f.resize(ncam); m->R.resize((size_t)ncam * 9); m->t.resize((size_t)ncam * 3); m->d.assign((size_t)ncam * 2, 0.0);
+    for (int j = 0; j < ncam; ++j) {
+        int flag = 0;
+        double c[3];
+        fo.get(m->names[j]); fo.get(m->f[j]); fo.get_int(flag);
+        double *R = &m->R[(size_t)j * 9], *t = &m->t[(size_t)j * 3];
+        for (int r = 0; r < 9; ++r) rt.get(R[r]);
+        rt.get(c[0]); rt.get(c[1]); rt.get(c[2]);
+        for (int r = 0; r < 3; ++r) t[r] = -(R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2]);   // getTfromRC, MergeClusters.cpp:133-137
+    }
+    if (!fo.ok()) { g_err = "focal_for_optimisation.txt: truncated"; delete m; return nullptr; }
+    if (!rt.ok()) { g_err = "RTglobalmapped_for_optimisation.txt: fewer than 12 numbers per camera"; delete m; return nullptr; }
+    Scanner inv, dist;
+    if (inv.open((dir + "Invmap.txt").c_str())) {
+        while (inv.peek() != '\0') {
+            int idx = -1; std::string name;
+            inv.get_int(idx); inv.get(name);
+            if (!inv.ok()) break;
+            if (idx < 0 || idx >= ncam) { g_err = "Invmap.txt: camera index out of range"; delete m; return nullptr; }
+            m->names[idx] = name;
+        }
+    }
+    if (dist.open((dir + "Distortion.txt").c_str()))
+        for (int j = 0; j < ncam && dist.peek() != '\0'; ++j) dist.get(m->d[2 * (size_t)j]);
+    while (pts.peek() != '\0') {
+        double X[3]; int rgb[3], nview = 0;
+        pts.get(X[0]); pts.get(X[1]); pts.get(X[2]); pts.get_int(rgb[0]); pts.get_int(rgb[1]); pts.get_int(rgb[2]); pts.get_int(nview);
+        if (!pts.ok() || nview < 0) { g_err = "ours_new.txt: truncated point record"; delete m; return nullptr; }
+        const int i = (int)m->npt();
+        m->xyz.insert(m->xyz.end(), X, X + 3); m->rgb.insert(m->rgb.end(), rgb, rgb + 3);
+        for (int v = 0; v < nview; ++v) {
+            int cidx = -1; long long pid = 0; double x = 0, y = 0;
+            pts.get_int(cidx); pts.get_int(pid); pts.get(x); pts.get(y);
+            if (!pts.ok()) { g_err = "ours_new.txt: truncated track"; delete m; return nullptr; }
+            if (cidx < 0 || cidx >= ncam) { g_err = "ours_new.txt: camera index out of range"; delete m; return nullptr; }
+            m->cam_idx.push_back(cidx); m->pt_idx.push_back(i); m->feat_id.push_back(pid);
+            m->xy.push_back(x); m->xy.push_back(y);
+        }
+    }
+    if (m->npt() == 0) { g_err = "ours_new.txt: no points"; delete m; return nullptr; }
+    return m;
+}
+
 int mi_model_save_nvm(const mi_model *m, const char *path)
 {
     if (!m) return MI_BA_ERROR;
@@ -598,11 +662,37 @@ static int rank_host_allreduce(void *user, double *buf, int64_t count, int op)
     return 0;
 }
 
+// what an NVM and the side files of one directory disagree on, in words ("" = they describe the same model to the
+// side files' printing precision: %.9lf cameras, %lf = 6 decimals points and measurements)
+static std::string describe_disagreement(const mi_model &a /* side files */, const mi_model &b /* NVM */)
+{
+    char buf[256];
+    if (a.ncam() != b.ncam() || a.npt() != b.npt() || a.nproj() != b.nproj()) {
+        std::snprintf(buf, sizeof buf, "side files %zu cameras / %zu points / %zu projections, NVM %zu / %zu / %zu",
+                      a.ncam(), a.npt(), a.nproj(), b.ncam(), b.npt(), b.nproj());
+        return buf;
+    }
+    auto maxdiff = [](const std::vector<double> &x, const std::vector<double> &y) {
+        double d = 0;
+        for (size_t i = 0; i < x.size(); ++i) d = std::max(d, std::fabs(x[i] - y[i]) / (1.0 + std::fabs(y[i])));
+        return d;
+    };
+    const double dr = maxdiff(a.R, b.R), dt = maxdiff(a.t, b.t), df = maxdiff(a.f, b.f), dx = maxdiff(a.xyz, b.xyz), dm = maxdiff(a.xy, b.xy);
+    if (dr > 1e-7 || dt > 1e-6 || df > 1e-7 || dx > 1e-5 || dm > 1e-5 || a.cam_idx != b.cam_idx) {
+        std::snprintf(buf, sizeof buf, "relative differences R %.2g, t %.2g, f %.2g, points %.2g, measurements %.2g%s", dr, dt, df, dx, dm,
+                      a.cam_idx != b.cam_idx ? ", different tracks" : "");
+        return buf;
+    }
+    return "";
+}
+
 // optimizer_all <dir>/ A B C D E F.  The reference's main (Optimizer/main_all.cpp) is missing from its
 // tree, so the meaning of A..F is the one documented in INTEGRATION.md:
 //   A  which blocks are free (utils.h:112 whatToCalibrate): < 0 -> intrinsics held (cnp 6), >= 0 -> pose + focal (cnp 7)
 //   B  maximum LM iterations          C, D  accepted, unused (always 16 / 32 at the call sites)
 //   E  accepted, unused (curErrorThresh, utils.cpp:35)        F  back end selector: every value runs this engine
+// Input: the side files the callers write (mi_model_load_side_files; at the two TriangulationMultiStep call sites they are the
+// ONLY input, :1024-1095, :1308-1382); <dir>/outputVSFM_GB.nvm only when they are absent.  Output: <dir>/outputVSFM_GB.nvm.
 // Environment: MI_BA_DEVICE (first GPU, default 0), MI_BA_GPUS (ranks = GPUs, default 1), MI_BA_TRANSPORT (rccl | host).
 int mi_optimizer_all_main(int argc, char **argv)
 {
@@ -614,10 +704,29 @@ int mi_optimizer_all_main(int argc, char **argv)
     if (!dir.empty() && dir.back() != '/') dir += '/';
     const int A = argc > 2 ? std::atoi(argv[2]) : 0;
     const int B = argc > 3 ? std::atoi(argv[3]) : 50;
+    std::printf("optimizer_all: A=%d (%s), B=%d LM iterations at most; ignored: C=%s D=%s E=%s F=%s (meaning not recoverable: the reference's main_all.cpp is missing)\n",
+                A, A >= 0 ? "poses, focal lengths and points free" : "focal lengths held", B > 0 ? B : 1,
+                argc > 4 ? argv[4] : "-", argc > 5 ? argv[5] : "-", argc > 6 ? argv[6] : "-", argc > 7 ? argv[7] : "-");
     const std::string nvm = dir + "outputVSFM_GB.nvm";
     const auto t_start = std::chrono::steady_clock::now();
     auto seconds = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
-    mi_model *m = mi_model_load_nvm(nvm.c_str());
+    auto exists = [&](const char *name) { return access((dir + name).c_str(), R_OK) == 0; };
+    const bool have_side = exists("RTglobalmapped_for_optimisation.txt") && exists("focal_for_optimisation.txt") && exists("ours_new.txt");
+    mi_model *m = nullptr;
+    if (have_side) {
+        m = mi_model_load_side_files(dir.c_str());
+        if (m && exists("outputVSFM_GB.nvm")) {   // both: the side files are what the caller just wrote, the NVM may be a stage behind
+            mi_model *old = mi_model_load_nvm(nvm.c_str());
+            const std::string diff = old ? describe_disagreement(*m, *old) : std::string("the NVM does not parse: ") + g_err;
+            if (!diff.empty()) std::printf("optimizer_all: %s and the side files disagree (%s); the side files win\n", nvm.c_str(), diff.c_str());
+            mi_model_free(old);
+        }
+        if (m) std::printf("optimizer_all: input = RTglobalmapped_for_optimisation.txt + focal_for_optimisation.txt + ours_new.txt%s%s\n",
+                           exists("Invmap.txt") ? " + Invmap.txt" : "", exists("Distortion.txt") ? " + Distortion.txt" : "");
+    } else {
+        m = mi_model_load_nvm(nvm.c_str());
+        if (m) std::printf("optimizer_all: no side files in %s, input = outputVSFM_GB.nvm\n", dir.c_str());
+    }
     const double t_load = seconds();
     if (!m) { std::fprintf(stderr, "optimizer_all: %s\n", mi_model_last_error()); return 1; }
     mi_ba_config cfg;

@@ -57,11 +57,11 @@ def build(force: bool = False) -> None:
 
 
 @contextmanager
-def quiet_stdout():
-    """silence printf from C (the reference prints every accepted step, sba_levmar.c:1563)."""
+def quiet_stdout(to: str | None = None):
+    """silence printf from C (the reference prints every accepted step, sba_levmar.c:1563), or keep it in a file."""
     sys.stdout.flush()
     saved = os.dup(1)
-    devnull = os.open(os.devnull, os.O_WRONLY)
+    devnull = os.open(os.devnull, os.O_WRONLY) if to is None else os.open(to, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
     os.dup2(devnull, 1)
     try:
         yield
@@ -138,7 +138,8 @@ class Reference:
         self.lib = C.CDLL(REF_SO)
         self.lib.ref_sba_motstr.restype = C.c_int
 
-    def run(self, sc, p0=None, itmax=150, opts=BUNDLER_OPTS, mcon=0, verbose=0, want_blocks=False):
+    def run(self, sc, p0=None, itmax=150, opts=BUNDLER_OPTS, mcon=0, verbose=0, want_blocks=False, log_path=None):
+        """log_path: file that receives the reference's own printf output (verbose 2: one line per damping trial)"""
         p = np.array(sc.p0 if p0 is None else p0, np.float64, copy=True)
         pt_ptr = np.ascontiguousarray(sc.pt_ptr, np.int32); obs_cam = np.ascontiguousarray(sc.obs_cam, np.int32)
         x = np.ascontiguousarray(sc.x, np.float64); R0 = np.ascontiguousarray(sc.R0, np.float64)
@@ -150,7 +151,7 @@ class Reference:
         if want_blocks:
             V = np.zeros((n, 3, 3)); S = np.zeros((m * cnp, m * cnp)); U = np.zeros((m, cnp, cnp))
             W = np.zeros((m * cnp, n * 3))
-        with quiet_stdout():
+        with quiet_stdout(log_path):
             ret = self.lib.ref_sba_motstr(n, m, mcon, cnp, _i(pt_ptr), _i(obs_cam), _d(x), _d(p), _d(R0), _d(ff),
                                           sc.est_focal, sc.undistort, sc.explicit_centers, itmax, verbose, o6,
                                           _d(info), _d(V), _d(S), _d(U), _d(W), getattr(sc, "nk", 2),

@@ -35,6 +35,47 @@ def write_nvm(path, sc, p=None, names=None):
             fo.write("\n")
 
 
+def write_side_files(d, sc, p=None, cam_names=None, distortion=True, invmap=True, drop_points=()):
+    """the five files a stage program leaves before system("../bin/optimizer_all ..."), with the reference's own printf formats
+    (SiftGPU/TriangulationMultiStep.cpp:1031-1088): R and the camera CENTRE with %.9lf, "camName focal 2", "index camName",
+    "0.000" per camera, and per point "%lf %lf %lf 255 255 255 n " + "%d %lld %lf %lf " per view.  No NVM is written."""
+    import os
+    p = sc.p0 if p is None else p
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    a = p[:m * cnp].reshape(m, cnp)
+    X = p[m * cnp:].reshape(n, 3)
+    R = np.einsum("mij,mjk->mik", rodrigues(a[:, 3:6]), sc.R0.reshape(m, 3, 3))
+    Cc = -np.einsum("mji,mj->mi", R, a[:, :3])                      # C = -R^T t
+    f = a[:, 6] / 0.001 if sc.est_focal else sc.f_fixed
+    cam_names = list(cam_names) if cam_names is not None else [100 + 3 * j for j in range(m)]
+    with open(os.path.join(d, "RTglobalmapped_for_optimisation.txt"), "w") as fr, \
+            open(os.path.join(d, "focal_for_optimisation.txt"), "w") as ff:
+        ff.write("%d\n" % m)
+        for j in range(m):
+            fr.write(" ".join("%.9f" % v for v in R[j].reshape(-1)) + "\n")
+            fr.write("%.9f %.9f %.9f\n" % tuple(Cc[j]))
+            ff.write("%d %.9f %d\n" % (cam_names[j], f[j], 2))
+    if invmap:
+        with open(os.path.join(d, "Invmap.txt"), "w") as fm:
+            for j in range(m):
+                fm.write("%d %d\n" % (j, cam_names[j]))
+    if distortion:
+        with open(os.path.join(d, "Distortion.txt"), "w") as fd:
+            fd.write("0.000\n" * m)
+    kept = []
+    with open(os.path.join(d, "ours_new.txt"), "w") as fo:
+        for i in range(n):
+            if i in drop_points:
+                continue
+            o0, o1 = sc.pt_ptr[i], sc.pt_ptr[i + 1]
+            fo.write("%f %f %f 255 255 255 %d " % (*X[i], o1 - o0))
+            for o in range(o0, o1):
+                fo.write("%d %d %f %f " % (sc.obs_cam[o], 5000 + 7 * i, sc.x[o, 0], sc.x[o, 1]))
+            fo.write("\n")
+            kept.append(i)
+    return dict(R=R, C=Cc, t=a[:, :3].copy(), f=np.asarray(f, float), X=X.copy(), names=cam_names, kept=np.array(kept))
+
+
 def read_model(mdl_lib, h):
     import ctypes as C
     cnt = (C.c_int64 * 3)()
@@ -53,6 +94,7 @@ def model_lib():
     L = pkg("capi").lib()
     L.mi_model_load_nvm.restype = C.c_void_p; L.mi_model_load_nvm.argtypes = [C.c_char_p]
     L.mi_model_load_bal.restype = C.c_void_p; L.mi_model_load_bal.argtypes = [C.c_char_p]
+    L.mi_model_load_side_files.restype = C.c_void_p; L.mi_model_load_side_files.argtypes = [C.c_char_p]
     L.mi_model_load_bundler_out.restype = C.c_void_p; L.mi_model_load_bundler_out.argtypes = [C.c_char_p]
     L.mi_model_save_bundler_out.argtypes = [C.c_void_p, C.c_char_p]; L.mi_model_remove_invisible_points.argtypes = [C.c_void_p]
     L.mi_model_save_nvm.argtypes = [C.c_void_p, C.c_char_p]; L.mi_model_save_bal.argtypes = [C.c_void_p, C.c_char_p]

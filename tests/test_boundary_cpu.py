@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT, pkg
-from helpers import model_lib, read_model, vsfm_scene, write_nvm
+from helpers import model_lib, read_model, vsfm_scene, write_nvm, write_side_files
 
 
 def test_library_exports_every_declared_symbol():
@@ -112,6 +112,45 @@ def test_optimizer_all_ranks_without_a_gpu_end_loudly_and_together(tmp_path, env
     assert open(nvm).read() == before
     bad = subprocess.run([exe, str(d) + "/"], capture_output=True, text=True, timeout=60, env={**os.environ, "MI_BA_GPUS": "65"})
     assert bad.returncode == 2 and "MI_BA_GPUS" in bad.stderr
+
+
+def test_side_files_are_read_as_the_callers_write_them(tmp_path):
+    """the input half of the optimizer_all contract: RTglobalmapped (R + CENTRE), focal, Invmap, ours_new, Distortion written with
+    the reference's printf formats (TriangulationMultiStep.cpp:1031-1088), no NVM anywhere; t = -R C, names through Invmap"""
+    L = model_lib()
+    sc = vsfm_scene(m=9, n=150, d=4, seed=6)
+    d = tmp_path / "cluster3"; d.mkdir()
+    w = write_side_files(str(d), sc, drop_points=(7, 8))
+    h = L.mi_model_load_side_files((str(d) + "/").encode())
+    assert h, L.mi_model_last_error()
+    mdl = read_model(L, h)
+    assert mdl["f"].shape == (9,) and mdl["xyz"].shape == (148, 3)
+    assert np.abs(mdl["R"].reshape(9, 3, 3) - w["R"]).max() < 1e-9 and np.abs(mdl["f"] - w["f"]).max() < 1e-8
+    assert np.abs(mdl["t"] - w["t"]).max() < 1e-7                   # t = -R C from 9-decimal text
+    assert np.abs(mdl["xyz"] - w["X"][w["kept"]]).max() < 1e-6      # %lf: six decimals
+    keep_obs = np.isin(sc.obs_pt(), w["kept"])
+    assert np.array_equal(mdl["cam"], sc.obs_cam[keep_obs]) and np.abs(mdl["xy"] - sc.x[keep_obs]).max() < 1e-6
+    assert np.array_equal(mdl["fid"], 5000 + 7 * sc.obs_pt()[keep_obs]) and (mdl["rgb"] == 255).all() and (mdl["d"] == 0).all()
+    assert np.array_equal(mdl["pt"], np.searchsorted(w["kept"], sc.obs_pt()[keep_obs]))
+    out = str(tmp_path / "o.nvm")
+    assert L.mi_model_save_nvm(h, out.encode()) == 0
+    names = [l.split()[0] for l in open(out).read().splitlines()[2:11]]
+    assert names == [str(v) for v in w["names"]]                    # camera names of the output NVM = Invmap's
+    L.mi_model_free(h)
+    # Invmap and Distortion are optional (MergeClusters.cpp:1009-1032 writes no Distortion.txt): names then come from the focal file
+    d2 = tmp_path / "cluster4"; d2.mkdir()
+    w2 = write_side_files(str(d2), sc, invmap=False, distortion=False, cam_names=range(40, 49))
+    h = L.mi_model_load_side_files(str(d2).encode())
+    assert h, L.mi_model_last_error()
+    assert L.mi_model_save_nvm(h, out.encode()) == 0
+    assert [l.split()[0] for l in open(out).read().splitlines()[2:11]] == [str(v) for v in range(40, 49)]
+    L.mi_model_free(h)
+    # failures are loud
+    os.remove(d2 / "ours_new.txt")
+    assert not L.mi_model_load_side_files(str(d2).encode()) and b"ours_new.txt" in L.mi_model_last_error()
+    with open(d / "ours_new.txt", "a") as fo:
+        fo.write("0.1 0.2 0.3 255 255 255 2 0 1 0.5 0.5 99 1 0.25 0.25 \n")
+    assert not L.mi_model_load_side_files(str(d).encode()) and b"camera index out of range" in L.mi_model_last_error()
 
 
 def test_nvm_round_trip(tmp_path):

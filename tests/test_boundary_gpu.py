@@ -106,6 +106,60 @@ def test_sba_motstr_levmar_shape():
     assert abs(info[1] - want[1]) < 1e-6 * want[1]
 
 
+def test_optimizer_all_with_only_the_side_files_the_callers_write(tmp_path, oracle):
+    """the two TriangulationMultiStep call sites (:1024-1095, :1308-1382) leave NO NVM before system("../bin/optimizer_all ..."):
+    the freshly triangulated points exist only in ours_new.txt, the cameras only as R + centre and a focal file.  The binary
+    must bundle exactly that and leave an outputVSFM_GB.nvm with the pointIds and Invmap's camera names (read back at :1102-1109)"""
+    from helpers import write_side_files
+    L = model_lib()
+    sc = vsfm_scene(m=14, n=1200, d=5, seed=21)
+    d = tmp_path / "cluster9"; d.mkdir()
+    w = write_side_files(str(d), sc)
+    assert not os.path.exists(d / "outputVSFM_GB.nvm")
+    o = oracle.run(sc, itmax=300, fd_jacobian=0)
+    want = np.sqrt(o["info"][1] / sc.nobs)
+    exe = os.path.join(ROOT, "large-scale-sfm_amd", "bin", "optimizer_all")
+    out = subprocess.run([exe, str(d) + "/", "0", "300", "16", "32", "0.5", "0"], capture_output=True, text=True)   # :1094
+    assert out.returncode == 0, out.stderr
+    assert "input = RTglobalmapped_for_optimisation.txt" in out.stdout and "ignored: C=16 D=32 E=0.5 F=0" in out.stdout
+    h = L.mi_model_load_nvm(str(d / "outputVSFM_GB.nvm").encode())
+    assert h, L.mi_model_last_error()
+    mdl = read_model(L, h)
+    assert abs(L.mi_model_rmse(h) - want) < 2e-4 and want < 0.2      # the noise level; inputs went through 6-decimal text
+    assert np.array_equal(mdl["fid"], 5000 + 7 * sc.obs_pt()) and (mdl["rgb"] == 255).all()
+    assert np.array_equal(mdl["cam"], sc.obs_cam) and mdl["xyz"].shape == (sc.n, 3)
+    names = [l.split()[0] for l in open(d / "outputVSFM_GB.nvm").read().splitlines()[2:2 + sc.m]]
+    assert names == [str(v) for v in w["names"]]
+    L.mi_model_free(h)
+
+
+def test_optimizer_all_side_files_win_over_a_stale_nvm(tmp_path, oracle):
+    """a directory that still holds the NVM of the previous stage (fewer, older points) beside fresh side files: the side files are
+    the input, and the disagreement is logged"""
+    from helpers import write_side_files
+    L = model_lib()
+    sc = vsfm_scene(m=12, n=900, d=5, seed=22)
+    stale = vsfm_scene(m=12, n=300, d=4, seed=23)
+    d = tmp_path / "cluster2"; d.mkdir()
+    write_nvm(str(d / "outputVSFM_GB.nvm"), stale)
+    write_side_files(str(d), sc)
+    exe = os.path.join(ROOT, "large-scale-sfm_amd", "bin", "optimizer_all")
+    out = subprocess.run([exe, str(d) + "/", "0", "50", "16", "32", "1", "0"], capture_output=True, text=True)     # :1374
+    assert out.returncode == 0, out.stderr
+    assert "disagree" in out.stdout and "the side files win" in out.stdout and "900 3D points" in out.stdout
+    h = L.mi_model_load_nvm(str(d / "outputVSFM_GB.nvm").encode())
+    mdl = read_model(L, h)
+    assert mdl["xyz"].shape == (900, 3) and np.array_equal(mdl["fid"], 5000 + 7 * sc.obs_pt())
+    assert L.mi_model_rmse(h) < 0.2
+    L.mi_model_free(h)
+    # an NVM that agrees with the side files (MergeClusters.cpp:1005-1052 writes both) raises no warning
+    d3 = tmp_path / "cluster5"; d3.mkdir()
+    write_nvm(str(d3 / "outputVSFM_GB.nvm"), sc)
+    write_side_files(str(d3), sc)
+    out = subprocess.run([exe, str(d3) + "/", "0", "50", "16", "32", "0.5", "0"], capture_output=True, text=True)
+    assert out.returncode == 0 and "disagree" not in out.stdout, out.stdout
+
+
 def test_model_optimize_and_optimizer_all_binary(tmp_path, oracle):
     L = model_lib()
     sc = vsfm_scene(m=16, n=1500, d=5, seed=11)
