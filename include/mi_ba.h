@@ -66,7 +66,12 @@ typedef struct {
      * ParallelBA::BUNDLE_ONLY_MOTION), 2: points only, cameras fixed (sba_str_levmar, sba.h:118-123;
      * BUNDLE_ONLY_STRUCTURE) */
     int mode;
-    int reserved[6];
+    /* 1: no floating-point atomics in the linear phase -- every point takes the block-major row path (csrc/plan.h), every sum
+     * has a fixed order, two runs give the same bits (the reference is deterministic: sba_levmar.c:1182-1339).  0 (default):
+     * points whose camera set repeats accumulate their blocks in registers and hand them over with f64 atomics (faster on
+     * such scenes; results differ from run to run at rounding level). */
+    int deterministic;
+    int reserved[5];
 } mi_ba_config;
 
 /* fills the defaults above (Bundler's run_sfm settings, cnp 7, explicit centres) */
@@ -156,7 +161,7 @@ typedef struct {
                                             * V / e_b / E terms), 2 x 138 per pair block, 120 per point (3x3 inverse, h) */
     double pcg_timed;                      /* solves that pcg_ms covers (mi_ba_set_timing_detail >= 2) */
     double spec_adopted;                   /* trials whose linear phase had been enqueued behind the previous trial (engine.cpp solve_phase) */
-    double reserved[1];
+    double build_index_bytes;              /* the engine's own tables and scratch one build launch also moves (pair entries, row-path records) */
 } mi_ba_timing;
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_reset_timing(mi_ba_engine *e);
@@ -180,21 +185,26 @@ int mi_ba_comm_set_host_allreduce(mi_ba_engine *e, mi_ba_host_allreduce_fn fn, v
  * shard cut, wave batches, LDS tiles, pair tables and the block-sparse pattern of S.          */
 mi_ba_plan *mi_ba_plan_build(int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
                              int rank, int world, int tile_max_batches);
+/* the same with every point on the row path (mi_ba_config.deterministic) */
+mi_ba_plan *mi_ba_plan_build_rows(int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
+                                  int rank, int world, int tile_max_batches);
 void mi_ba_plan_free(mi_ba_plan *p);
 /* stats: see MI_BA_PLAN_* indices */
 enum {
     MI_BA_PLAN_NPTS_LOCAL = 0, MI_BA_PLAN_NOBS_LOCAL, MI_BA_PLAN_NBATCH, MI_BA_PLAN_NTILE,
     MI_BA_PLAN_NPAIR, MI_BA_PLAN_NB_UPPER, MI_BA_PLAN_NB_FULL, MI_BA_PLAN_NSLOT_TOTAL,
-    MI_BA_PLAN_NBATCH_DIRECT, MI_BA_PLAN_NPAIR_DIRECT, MI_BA_PLAN_NLONG, MI_BA_PLAN_PT_BEGIN,
-    MI_BA_PLAN_PT_END, MI_BA_PLAN_MAX_SLOTS, MI_BA_PLAN_NSTATS = 16
+    MI_BA_PLAN_NBATCH_ROWS, MI_BA_PLAN_NPAIR_ROWS, MI_BA_PLAN_NLONG, MI_BA_PLAN_PT_BEGIN,
+    MI_BA_PLAN_PT_END, MI_BA_PLAN_MAX_SLOTS, MI_BA_PLAN_NREC, MI_BA_PLAN_NROW_PTS, MI_BA_PLAN_NSTATS = 16
 };
 int mi_ba_plan_stats(const mi_ba_plan *p, int64_t stats[MI_BA_PLAN_NSTATS]);
 /* array access for tests: returns element count, copies min(cap, count) elements.
  * names: "perm" (int32, internal->original point), "obs_cam", "obs_pt" (int32, internal local),
  * "obs_src" (int64 original observation index), "batch_obs", "batch_pair", "batch_pt", "tile_batch",
- * "tile_slot", "slot_gblk", "tile_cslot", "cslot_cam", "pair" (uint32), "pair_gblk" (uint32),
+ * "tile_slot", "slot_gblk", "tile_cslot", "cslot_cam", "pair" (uint32),
  * "obs_cslot" (uint8), "up_row" (int32 m+1), "up_col" (int32), "bsr_row", "bsr_col", "bsr_src",
- * "tile_mode" (uint8: 1 = LDS accumulate, 0 = direct)                                           */
+ * "tile_mode" (uint8: 1 = blocks in registers, 2 = blocks in an LDS table, 0 = row tile); the row path: "obs_rec" (int32 per
+ * observation, -1 = none), "rec_cam" (m+1), "wk_blk", "wk_q" (int64, nwork+1), "rpair" (uint32, 2 per pair),
+ * "wk_diag_cam", "wk_diag_blk"                                                                  */
 int64_t mi_ba_plan_get(const mi_ba_plan *p, const char *name, void *out, int64_t cap_elems);
 
 #ifdef __cplusplus

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 
 INFOSZ = 10
 PLAN_STATS = ["npts_local", "nobs_local", "nbatch", "ntile", "npair", "nb_upper", "nb_full", "nslot_total",
-              "nbatch_direct", "npair_direct", "nlong", "pt_begin", "pt_end", "max_slots"]
+              "nbatch_rows", "npair_rows", "nlong", "pt_begin", "pt_end", "max_slots", "nrec", "nrow_pts"]
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -29,13 +29,13 @@ class Config(C.Structure):
                 ("itmax", C.c_int), ("opts", C.c_double * 6), ("disable_stops", C.c_int),
                 ("pcg_maxit", C.c_int), ("pcg_tol", C.c_double),
                 ("device", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("verbose", C.c_int),
-                ("tile_max_batches", C.c_int), ("mode", C.c_int), ("reserved", C.c_int * 6)]
+                ("tile_max_batches", C.c_int), ("mode", C.c_int), ("deterministic", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class Timing(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("build_ms", "build_launches", "pcg_ms", "pcg_solves", "pcg_iters", "backsub_ms", "backsub_launches",
-                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes", "pcg_resumes", "build_flops", "pcg_timed", "spec_adopted")] + [("reserved", C.c_double * 1)]
+                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes", "pcg_resumes", "build_flops", "pcg_timed", "spec_adopted", "build_index_bytes")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
         L.mi_ba_last_error.restype = C.c_char_p
         L.mi_ba_last_error.argtypes = [C.c_void_p]
         L.mi_ba_plan_build.restype = C.c_void_p
+        L.mi_ba_plan_build_rows.restype = C.c_void_p
         L.mi_ba_plan_get.restype = C.c_int64
         vp, dp, ip, dbl, i32, i64 = C.c_void_p, _dp, _ip, C.c_double, C.c_int, C.c_int64
         sig = {
@@ -79,7 +80,7 @@ def lib() -> C.CDLL:
             "mi_ba_get_rotations": [vp, dp], "mi_ba_debug_linearize": [vp, dbl, dp, dp, dp, dp, dp, dp, dp],
             "mi_ba_debug_solve": [vp, dbl, dp, dp, dp], "mi_ba_get_timing": [vp, C.POINTER(Timing)],
             "mi_ba_comm_init": [vp, C.c_char_p], "mi_ba_comm_unique_id": [C.c_char_p],
-            "mi_ba_plan_build": [i32, i32, i64, ip, ip, i32, i32, i32], "mi_ba_plan_free": [vp],
+            "mi_ba_plan_build": [i32, i32, i64, ip, ip, i32, i32, i32], "mi_ba_plan_build_rows": [i32, i32, i64, ip, ip, i32, i32, i32], "mi_ba_plan_free": [vp],
             "mi_ba_plan_stats": [vp, C.POINTER(i64)], "mi_ba_plan_get": [vp, C.c_char_p, vp, i64],
             "mi_ba_create": [C.POINTER(Config)], "mi_ba_default_config": [C.POINTER(Config)],
         }
@@ -273,14 +274,14 @@ def comm_unique_id() -> bytes:
 class Plan:
     """host-only shard plan (usable without a GPU)."""
 
-    _dtypes = dict(obs_src=np.int64, batch_pair=np.int64, pair=np.uint32, pair_gblk=np.uint32, obs_cslot=np.uint8,
+    _dtypes = dict(obs_src=np.int64, batch_pair=np.int64, pair=np.uint32, rpair=np.uint32, wk_q=np.int64, obs_cslot=np.uint8,
                    tile_mode=np.uint8, bsr_trans=np.uint8)
 
-    def __init__(self, n, m, pt_idx, cam_idx, rank=0, world=1, tile_max_batches=0):
+    def __init__(self, n, m, pt_idx, cam_idx, rank=0, world=1, tile_max_batches=0, all_rows=False):
         self.L = lib()
         pt = np.ascontiguousarray(pt_idx, np.int32); cam = np.ascontiguousarray(cam_idx, np.int32)
-        self.h = self.L.mi_ba_plan_build(n, m, len(pt), pt.ctypes.data_as(_ip), cam.ctypes.data_as(_ip),
-                                         rank, world, tile_max_batches)
+        build = self.L.mi_ba_plan_build_rows if all_rows else self.L.mi_ba_plan_build
+        self.h = build(n, m, len(pt), pt.ctypes.data_as(_ip), cam.ctypes.data_as(_ip), rank, world, tile_max_batches)
         if not self.h:
             raise ValueError("plan: " + self.L.mi_ba_last_error(None).decode())
 

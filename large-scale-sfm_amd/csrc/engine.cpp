@@ -20,6 +20,22 @@ constexpr double kOneThird = 0.3333333334;   // SBA_ONE_THIRD, sba_levmar.c:40
 constexpr int kPcgChunk = 8;                 // PCG iterations launched between two host checks
 constexpr int kPcgRowPerWorkgroupMax = 512; // up to this many cameras a block row of S~ gets a whole workgroup (4 wavefronts), above: a wavefront
 
+// Every public entry point runs with the engine's device current and puts the caller's back afterwards: buffers are allocated
+// and copied on "the current device" of the calling THREAD, which another engine, another library or another thread of the host
+// program may have changed since the constructor ran (ParallelBA with device != 0, the sharded C ABI used in-process).
+struct DeviceGuard {
+    int prev = -1, want;
+    explicit DeviceGuard(int dev) : want(dev)   // dev < 0: nothing to do (an engine that never opened its device)
+    {
+        if (want < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 double now_ms()
 {
     using namespace std::chrono;
@@ -47,7 +63,7 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
         return;
     }
     if (cfg.device < 0 || cfg.device >= ndev) { err = "bad device ordinal"; return; }
-    if (!hipok(hipSetDevice(cfg.device), "hipSetDevice")) return;
+    DeviceGuard on_device(cfg.device);
     if (!hipok(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking), "hipStreamCreate")) return;
     for (auto &ev : ev_) if (!hipok(hipEventCreate(&ev), "hipEventCreate")) return;
     speculate_ = std::getenv("MI_BA_NO_SPECULATION") == nullptr;
@@ -57,6 +73,7 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
 
 Engine::~Engine()
 {
+    DeviceGuard on_device(st_ ? cfg.device : -1);
     if (d_dbg_.p) { // diagnostic build: per-phase cycle sums of k_build over the engine's life
         unsigned long long h[8];
         if (hipMemcpy(h, d_dbg_.p, 64, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -172,6 +189,7 @@ int Engine::set_observations(int64_t nobs, const double *xy, const int *pt_idx, 
 
 int Engine::comm_init(const char *id)
 {
+    DeviceGuard on_device(cfg.device);
     if (cfg.world <= 1) return 0;
     ncclUniqueId uid;
     static_assert(sizeof(uid) <= MI_BA_UNIQUE_ID_BYTES, "unique id size");
@@ -185,6 +203,7 @@ int Engine::comm_init(const char *id)
 
 int Engine::prepare()
 {
+    DeviceGuard on_device(cfg.device);
     if (!created_) return MI_BA_ERROR;
     if (!m_ || !n_ || !nobs_) { err = "prepare: cameras, points and observations must be set first"; return MI_BA_ERROR; }
     if (cfg.mcon < 0 || cfg.mcon > m_) { err = "prepare: bad mcon"; return MI_BA_ERROR; }
@@ -207,7 +226,7 @@ int Engine::prepare()
     }
     if (!h_link_cam_.empty() && cfg.mode == 2) { err = "prepare: camera links make no sense in a structure-only bundle"; return MI_BA_ERROR; }
     std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches,
-                                  h_link_cam_.empty() ? nullptr : &h_link_cam_);
+                                  h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic != 0);
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
     const Plan &pl = plan_;
 #define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
@@ -216,11 +235,14 @@ int Engine::prepare()
     UP(d_batch_obs_, pl.batch_obs); UP(d_batch_pt_, pl.batch_pt); UP(d_pt_obs_, pl.pt_obs);
     UP(d_bs_batch_obs_, pl.bs_batch_obs); UP(d_bs_batch_pt_, pl.bs_batch_pt);
     UP(d_obs_cam_, pl.obs_cam); UP(d_obs_pt_, pl.obs_pt); UP(d_obs_cslot_, pl.obs_cslot);
-    UP(d_pair_, pl.pair); UP(d_pair_gblk_, pl.pair_gblk);
+    UP(d_pair_, pl.pair);
+    UP(d_obs_rec_, pl.obs_rec); UP(d_rec_cam_, pl.rec_cam); UP(d_wk_blk_, pl.wk_blk); UP(d_rpair_, pl.rpair);
+    UP(d_wk_diag_cam_, pl.wk_diag_cam); UP(d_wk_diag_blk_, pl.wk_diag_blk);
+    if (!hipok(d_rec_.alloc((size_t)pl.rec_cam[m_] * kRec), "alloc observation records")) return MI_BA_ERROR;
     UP(d_bsr_row_, pl.bsr_row); UP(d_bsr_col_, pl.bsr_col); UP(d_bsr_src_, pl.bsr_src); UP(d_bsr_trans_, pl.bsr_trans);
     {
-        std::vector<long long> bp(pl.batch_pair.begin(), pl.batch_pair.end());
-        UP(d_batch_pair_, bp);
+        std::vector<long long> bp(pl.batch_pair.begin(), pl.batch_pair.end()), wq(pl.wk_q.begin(), pl.wk_q.end());
+        UP(d_batch_pair_, bp); UP(d_wk_q_, wq);
         std::vector<int> rowidx(pl.nb_full()), diag(m_, -1);
         for (int j = 0; j < m_; ++j)
             for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) { rowidx[q] = j; if (pl.bsr_col[q] == j) diag[j] = q; }
@@ -286,17 +308,7 @@ int Engine::prepare()
         links_.row = d_link_row_.p; links_.other = d_link_other_.p; links_.w = d_link_w_.p;
         links_.blk_pair = d_link_blk_.p; links_.pair_w = d_link_pair_w_.p;
     }
-    {   // long tracks: scratch rows and the upper pattern for the block lookup
-        std::vector<int> scr(pl.long_pts.size() + 1, 0);
-        long_max_pairs_ = 0;
-        for (size_t l = 0; l < pl.long_pts.size(); ++l) {
-            const long long d = pl.pt_obs[pl.long_pts[l] + 1] - pl.pt_obs[pl.long_pts[l]];
-            scr[l + 1] = scr[l] + (int)d;
-            long_max_pairs_ = std::max(long_max_pairs_, d * (d + 1) / 2);
-        }
-        UP(d_long_pts_, pl.long_pts); UP(d_long_scr_, scr); UP(d_up_row_, pl.up_row); UP(d_up_col_, pl.up_col);
-        if (!hipok(d_long_scratch_.alloc((size_t)scr.back() * 30), "alloc long scratch")) return MI_BA_ERROR;
-    }
+    UP(d_long_pts_, pl.long_pts);
     {
         if ((int)h_fixed_.size() != m_) h_fixed_.assign(m_, 0);
         std::vector<unsigned char> fx(h_fixed_);
@@ -336,24 +348,28 @@ int Engine::prepare()
     }
     prepared_ = true;
     if (set_params(h_a0_.data(), h_xyz_.data()) != 0) return MI_BA_ERROR;
-    // algorithmic HBM bytes of one k_build launch (DESIGN.md "k_build"): observation stream 25 B,
-    // pair table 4 B, point in 24 B / ptout 96 B, camera records once, every S block once
-    timing.build_bytes = 25.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 120.0 * (double)npl +
-                         192.0 * m_ + 512.0 * pl.nb_up() + 4.0 * (double)pl.pair_gblk.size();
+    // algorithmic HBM bytes of one linearisation + Schur build, SURVEY.md 8(d) "Pass A" with the f64 state the engine really
+    // moves: per observation 2 f64 measurement + 2 i32 indices (24 B), per point 3 f64 in, V*^-1 (6) + h (3) out (96 B), per
+    // camera its 192-B record, every upper block of S once (512 B).  The engine's own index tables (pair entries, batch and
+    // tile descriptors) and the row path's observation records are NOT problem data: they are reported beside it.
+    timing.build_bytes = 24.0 * (double)pl.nobs_local() + 96.0 * (double)npl + 192.0 * m_ + 512.0 * pl.nb_up();
+    timing.build_index_bytes = 1.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 8.0 * (double)(pl.rpair.size() / 2) +
+                               2.0 * 8.0 * kRec * (double)pl.rec_cam[m_];
     {   // arithmetic of the same launch (for the f64 vector roofline beside the HBM one)
         double pairs = 0.0;
         for (size_t t = 0; t < npl; ++t) { const double d = pl.pt_obs[t + 1] - pl.pt_obs[t]; pairs += 0.5 * d * (d + 1); }
         timing.build_flops = 400.0 * (double)pl.nobs_local() + 276.0 * pairs + 120.0 * (double)npl;
     }
     if (cfg.verbose)
-        std::fprintf(stderr, "[mi_ba] rank %d/%d: %lld pts %lld obs, %d batches, %d tiles (%d LDS), %zu pairs, S: %d upper / %d full blocks\n",
+        std::fprintf(stderr, "[mi_ba] rank %d/%d: %lld pts %lld obs, %d batches, %d tiles (%d LDS), %zu pair entries; row path: %lld pts, %d records, %zu pairs in %zu + %zu blocks; S: %d upper / %d full blocks\n",
                      cfg.rank, cfg.world, (long long)npl, (long long)pl.nobs_local(), pl.nbatch(), pl.ntile(), pl.ntile_lds,
-                     pl.pair.size(), pl.nb_up(), pl.nb_full());
+                     pl.pair.size(), (long long)pl.nrow_pts, pl.rec_cam[m_], pl.rpair.size() / 2, pl.wk_blk.size(), pl.wk_diag_cam.size(), pl.nb_up(), pl.nb_full());
     return 0;
 }
 
 int Engine::set_params(const double *a, const double *xyz)
 {
+    DeviceGuard on_device(cfg.device);
     if (!prepared_) { err = "set_params: prepare first"; return MI_BA_ERROR; }
     std::vector<double> ap((size_t)m_ * kCP, 0.0);
     for (int j = 0; j < m_; ++j)
@@ -381,6 +397,7 @@ int Engine::set_params(const double *a, const double *xyz)
 // back to the parameters of the last set_params / prepare without touching the host (a 24 MB device copy at C3), then begin()
 int Engine::restart()
 {
+    DeviceGuard on_device(cfg.device);
     if (!prepared_ || !d_cam_a_init_.p) { err = "restart: prepare first"; return MI_BA_ERROR; }
     cur_ = 0; cam_lin_valid_ = false;
     if (!hipok(hipMemcpyAsync(d_cam_a_[0].p, d_cam_a_init_.p, d_cam_a_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore cam_a")) return MI_BA_ERROR;
@@ -424,16 +441,16 @@ bool Engine::allreduce2()
     return true;
 }
 
-LongArgs Engine::long_args(double mu, bool want_diag, double *dB_dev, int part_row0)
+LongArgs Engine::long_args(double mu, double *dB_dev, int part_row0)
 {
     LongArgs a{};
-    a.long_pts = d_long_pts_.p; a.long_scr = d_long_scr_.p; a.pt_obs = d_pt_obs_.p; a.obs_cam = d_obs_cam_.p;
-    a.up_row = d_up_row_.p; a.up_col = d_up_col_.p; a.cam_fixed = d_fixed_.p; a.obs_xy = d_obs_xy_.p;
+    a.long_pts = d_long_pts_.p; a.pt_obs = d_pt_obs_.p; a.obs_cam = d_obs_cam_.p; a.obs_rec = d_obs_rec_.p;
+    a.cam_fixed = d_fixed_.p; a.obs_xy = d_obs_xy_.p;
     a.cam_lin = d_cam_lin_[cur_].p; a.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; a.pts = d_pts_[cur_].p; a.dA = d_dA_.p;
     a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
-    a.scratch = d_long_scratch_.p; a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p;
-    a.pts_new = d_pts_[cur_ ^ 1].p; a.dB = dB_dev; a.mu = mu; a.eps5 = cfg.opts[5]; a.max_pairs = long_max_pairs_;
-    a.nlong = (int)plan_.long_pts.size(); a.m = m_; a.want_diag = want_diag ? 1 : 0; a.part_row0 = part_row0; a.cfg = model();
+    a.rec = d_rec_.p; a.ptout = d_ptout_.p; a.part = d_part_.p;
+    a.pts_new = d_pts_[cur_ ^ 1].p; a.dB = dB_dev; a.mu = mu; a.eps5 = cfg.opts[5];
+    a.nlong = (int)plan_.long_pts.size(); a.m = m_; a.part_row0 = part_row0; a.cfg = model();
     a.scal = scal_();
     return a;
 }
@@ -452,7 +469,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     a.slot_gblk = d_slot_gblk_.p; a.cslot_cam = d_cslot_cam_.p;
     a.batch_obs = d_batch_obs_.p; a.batch_pt = d_batch_pt_.p; a.batch_pair = d_batch_pair_.p; a.pt_obs = d_pt_obs_.p;
     a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p; a.cam_fixed = d_fixed_.p;
-    a.pair = d_pair_.p; a.pair_gblk = d_pair_gblk_.p; a.pair_gblk_base = pl.npair_lds;
+    a.pair = d_pair_.p; a.obs_rec = d_obs_rec_.p; a.rec = d_rec_.p;
     a.m = m_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
     a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc; a.spec = spec;
     a.dbg = d_dbg_.p; a.want_diag = want_diag ? 1 : 0;
@@ -464,9 +481,16 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     a.tile0 = pl.ntile_lds;
     launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
     {
-        LongArgs la = long_args(mu, want_diag, nullptr, pl.ntile());
+        LongArgs la = long_args(mu, nullptr, pl.ntile());
         la.spec = spec;
         launch_long_build(st_, cnp, la);
+        // the row path's blocks of S and camera-side vectors, from the records the two launches above have left
+        SchurArgs sa{};
+        sa.rec = d_rec_.p; sa.wk_blk = d_wk_blk_.p; sa.wk_q = d_wk_q_.p; sa.rpair = d_rpair_.p;
+        sa.diag_cam = d_wk_diag_cam_.p; sa.diag_blk = d_wk_diag_blk_.p; sa.rec_cam = d_rec_cam_.p;
+        sa.nwork = (int)pl.wk_blk.size(); sa.ndiag = (int)pl.wk_diag_cam.size(); sa.m = m_; sa.want_diag = want_diag ? 1 : 0;
+        sa.S_up = S_up_(); sa.camvec = camvec_(); sa.spec = spec;
+        launch_schur_blocks(st_, cnp, sa);
     }
     if (timing_detail >= 1) (void)hipEventRecord(ev_[lin_pair_ + 1], st_);
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST,
@@ -603,7 +627,7 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, kBacksubGrid); b.cfg = mc; b.scal = scal_();
     if (timing_detail >= 2) (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
-    launch_long_backsub(st_, cnp, long_args(mu, false, dB_dev, b.ngrid));
+    launch_long_backsub(st_, cnp, long_args(mu, dB_dev, b.ngrid));
     if (timing_detail >= 2) (void)hipEventRecord(ev_[5], st_);
     launch_reduce_final(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
                         cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT,
@@ -620,6 +644,7 @@ bool Engine::read_scalars()
 
 int Engine::begin()
 {
+    DeviceGuard on_device(cfg.device);
     if (!prepared_) { err = "begin: prepare first"; return MI_BA_ERROR; }
     mu_ = 0; nu_ = 2; itno_ = 0; stop_ = 0; nfev_ = 1; njev_ = 0; nlss_ = 0; dp_L2_ = DBL_MAX; new_outer_ = true;
     pcg_pred_ = pcg_pred_prev_ = 0;      // a new solve: nothing to extrapolate from
@@ -651,6 +676,7 @@ double Engine::measured_maxdiag() const
 // one damping trial; the control flow is sba_levmar.c:1085-1614 unrolled into a resumable step
 int Engine::step()
 {
+    DeviceGuard on_device(cfg.device);
     if (!begun_) { err = "step: begin first"; return MI_BA_ERROR; }
     if (stop_ || itno_ >= cfg.itmax) { if (!stop_) stop_ = 3; return 2; }
     const double t0 = now_ms();
@@ -750,6 +776,7 @@ void Engine::fill_info(double info[MI_BA_INFOSZ]) const
 
 int Engine::run(double info[MI_BA_INFOSZ])
 {
+    DeviceGuard on_device(cfg.device);
     if (begin() != 0) return MI_BA_ERROR;
     while (!stop_ && itno_ < cfg.itmax) {
         int r = step();
@@ -767,6 +794,7 @@ int Engine::run(double info[MI_BA_INFOSZ])
 
 int Engine::get_params(double *a, double *xyz)
 {
+    DeviceGuard on_device(cfg.device);
     if (!prepared_) { err = "get_params: prepare first"; return MI_BA_ERROR; }
     const Plan &pl = plan_;
     if (a) {
@@ -801,6 +829,7 @@ int Engine::get_params(double *a, double *xyz)
 
 int Engine::get_rotations(double *R)
 {
+    DeviceGuard on_device(cfg.device);
     if (!prepared_) { err = "get_rotations: prepare first"; return MI_BA_ERROR; }
     launch_cam_prep(st_, m_, cnp, model(), d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p);
     DevBuf<double> tmp;
@@ -812,6 +841,7 @@ int Engine::get_rotations(double *R)
 
 int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double *eb, double *V, double *diagU, double *cost)
 {
+    DeviceGuard on_device(cfg.device);
     if (!prepared_) { err = "debug_linearize: prepare first"; return MI_BA_ERROR; }
     if (cfg.world > 1 && (eb || V)) { err = "debug_linearize: point outputs need world == 1"; return MI_BA_ERROR; }
     spec_ready_ = false;   // whatever was enqueued for the next trial is overwritten here
@@ -868,6 +898,7 @@ int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double 
 
 int Engine::debug_solve(double mu, double *da, double *db, double *cost_new)
 {
+    DeviceGuard on_device(cfg.device);
     if (!prepared_) { err = "debug_solve: prepare first"; return MI_BA_ERROR; }
     if (cfg.world > 1 && db) { err = "debug_solve: point outputs need world == 1"; return MI_BA_ERROR; }
     spec_ready_ = false;

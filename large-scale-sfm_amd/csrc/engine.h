@@ -125,17 +125,19 @@ private:
         d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_;
     DevBuf<long long> d_batch_pair_;
     DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_, d_pfix_;   // d_pfix_: per camera, bit r = parameter r held constant
-    DevBuf<unsigned> d_pair_, d_pair_gblk_;
+    DevBuf<unsigned> d_pair_, d_rpair_;
+    DevBuf<int> d_obs_rec_, d_rec_cam_, d_wk_blk_, d_wk_diag_cam_, d_wk_diag_blk_;   // row path (plan.h)
+    DevBuf<long long> d_wk_q_;
+    DevBuf<double> d_rec_;                                                             // kRec doubles per row-path observation
     DevBuf<unsigned long long> d_dbg_;
-    DevBuf<int> d_long_pts_, d_long_scr_, d_up_row_, d_up_col_;
-    DevBuf<double> d_long_scratch_, d_cam_cw_, d_cam_cv_, d_pt_cw_, d_pt_cv_;
+    DevBuf<int> d_long_pts_;
+    DevBuf<double> d_cam_cw_, d_cam_cv_, d_pt_cw_, d_pt_cv_;
     DevBuf<int> d_link_row_, d_link_other_, d_link_blk_;
     DevBuf<unsigned char> d_tile_mode_;
     DevBuf<int> d_bs_batch_obs_, d_bs_batch_pt_;
     DevBuf<double> d_cam_a_init_, d_pts_init_;
     DevBuf<double> d_link_w_, d_link_pair_w_, d_cam_part_, d_cam_part2_;   // partial rows of k_finalize_vec / of k_cam_update
-    long long long_max_pairs_ = 0;
-    LongArgs long_args(double mu, bool want_diag, double *dB_dev, int part_row0);
+    LongArgs long_args(double mu, double *dB_dev, int part_row0);
     DevBuf<double2> d_obs_xy_;
     // device: state
     DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_S_pcg_, d_Linv_, d_E_, d_dA_, d_dB_,

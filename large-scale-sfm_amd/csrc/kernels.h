@@ -63,7 +63,7 @@ struct CamLinks {
 };
 
 struct BuildArgs {
-    const unsigned char *tile_mode; // per tile: 1 register-accumulated blocks, 2 LDS block table, 0 direct
+    const unsigned char *tile_mode; // per tile: 1 register-accumulated blocks, 2 LDS block table, 0 row tiles
     int has_table;                  // some tile of this launch range has mode 2
     const int *tile_batch, *tile_slot, *tile_cslot, *slot_gblk, *cslot_cam;
     const int *batch_obs, *batch_pt;
@@ -72,8 +72,9 @@ struct BuildArgs {
     const int *obs_cam, *obs_pt;
     const unsigned char *obs_cslot, *cam_fixed;   // cam_fixed [m]: 1 = camera held constant (A_ij := 0)
     const double2 *obs_xy;
-    const unsigned *pair, *pair_gblk;
-    long long pair_gblk_base;
+    const unsigned *pair;
+    const int *obs_rec;                     // row tiles: record of every observation (plan.h)
+    double *rec;                            // the records, kRec doubles each
     int tile0, m, want_diag;                // want_diag: also accumulate diag U_j (mu0 and info[4] only)
     const double *cam_lin, *pts;
     const double *pt_cw, *pt_cv;            // soft point constraints (weight already x nvis), internal order; NULL = none
@@ -96,19 +97,30 @@ struct BacksubArgs {
     const double *scal;                     // SC_PCG_FINAL == 0: the reduced solve has not finished, nothing to do yet
 };
 
-// long tracks (> 64 views): one workgroup per point, HBM scratch row per observation
+// long tracks (> 64 views): one workgroup per point; the records go where the row tiles' go
 struct LongArgs {
-    const int *long_pts, *long_scr, *pt_obs, *obs_cam, *up_row, *up_col;
+    const int *long_pts, *pt_obs, *obs_cam, *obs_rec;
     const unsigned char *cam_fixed;
     const double2 *obs_xy;
     const double *cam_lin, *cam_lin_new, *pts, *dA, *pt_cw, *pt_cv;
-    double *scratch, *S_up, *camvec, *ptout, *part, *pts_new, *dB;
+    double *rec, *ptout, *part, *pts_new, *dB;
     double mu, eps5;
-    long long max_pairs;
-    int nlong, m, want_diag, part_row0;
+    int nlong, m, part_row0;
     ModelCfg cfg;
     const double *scal;
     const double *spec;                     // as in BuildArgs (the linear-phase kernels)
+};
+
+// k_schur_blocks: the blocks of S (and the camera-side vectors) of the row path, summed from the observation records
+struct SchurArgs {
+    const double *rec;
+    const int *wk_blk;            // off-diagonal work items: upper block ...
+    const long long *wk_q;        // ... and its pair range
+    const unsigned *rpair;        // 2 per pair: record of the row camera, record of the column camera
+    const int *diag_cam, *diag_blk, *rec_cam;   // diagonal work items: camera, its diagonal block, its record range
+    int nwork, ndiag, m, want_diag;
+    double *S_up, *camvec;
+    const double *spec;           // as in BuildArgs
 };
 
 // where the CG starts: written by k_block_inv, which holds L^-1 of every camera's diagonal block anyway
@@ -156,7 +168,8 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, cons
                        double *dA, const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
                        double *cam_lin_new, double *cam_part);   // ends the scaled solve (da = Linv^T x~, + k_pcg_tail's work with pa.tail), then a + da
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a);
-void launch_long_build(hipStream_t st, int cnp, const LongArgs &a);   // k_long_reduce + k_long_pairs
+void launch_long_build(hipStream_t st, int cnp, const LongArgs &a);   // k_long_reduce
+void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a); // after every record of this linearisation has been written
 void launch_long_backsub(hipStream_t st, int cnp, const LongArgs &a);
 void launch_rotations(hipStream_t st, int m, const double *cam_lin, double *R);
 

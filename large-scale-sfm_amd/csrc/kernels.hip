@@ -336,7 +336,9 @@ __global__ void k_cam_prep(int m, int cnp, ModelCfg cfg, const double *__restric
 //              registers for as long as consecutive rounds give it the same block and spills it
 //              into the tile's LDS table (ds_add_f64) only when the block changes; the table is
 //              flushed once per tile as contiguous f64 atomics (one S block = one wave instruction).
-//   direct mode (points with > kMaxViewsLds views): every pair adds straight into HBM.
+//   row tiles (points whose camera set does not repeat, or with > kMaxViewsLds views): phases 1-4 only; phase 5 leaves one
+//              record per observation in HBM (A | B | e | G = B V*^-1 | e - B h) and k_schur_blocks sums the blocks and the
+//              camera-side vectors from them -- no atomics.
 // ------------------------------------------------------------------------------------------
 // what one lane needs before it can start a batch; filled one batch ahead (software pipeline:
 // the kernel runs one wavefront per SIMD, so nothing else hides the global-load latency)
@@ -454,11 +456,10 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
     // LDS budget: <= 20 KB so that TWO tiles share a SIMD (8 workgroups per CU).  The S blocks live in
     // registers; sStage only transposes them (kStageLanes lanes at a time) into the contiguous 49-double
     // shape a global f64 atomic wants.
-    constexpr int kStageLanes = LDS ? 5 : 8;
-    __shared__ double sStage[TABLE ? 1 : kStageLanes * BLK], sC[LDS ? kNCSlot * SC : 1];
+    constexpr int kStageLanes = 5;
+    __shared__ double sStage[(TABLE || !LDS) ? 1 : kStageLanes * BLK], sC[LDS ? kNCSlot * SC : 1];
     __shared__ double sTab[TABLE ? kNSlot * BLK : 1];
     __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
-    __shared__ int sLp[LDS ? 1 : kWave];      // local point of every observation (direct tiles; LDS tiles carry it in the pair entry)
 
     const int lane = threadIdx.x;
     const int tile = g.tile0 + blockIdx.x;
@@ -553,7 +554,6 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
 #pragma unroll
                 for (int t = 0; t < 3; ++t) { row[OB + t] = B[0][t]; row[OB + 3 + t] = B[1][t]; }
                 row[OB + 6] = e[0]; row[OB + 7] = e[1];
-                if constexpr (!LDS) sLp[lane] = lp;
             }
             // point boundaries without touching memory: observations of a point are consecutive lanes
             const int lp_prev = __builtin_amdgcn_update_dpp(-2, active ? lp : -2, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -2)
@@ -630,29 +630,26 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
         // The pair entries of this batch are requested first; phase 4 and the other wavefront of the SIMD
         // cover their latency.
         unsigned ent_r[LDS ? kMaxRounds : 1];
+        int my_rec = 0;
         if constexpr (LDS) {
 #pragma unroll
             for (int t = 0; t < kMaxRounds; ++t) {
                 const long long q = cur.q0 + (long long)t * kWave + lane;
                 ent_r[t] = (q < cur.q1) ? g.pair[q] : kPairInvalid;
             }
-        }
-        if (active && !g.cam_fixed[j]) {
+        } else if (active) my_rec = g.obs_rec[cur.o0 + lane];
+        double er[2] = { 0.0, 0.0 };
+        if (active && (!LDS || !g.cam_fixed[j])) {
             const double *sv = sV + lp * SV;
-            double er[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) er[r] = e[r] - (B[r][0] * sv[6] + B[r][1] * sv[7] + B[r][2] * sv[8]);
+            if constexpr (LDS) {
 #pragma unroll
-            for (int t = 0; t < CNP; ++t) {
-                const double vea = fma(A[1][t], e[1], A[0][t] * e[0]);
-                const double vE = fma(A[1][t], er[1], A[0][t] * er[0]);
-                if constexpr (LDS) {
+                for (int t = 0; t < CNP; ++t) {
+                    const double vea = fma(A[1][t], e[1], A[0][t] * e[0]);
+                    const double vE = fma(A[1][t], er[1], A[0][t] * er[0]);
                     ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE);
                     if (g.want_diag) ladd(&sC[cs * SC + 2 * CNP + t], fma(A[1][t], A[1][t], A[0][t] * A[0][t]));
-                } else {
-                    gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], vea);
-                    gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], vE);
-                    if (g.want_diag) gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], fma(A[1][t], A[1][t], A[0][t] * A[0][t]));
                 }
             }
         }
@@ -689,49 +686,28 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
                 }
             }
         } else {
-            // direct tiles (points with too many views for the tile's block table): every round of 64 pairs is computed
-            // into registers and handed to HBM at once, kStageLanes blocks at a time through sStage, so that ONE
-            // atomic instruction adds ONE contiguous block (64 lanes adding to 64 different blocks would be 64 cache
-            // lines per instruction: measured 12x slower)
-            const int rr = lane / CNP, cc = lane - rr * CNP;
-            for (long long q0 = cur.q0; q0 < cur.q1; q0 += kWave) {
-                const long long q = q0 + lane;
-                const bool valid = q < cur.q1;
-                double blk[BLK];
-                int gb = -1;
-                if (valid) {
-                    const unsigned ent = g.pair[q];
-                    const int la = ent & 63, lb = (ent >> 6) & 63;
-                    double T0[CNP], T1[CNP];
-                    pair_block<CNP, SR>(sR, sV + sLp[la] * SV, la, lb, T0, T1);
-                    const double *Aa = sR + la * SR;
-                    gb = g.pair_gblk[q - g.pair_gblk_base];
+            // row tiles: the observation's record goes to HBM (camera-major, plan.h); k_schur_blocks does the rest.
+            // A fixed camera's A is zero (linearize_obs), so its record contributes nothing there.
+            if (active) {
+                const double2 *sv2 = reinterpret_cast<const double2 *>(sV + lp * SV);
+                const double2 v01 = sv2[0], v23 = sv2[1], v45 = sv2[2];
+                const double i00 = v01.x, i01 = v01.y, i02 = v23.x, i11 = v23.y, i12 = v45.x, i22 = v45.y;
+                double G[2][3];
 #pragma unroll
-                    for (int r = 0; r < CNP; ++r) {
-                        const double a0 = Aa[r], a1 = Aa[CNP + r];
-#pragma unroll
-                        for (int c = 0; c < CNP; ++c) blk[r * CNP + c] = fma(a1, T1[c], a0 * T0[c]);
-                    }
+                for (int r = 0; r < 2; ++r) {
+                    G[r][0] = fma(B[r][2], i02, fma(B[r][1], i01, B[r][0] * i00));
+                    G[r][1] = fma(B[r][2], i12, fma(B[r][1], i11, B[r][0] * i01));
+                    G[r][2] = fma(B[r][2], i22, fma(B[r][1], i12, B[r][0] * i02));
                 }
-                for (int base = 0; base < kWave; base += kStageLanes) {
-                    const int ql = lane - base;
-                    if (ql >= 0 && ql < kStageLanes && valid) {
-                        double *dst = sStage + ql * BLK;
+                double out[kRec];
 #pragma unroll
-                        for (int i = 0; i < BLK; ++i) dst[i] = blk[i];
-                    }
-                    wave_lds_sync();
-                    for (int q2 = 0; q2 < kStageLanes && base + q2 < kWave; ++q2) {
-                        const int gL = rl(gb, base + q2);
-                        if (gL < 0 || (q2 > 0 && rl(gb, base + q2 - 1) == gL)) continue;   // nothing, or merged into the lane before
-                        // the plan sorted the batch's pairs by block: a run of lanes with the same block becomes one atomic
-                        double v = lane < BLK ? sStage[q2 * BLK + lane] : 0.0;
-                        for (int q3 = q2 + 1; q3 < kStageLanes && base + q3 < kWave && rl(gb, base + q3) == gL; ++q3)
-                            if (lane < BLK) v += sStage[q3 * BLK + lane];
-                        if (lane < BLK) gadd(&g.S_up[(size_t)gL * (kCP * kCP) + rr * kCP + cc], v);
-                    }
-                    wave_lds_sync();
-                }
+                for (int t = 0; t < 8; ++t) { out[t] = t < CNP ? A[0][t] : 0.0; out[8 + t] = t < CNP ? A[1][t] : 0.0; }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { out[16 + t] = B[0][t]; out[19 + t] = B[1][t]; out[24 + t] = G[0][t]; out[27 + t] = G[1][t]; }
+                out[22] = e[0]; out[23] = e[1]; out[30] = er[0]; out[31] = er[1];
+                double2 *dst = reinterpret_cast<double2 *>(g.rec + (size_t)my_rec * kRec);
+#pragma unroll
+                for (int t = 0; t < kRec / 2; ++t) dst[t] = make_double2(out[2 * t], out[2 * t + 1]);
             }
         }
         wave_lds_sync();
@@ -770,12 +746,9 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
 
 // ------------------------------------------------------------------------------------------
 // Long tracks: points seen by more than 64 cameras do not fit a wavefront batch.  They take a
-// workgroup each (k_long_reduce: phases 1-4 with block reductions, A/B/e/G parked in an HBM scratch
-// row per observation) and their d(d+1)/2 pair blocks are spread over a 2-D grid (k_long_pairs,
-// direct f64 atomics, block found by binary search in the upper pattern).  Same arithmetic as k_build.
+// workgroup each (k_long_reduce: phases 1-4 with block reductions) and leave the same observation
+// records as the row tiles; their d(d+1)/2 pair blocks are k_schur_blocks' work like everybody else's.
 // ------------------------------------------------------------------------------------------
-constexpr int kLongRow = 2 * 8 + 6 + 2 + 6; // A (2 x 8 padded), B (6), e (2), G (6) doubles per observation
-
 __device__ __forceinline__ double block_sum_256(double v, double *sh)
 {
     v = wave_sum(v);
@@ -795,7 +768,6 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
     const int l = blockIdx.x, ip = g.long_pts[l], tid = threadIdx.x;
     const int os = g.pt_obs[ip], oe = g.pt_obs[ip + 1];
     const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
-    double *scr = g.scratch + (size_t)g.long_scr[l] * kLongRow;
     double v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, cost = 0.0;
     for (int o = os + tid; o < oe; o += 256) {
         const int j = g.obs_cam[o];
@@ -807,9 +779,9 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
         v[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2]; v[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
 #pragma unroll
         for (int r = 0; r < 3; ++r) v[6 + r] += B[0][r] * e[0] + B[1][r] * e[1];
-        double *row = scr + (size_t)(o - os) * kLongRow;
+        double *row = g.rec + (size_t)g.obs_rec[o] * kRec;
 #pragma unroll
-        for (int t = 0; t < CNP; ++t) { row[t] = A[0][t]; row[8 + t] = A[1][t]; }
+        for (int t = 0; t < 8; ++t) { row[t] = t < CNP ? A[0][t] : 0.0; row[8 + t] = t < CNP ? A[1][t] : 0.0; }
 #pragma unroll
         for (int t = 0; t < 3; ++t) { row[16 + t] = B[0][t]; row[19 + t] = B[1][t]; }
         row[22] = e[0]; row[23] = e[1];
@@ -853,86 +825,118 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
     __syncthreads();
     const double i00 = sVh[0], i01 = sVh[1], i02 = sVh[2], i11 = sVh[3], i12 = sVh[4], i22 = sVh[5];
     for (int o = os + tid; o < oe; o += 256) {
-        const int j = g.obs_cam[o];
-        double *row = scr + (size_t)(o - os) * kLongRow; // written by this same thread above
+        double *row = g.rec + (size_t)g.obs_rec[o] * kRec; // written by this same thread above
         const double B0[3] = { row[16], row[17], row[18] }, B1[3] = { row[19], row[20], row[21] };
         row[24] = B0[0] * i00 + B0[1] * i01 + B0[2] * i02; row[25] = B0[0] * i01 + B0[1] * i11 + B0[2] * i12;
         row[26] = B0[0] * i02 + B0[1] * i12 + B0[2] * i22; row[27] = B1[0] * i00 + B1[1] * i01 + B1[2] * i02;
         row[28] = B1[0] * i01 + B1[1] * i11 + B1[2] * i12; row[29] = B1[0] * i02 + B1[1] * i12 + B1[2] * i22;
-        if (g.cam_fixed[j]) continue;
-        const double e0 = row[22], e1 = row[23];
-        const double er0 = e0 - (B0[0] * sVh[6] + B0[1] * sVh[7] + B0[2] * sVh[8]);
-        const double er1 = e1 - (B1[0] * sVh[6] + B1[1] * sVh[7] + B1[2] * sVh[8]);
-#pragma unroll
-        for (int t = 0; t < CNP; ++t) {
-            const double a0 = row[t], a1 = row[8 + t];
-            gadd(&g.camvec[((size_t)0 * g.m + j) * kCP + t], a0 * e0 + a1 * e1);
-            gadd(&g.camvec[((size_t)1 * g.m + j) * kCP + t], a0 * er0 + a1 * er1);
-            if (g.want_diag) gadd(&g.camvec[((size_t)2 * g.m + j) * kCP + t], a0 * a0 + a1 * a1);
-        }
+        row[30] = row[22] - (B0[0] * sVh[6] + B0[1] * sVh[7] + B0[2] * sVh[8]);
+        row[31] = row[23] - (B1[0] * sVh[6] + B1[1] * sVh[7] + B1[2] * sVh[8]);
     }
 }
 
-template <int CNP>
-__global__ __launch_bounds__(256) void k_long_pairs(const LongArgs g)
+// ------------------------------------------------------------------------------------------
+// k_schur_blocks: S_jk = delta_jk U_j - sum_i Y_ij W_ik^T and e_j = ea_j - sum_i Y_ij eb_i (sba_levmar.c:1182-1339) for the
+// points of the row path, BLOCK-major: one wavefront per block of S, a lane per (observation of camera j, observation of
+// camera k) pair of one point from the plan's list, CNP x CNP accumulators per lane across the whole list, one reduction over
+// the lanes through LDS and one store.  No atomics: the sum has a fixed order, whatever the visibility looks like.
+// DIAG: the diagonal block of a camera runs over the camera's records themselves and also leaves ea_j, E_j (and diag U_j).
+// ------------------------------------------------------------------------------------------
+template <int CNP, bool DIAG>
+__global__ __launch_bounds__(64, (CNP <= 7 && !DIAG) ? 2 : 1) void k_schur_blocks(const SchurArgs g)
 {
-    // every wavefront computes 64 pair blocks into registers and hands them to HBM kStage at a time through LDS, so
-    // that one atomic instruction adds one contiguous block (the shape of k_build's direct tiles; 64 lanes adding to
-    // 64 different blocks was measured ~6x slower)
-    constexpr int BLK = CNP * CNP, kStage = 8;
-    __shared__ double sStage[4][kStage * BLK];
+    constexpr int BLK = CNP * CNP;
+    constexpr int NV = DIAG ? BLK + 3 * CNP : BLK;
+    constexpr int ST = NV | 1;                       // odd row stride: the lanes' ds_write_b64 and the column reads are conflict-free
+    __shared__ double sRed[32 * ST];
     if (g.spec && g.spec[0] == 0.0) return;
-    const int l = blockIdx.y, ip = g.long_pts[l], lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int os = g.pt_obs[ip], d = g.pt_obs[ip + 1] - os;
-    const long long np = (long long)d * (d + 1) / 2, t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if ((long long)blockIdx.x * 256 >= np) return;          // whole workgroup past the end
-    double blk[BLK];
-    int gb = -1;
-    if (t < np) {
-        // pair index -> (a <= b): t = a*d - a(a-1)/2 + (b - a)
-        int a = (int)floor(((2.0 * d + 1.0) - sqrt((2.0 * d + 1.0) * (2.0 * d + 1.0) - 8.0 * (double)t)) * 0.5);
-        if (a < 0) a = 0;
-        while ((long long)a * d - (long long)a * (a - 1) / 2 > t) --a;
-        while ((long long)(a + 1) * d - (long long)(a + 1) * a / 2 <= t) ++a;
-        const int b = a + (int)(t - ((long long)a * d - (long long)a * (a - 1) / 2));
-        const double *scr = g.scratch + (size_t)g.long_scr[l] * kLongRow;
-        const double *ra = scr + (size_t)a * kLongRow, *rb = scr + (size_t)b * kLongRow;
-        const int ja = g.obs_cam[os + a], jb = g.obs_cam[os + b];
-        if (!g.cam_fixed[ja] && !g.cam_fixed[jb]) {         // a fixed camera has A = 0: the block vanishes
-            int lo = g.up_row[ja], hi = g.up_row[ja + 1] - 1; // cameras ascend inside a point: ja <= jb
-            while (lo <= hi) { const int mid = (lo + hi) >> 1, c = g.up_col[mid]; if (c < jb) lo = mid + 1; else if (c > jb) hi = mid - 1; else { gb = mid; break; } }
-        }
-        if (gb >= 0) {
-            double M00 = ra[24] * rb[16] + ra[25] * rb[17] + ra[26] * rb[18], M01 = ra[24] * rb[19] + ra[25] * rb[20] + ra[26] * rb[21];
-            double M10 = ra[27] * rb[16] + ra[28] * rb[17] + ra[29] * rb[18], M11 = ra[27] * rb[19] + ra[28] * rb[20] + ra[29] * rb[21];
-            const double dg = (a == b) ? 1.0 : 0.0;
-            M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
-            double T0[CNP], T1[CNP];
+    const int lane = threadIdx.x, w = blockIdx.x;
+    long long q0, q1;
+    int gb, cam = 0;
+    if constexpr (DIAG) { cam = g.diag_cam[w]; gb = g.diag_blk[w]; q0 = g.rec_cam[cam]; q1 = g.rec_cam[cam + 1]; }
+    else { gb = g.wk_blk[w]; q0 = g.wk_q[w]; q1 = g.wk_q[w + 1]; }
+    const uint2 *rp = reinterpret_cast<const uint2 *>(g.rpair);
+    double acc[NV];
 #pragma unroll
-            for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, rb[8 + c], M00 * rb[c]); T1[c] = fma(M11, rb[8 + c], M10 * rb[c]); }
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    uint2 ent_next = make_uint2(0u, 0u);
+    if constexpr (!DIAG) { if (q0 + lane < q1) ent_next = rp[q0 + lane]; }
+    for (long long q = q0 + lane; q < q1; q += kWave) {
+        size_t ra, rb;
+        if constexpr (DIAG) { ra = rb = (size_t)q; }
+        else { ra = ent_next.x; rb = ent_next.y; if (q + kWave < q1) ent_next = rp[q + kWave]; }
+        const double2 *pa = reinterpret_cast<const double2 *>(g.rec + ra * kRec);
+        const double2 *pb = reinterpret_cast<const double2 *>(g.rec + rb * kRec);
+        double Aa[16], Ab[16], G[6], Bb[6];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const double2 v = pa[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { const double2 v = pa[12 + t]; G[2 * t] = v.x; G[2 * t + 1] = v.y; }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { const double2 v = pb[8 + t]; Bb[2 * t] = v.x; Bb[2 * t + 1] = v.y; }
+        if constexpr (DIAG) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) Ab[t] = Aa[t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const double2 v = pb[t]; Ab[2 * t] = v.x; Ab[2 * t + 1] = v.y; }
+        }
+        // M = delta_ab I - G_a B_b^T;  G = [G0 (3) | G1 (3)], B = [B0 (3) | B1 (3)]
+        double M00 = fma(G[2], Bb[2], fma(G[1], Bb[1], G[0] * Bb[0])), M01 = fma(G[2], Bb[5], fma(G[1], Bb[4], G[0] * Bb[3]));
+        double M10 = fma(G[5], Bb[2], fma(G[4], Bb[1], G[3] * Bb[0])), M11 = fma(G[5], Bb[5], fma(G[4], Bb[4], G[3] * Bb[3]));
+        const double dg = DIAG ? 1.0 : 0.0;
+        M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
+        double T0[CNP], T1[CNP];
+#pragma unroll
+        for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, Ab[8 + c], M00 * Ab[c]); T1[c] = fma(M11, Ab[8 + c], M10 * Ab[c]); }
+#pragma unroll
+        for (int r = 0; r < CNP; ++r)
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) acc[r * CNP + c] = fma(Aa[8 + r], T1[c], fma(Aa[r], T0[c], acc[r * CNP + c]));
+        if constexpr (DIAG) {
+            const double2 ee = pa[11], rr = pa[15];
 #pragma unroll
             for (int r = 0; r < CNP; ++r) {
-                const double a0 = ra[r], a1 = ra[8 + r];
-#pragma unroll
-                for (int c = 0; c < CNP; ++c) blk[r * CNP + c] = fma(a1, T1[c], a0 * T0[c]);
+                acc[BLK + r] = fma(Aa[8 + r], ee.y, fma(Aa[r], ee.x, acc[BLK + r]));
+                acc[BLK + CNP + r] = fma(Aa[8 + r], rr.y, fma(Aa[r], rr.x, acc[BLK + CNP + r]));
+                acc[BLK + 2 * CNP + r] = fma(Aa[8 + r], Aa[8 + r], fma(Aa[r], Aa[r], acc[BLK + 2 * CNP + r]));
             }
         }
     }
-    const int rr = lane / CNP, cc = lane - rr * CNP;
-    double *stage = sStage[wv];
-    for (int base = 0; base < kWave; base += kStage) {
-        const int ql = lane - base;
-        if (ql >= 0 && ql < kStage && gb >= 0) {
-            double *dst = stage + ql * BLK;
+    // the lanes' partial blocks -> one: the upper half of the wavefront onto the lower through LDS, then every value of
+    // the block is one lane's column sum over the <= 32 rows that hold something
+    const long long npairs = q1 - q0;
+    if (npairs > 32) {
+        if (lane >= 32) {
 #pragma unroll
-            for (int i = 0; i < BLK; ++i) dst[i] = blk[i];
+            for (int i = 0; i < NV; ++i) sRed[(lane - 32) * ST + i] = acc[i];
         }
         wave_lds_sync();
-        for (int q2 = 0; q2 < kStage; ++q2) {
-            const int gL = rl(gb, base + q2);
-            if (gL >= 0 && lane < BLK) gadd(&g.S_up[(size_t)gL * (kCP * kCP) + rr * kCP + cc], stage[q2 * BLK + lane]);
+        if (lane < 32) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) acc[i] += sRed[lane * ST + i];
         }
         wave_lds_sync();
+    }
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sRed[lane * ST + i] = acc[i];
+    }
+    wave_lds_sync();
+    const int rows = npairs < 32 ? (int)npairs : 32;
+    for (int c = lane; c < NV; c += kWave) {
+        double s0 = 0.0, s1 = 0.0;
+        int r = 0;
+        for (; r + 1 < rows; r += 2) { s0 += sRed[r * ST + c]; s1 += sRed[(r + 1) * ST + c]; }
+        if (r < rows) s0 += sRed[r * ST + c];
+        const double v = s0 + s1;
+        if (c < BLK) {
+            double *dst = g.S_up + (size_t)gb * (kCP * kCP) + (c / CNP) * kCP + (c % CNP);
+            *dst += v;        // the register tiles of the same linearisation (an earlier kernel on this stream) may have added here already
+        } else if constexpr (DIAG) {
+            const int which = (c - BLK) / CNP, t = (c - BLK) % CNP;
+            if (which < 2 || g.want_diag) g.camvec[((size_t)which * g.m + cam) * kCP + t] += v;
+        }
     }
 }
 
@@ -944,11 +948,10 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
     const int l = blockIdx.x, ip = g.long_pts[l], tid = threadIdx.x;
     const int os = g.pt_obs[ip], oe = g.pt_obs[ip + 1];
     const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
-    const double *scr = g.scratch + (size_t)g.long_scr[l] * kLongRow; // A, B, e of this trial's k_long_reduce
     double t3[3] = { 0, 0, 0 };
     for (int o = os + tid; o < oe; o += 256) {
         const int j = g.obs_cam[o];
-        const double *row = scr + (size_t)(o - os) * kLongRow;
+        const double *row = g.rec + (size_t)g.obs_rec[o] * kRec; // A, B, e of this trial's k_long_reduce
         double w0 = 0.0, w1 = 0.0;
 #pragma unroll
         for (int t = 0; t < CNP; ++t) { const double dd = g.dA[j * kCP + t]; w0 += row[t] * dd; w1 += row[8 + t] * dd; }
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
     double cn = 0.0, pct = 0.0;
     for (int o = os + tid; o < oe; o += 256) {
         const int j = g.obs_cam[o];
-        const double *row = scr + (size_t)(o - os) * kLongRow;
+        const double *row = g.rec + (size_t)g.obs_rec[o] * kRec;
         const double2 xy = g.obs_xy[o];
         double u, v;
         project_obs<true>(g.cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, xy, u, v);
@@ -1848,17 +1851,23 @@ void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
 void launch_long_build(hipStream_t st, int cnp, const LongArgs &a)
 {
     if (a.nlong <= 0) return;
-    const unsigned gx = (unsigned)((a.max_pairs + 255) / 256);
-    if (cnp == 8) {
-        hipLaunchKernelGGL((k_long_reduce<8>), dim3(a.nlong), dim3(256), 0, st, a);
-        hipLaunchKernelGGL((k_long_pairs<8>), dim3(gx, a.nlong), dim3(256), 0, st, a);
-    } else if (cnp == 7) {
-        hipLaunchKernelGGL((k_long_reduce<7>), dim3(a.nlong), dim3(256), 0, st, a);
-        hipLaunchKernelGGL((k_long_pairs<7>), dim3(gx, a.nlong), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((k_long_reduce<6>), dim3(a.nlong), dim3(256), 0, st, a);
-        hipLaunchKernelGGL((k_long_pairs<6>), dim3(gx, a.nlong), dim3(256), 0, st, a);
-    }
+    if (cnp == 8) hipLaunchKernelGGL((k_long_reduce<8>), dim3(a.nlong), dim3(256), 0, st, a);
+    else if (cnp == 7) hipLaunchKernelGGL((k_long_reduce<7>), dim3(a.nlong), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_long_reduce<6>), dim3(a.nlong), dim3(256), 0, st, a);
+}
+
+template <int CNP>
+static void launch_schur_blocks_t(hipStream_t st, const SchurArgs &a)
+{
+    if (a.ndiag > 0) hipLaunchKernelGGL((k_schur_blocks<CNP, true>), dim3(a.ndiag), dim3(64), 0, st, a);
+    if (a.nwork > 0) hipLaunchKernelGGL((k_schur_blocks<CNP, false>), dim3(a.nwork), dim3(64), 0, st, a);
+}
+
+void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a)
+{
+    if (cnp == 8) launch_schur_blocks_t<8>(st, a);
+    else if (cnp == 7) launch_schur_blocks_t<7>(st, a);
+    else launch_schur_blocks_t<6>(st, a);
 }
 
 void launch_long_backsub(hipStream_t st, int cnp, const LongArgs &a)

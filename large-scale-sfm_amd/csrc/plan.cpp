@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <numeric>
 #include <thread>
 #include <unordered_map>
@@ -50,7 +51,7 @@ static void parallel_ranges(int n, F fn)
 }
 
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
-                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs)
+                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs, bool all_rows)
 {
     if (n <= 0 || m <= 0 || nobs < 0) return "empty problem";
     if (world < 1 || rank < 0 || rank >= world) return "bad rank/world";
@@ -111,7 +112,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     std::iota(pl.perm.begin(), pl.perm.end(), 0);
     auto deg = [&](int i) { return pt_ptr[i + 1] - pt_ptr[i]; };
     std::vector<uint8_t> cls(n);
-    for (int i = 0; i < n; ++i) cls[i] = (uint8_t)point_class(deg(i));
+    for (int i = 0; i < n; ++i) { cls[i] = (uint8_t)point_class(deg(i)); if (all_rows && cls[i] == 0) cls[i] = 1; }
     auto by_class_then_signature = [&](int a, int b) {
         int ca = cls[a], cb = cls[b];
         if (ca != cb) return ca < cb;
@@ -159,18 +160,27 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                 for (int q = first[g]; q < first[g + 1]; ++q) pl.perm[w++] = hashed[q].second;   // index order inside a group
         }
     }
-    if (kMinRunObs > 0) { // optional: points whose camera set hardly repeats -> direct tiles (see plan.h: measured slower, off)
+    {   // a camera set has to repeat to earn a register-accumulated tile: short runs take the row path (plan.h kMinRunPts).
+        // perm is sorted by (class, signature); moving a subset of class 0 to class 1 keeps both parts in signature order,
+        // so the new order is a stable partition plus one merge of the two class-1 pieces
+        int min_run = kMinRunPts;
+        if (const char *ev = std::getenv("MI_BA_MIN_RUN_PTS")) min_run = std::atoi(ev);
         bool changed = false;
-        int t0 = 0;
-        while (t0 < n && cls[pl.perm[t0]] == 0) {
+        int t0 = 0, n0 = 0;
+        while (n0 < n && cls[pl.perm[n0]] == 0) ++n0;
+        while (t0 < n0) {
             const int i0 = pl.perm[t0], d = deg(i0);
             int t1 = t0 + 1;
-            while (t1 < n && cls[pl.perm[t1]] == 0 && deg(pl.perm[t1]) == d &&
-                   std::memcmp(cam.data() + pt_ptr[i0], cam.data() + pt_ptr[pl.perm[t1]], sizeof(int) * d) == 0) ++t1;
-            if ((int64_t)(t1 - t0) * d < kMinRunObs) { for (int t = t0; t < t1; ++t) cls[pl.perm[t]] = 1; changed = true; }
+            while (t1 < n0 && deg(pl.perm[t1]) == d && std::memcmp(cam.data() + pt_ptr[i0], cam.data() + pt_ptr[pl.perm[t1]], sizeof(int) * d) == 0) ++t1;
+            if (t1 - t0 < min_run) { for (int t = t0; t < t1; ++t) cls[pl.perm[t]] = 1; changed = true; }
             t0 = t1;
         }
-        if (changed) std::sort(pl.perm.begin(), pl.perm.end(), by_class_then_signature);
+        if (changed) {
+            int n1 = n0;
+            while (n1 < n && cls[pl.perm[n1]] == 1) ++n1;                       // old class 1: [n0, n1)
+            auto mid = std::stable_partition(pl.perm.begin(), pl.perm.begin() + n0, [&](int i) { return cls[i] == 0; });
+            std::inplace_merge(mid, pl.perm.begin() + n0, pl.perm.begin() + n1, by_class_then_signature);
+        }
     }
     pl.n_active = 0;
     for (int i = 0; i < n; ++i) if (deg(i) > 0) pl.n_active++;
@@ -279,12 +289,12 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     // ---- batches and tiles (as a lambda: the automatic tile length needs a first pass to see where the
     // slot / camera budgets force tiles to end)
     std::vector<std::pair<int, bool>> tile_log; // per LDS tile: batches, closed only because of the length cap
-    int t = 0;
+    int t = 0, t_rows = 0;            // t_rows: first local point of the row path
     std::string tiling_error;
     // dry: only the shape of the LDS tiles (tile_log) is wanted -- no pair entries, no slots per observation, class 0 only
     auto do_tiling = [&](int tile_max_batches, bool dry) {
     tile_log.clear();
-    pl.pair.clear(); pl.pair_gblk.clear(); pl.slot_gblk.clear(); pl.cslot_cam.clear(); pl.tile_mode.clear();
+    pl.pair.clear(); pl.slot_gblk.clear(); pl.cslot_cam.clear(); pl.tile_mode.clear();
     pl.long_pts.clear(); pl.max_slots = 0;
     std::fill(pl.obs_cslot.begin(), pl.obs_cslot.end(), 0);
     pl.batch_obs.assign(1, 0); pl.batch_pt.assign(1, 0); pl.batch_pair.assign(1, 0);
@@ -315,15 +325,6 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     auto close_batch = [&](int t_end) {
         if (cur_obs == 0) return;
         if (rounds_mode) flush_round();
-        else if (!dry) {
-            // direct tiles: the batch's pairs in block order, so that pairs of different points that land on the same
-            // block sit in neighbouring lanes and the kernel merges them before the atomic (k_build, direct branch)
-            const size_t q0 = (size_t)pl.batch_pair.back(), q1 = pl.pair.size(), base = (size_t)pl.npair_lds;
-            std::vector<std::pair<uint32_t, uint32_t>> tmp(q1 - q0);
-            for (size_t q = q0; q < q1; ++q) tmp[q - q0] = { pl.pair_gblk[q - base], pl.pair[q] };
-            std::stable_sort(tmp.begin(), tmp.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
-            for (size_t q = q0; q < q1; ++q) { pl.pair_gblk[q - base] = tmp[q - q0].first; pl.pair[q] = tmp[q - q0].second; }
-        }
         pl.batch_obs.push_back(pl.pt_obs[t_end]);
         pl.batch_pt.push_back(t_end);
         pl.batch_pair.push_back((int64_t)pl.pair.size());
@@ -415,23 +416,17 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     pl.ntile_lds = pl.ntile();
     pl.nbatch_lds = pl.nbatch();
 
-    // class 1: direct tiles (pairs add straight into S with global atomics); dense pair list
+    // class 1: row tiles -- batches of whole points, no pair entries: the linearisation leaves one record per observation
+    // and k_schur_blocks sums the blocks from the pair lists built below
     rounds_mode = false;
+    t_rows = t;
     for (; t < npl; ++t) {
         int d = pl.pt_obs[t + 1] - pl.pt_obs[t];
         if (cls[pl.perm[pl.pt_begin + t]] != 1) break;
-        const int *c = pl.obs_cam.data() + pl.pt_obs[t];
         if (cur_obs + d > kWave || pts_in_batch >= kMaxPtsBatch) {
             close_batch(t);
             if (batches_in_tile >= tile_max_batches) close_tile(0);
         }
-        for (int a = 0; a < d; ++a)
-            for (int b = a; b < d; ++b) {
-                int g = pl.upper_block(c[a], c[b]);
-                if (g < 0) { tiling_error = "internal: block missing from pattern"; return; }
-                pl.pair.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6));
-                pl.pair_gblk.push_back((uint32_t)g);
-            }
         cur_obs += d; pts_in_batch++;
     }
     close_batch(t);
@@ -481,6 +476,72 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             cur += d; ++pts;
         }
         if (cur) { pl.bs_batch_obs.push_back(pl.pt_obs[nshort]); pl.bs_batch_pt.push_back(nshort); }
+    }
+    stage("back-substitution batches");
+    // ---- row path: records camera-major (points ascending inside a camera), and for every block of S the list of its
+    // (record of the row camera, record of the column camera) pairs, in point order.  The role of sba's per-camera scans
+    // (sba_crsm_col_elmidxs, sba_levmar.c:1185) -- done once per problem instead of once per camera per iteration.
+    {
+        pl.nrow_pts = npl - t_rows;
+        pl.obs_rec.assign(nol, -1);
+        pl.rec_cam.assign(m + 1, 0);
+        const int o_rows = pl.pt_obs[t_rows];
+        for (int o = o_rows; o < nol; ++o) pl.rec_cam[pl.obs_cam[o] + 1]++;
+        for (int j = 0; j < m; ++j) pl.rec_cam[j + 1] += pl.rec_cam[j];
+        {
+            std::vector<int> fill(pl.rec_cam.begin(), pl.rec_cam.end() - 1);
+            for (int o = o_rows; o < nol; ++o) pl.obs_rec[o] = fill[pl.obs_cam[o]]++;
+        }
+        const int nbu = pl.nb_up();
+        const int nrow = npl - t_rows;
+        const int nt = nrow < (1 << 14) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::vector<int>> cnt(nt, std::vector<int>(nrow ? nbu : 0, 0));
+        std::atomic<bool> missing(false);
+        auto walk = [&](int k, bool fill_pass, std::vector<int64_t> *pos) {
+            const int b0 = t_rows + (int)((int64_t)nrow * k / nt), b1 = t_rows + (int)((int64_t)nrow * (k + 1) / nt);
+            for (int tt = b0; tt < b1; ++tt) {
+                const int os = pl.pt_obs[tt], d = pl.pt_obs[tt + 1] - os;
+                const int *c = pl.obs_cam.data() + os;
+                for (int a = 0; a < d; ++a) {
+                    const int *rb = pl.up_col.data() + pl.up_row[c[a]], *re = pl.up_col.data() + pl.up_row[c[a] + 1];
+                    const int *it = rb;
+                    for (int b = a + 1; b < d; ++b) {
+                        it = std::lower_bound(it, re, c[b]);             // cameras ascend inside a point: the search only moves right
+                        if (it == re || *it != c[b]) { missing = true; return; }
+                        const int g = (int)(it - pl.up_col.data());
+                        if (!fill_pass) cnt[k][g]++;
+                        else {
+                            const int64_t q = (*pos)[g]++;
+                            pl.rpair[2 * q] = (uint32_t)pl.obs_rec[os + a]; pl.rpair[2 * q + 1] = (uint32_t)pl.obs_rec[os + b];
+                        }
+                    }
+                }
+            }
+        };
+        auto run_threads = [&](const std::function<void(int)> &fn) {
+            if (nt == 1) { fn(0); return; }
+            std::vector<std::thread> th;
+            for (int k = 0; k < nt; ++k) th.emplace_back(fn, k);
+            for (auto &x : th) x.join();
+        };
+        if (nrow) run_threads([&](int k) { walk(k, false, nullptr); });
+        if (missing) return "internal: block missing from pattern";
+        // block g's pairs: [base[g], base[g + 1]), thread k's share of them after the shares of the threads before it
+        std::vector<int64_t> base(nbu + 1, 0);
+        std::vector<std::vector<int64_t>> pos(nt);
+        if (nrow) {
+            for (int g = 0; g < nbu; ++g) { int64_t tot = 0; for (int k = 0; k < nt; ++k) tot += cnt[k][g]; base[g + 1] = base[g] + tot; }
+            for (int k = 0; k < nt; ++k) pos[k].resize(nbu);
+            for (int g = 0; g < nbu; ++g) { int64_t at = base[g]; for (int k = 0; k < nt; ++k) { pos[k][g] = at; at += cnt[k][g]; } }
+        }
+        pl.rpair.assign((size_t)(2 * base[nbu]), 0u);
+        if (nrow) run_threads([&](int k) { walk(k, true, &pos[k]); });
+        pl.wk_blk.clear(); pl.wk_q.assign(1, 0); pl.wk_diag_cam.clear(); pl.wk_diag_blk.clear();
+        for (int g = 0; g < nbu; ++g)
+            if (base[g + 1] > base[g]) { pl.wk_blk.push_back(g); pl.wk_q.push_back(base[g + 1]); }
+        for (int j = 0; j < m; ++j)
+            if (pl.rec_cam[j + 1] > pl.rec_cam[j]) { pl.wk_diag_cam.push_back(j); pl.wk_diag_blk.push_back(pl.upper_block(j, j)); }
+        stage("row path: records + pair lists");
     }
     return "";
 }

@@ -14,6 +14,11 @@
 //     kPairInvalid): a round holds whole points, and points with the same camera set put the
 //     same block on the same lane round after round, so k_build keeps that block in registers
 //     and touches the LDS accumulator only when the lane's block changes;
+//   * points whose camera set does not repeat (a signature run shorter than kMinRunPts points), points with more views
+//     than an LDS tile's block table holds, and tracks longer than a wavefront take the ROW path instead: the
+//     linearisation leaves one 256-byte record per observation in HBM, camera-major (k_build's row tiles,
+//     k_long_reduce), and k_schur_blocks sums every block of S from the plan-time list of its (record, record) pairs --
+//     one wavefront per block, no atomics, a fixed order (sba_levmar.c:1182-1339 visits any visibility at the same cost);
 //   * S = U* - W V*^-1 W^T is block sparse by co-visibility: upper pattern + full BSR pattern.
 #pragma once
 #include <cstdint>
@@ -32,8 +37,11 @@ constexpr int kMaxRounds = 8;    // pair rounds per LDS-tile batch (k_build prel
 constexpr uint32_t kPairInvalid = 0xFFFFFFFFu; // padding entry of a pair round
 constexpr int kMaxViewsLds = 10;        // d(d+1)/2 <= kNSlot
 constexpr int kTableRuns = 4;           // a tile whose points change camera set more often than this sums its blocks in an LDS table
-constexpr int kMinRunObs = 0;           // > 0: camera sets repeating over fewer observations go to the direct tiles.  Measured (tools/real_run.py,
-                                        // every point a different camera set): 32 made the build 1.2-3x SLOWER than poorly packed register tiles -> off
+constexpr int kMinRunPts = 12;          // a camera set shared by fewer consecutive points than this goes to the row path: a register-resident block is
+                                        // handed to HBM once per run (49 f64 atomics per block, ~120 G elements/s chip-wide), the row path costs ~2.5x the
+                                        // per-point work and no atomics; break-even ~14 points.  MI_BA_MIN_RUN_PTS overrides (probes);
+                                        // mi_ba_config.deterministic sends EVERY point down the row path
+constexpr int kRec = 32;                // doubles per observation record: A (2 x 8) | B (6) | e (2) | G = B V*^-1 (6) | e - B h (2)
 constexpr int kCP = 8;           // padded camera block dimension (cnp <= 8)
 
 struct Plan {
@@ -57,14 +65,21 @@ struct Plan {
     std::vector<int> bs_batch_obs, bs_batch_pt;      // batches of k_backsub (same points, packed regardless of tiles)
     std::vector<int64_t> batch_pair;                 // nbatch+1
     std::vector<int> tile_batch, tile_slot, tile_cslot; // ntile+1
-    std::vector<uint8_t> tile_mode;                  // 1 register-accumulated blocks, 2 blocks summed in an LDS table, 0 direct global atomics
+    std::vector<uint8_t> tile_mode;                  // 1 register-accumulated blocks, 2 blocks summed in an LDS table, 0 row tiles (records to HBM)
     int ntile_table = 0;                             // tiles of mode 2
     std::vector<int> slot_gblk, cslot_cam;
-    std::vector<uint32_t> pair;                      // la | lb<<6 | slot<<12 (6 bits) | local point<<18 (LDS tiles)
-    std::vector<uint32_t> pair_gblk;                 // direct pairs only: upper block id
-    int64_t npair_lds = 0;                           // pairs [0,npair_lds) belong to LDS tiles
+    std::vector<uint32_t> pair;                      // la | lb<<6 | slot<<12 (6 bits) | local point<<18 (LDS tiles only)
+    int64_t npair_lds = 0;                           // = pair.size()
+    // row path (class 1 and 2 points): records camera-major, points ascending inside a camera
+    std::vector<int> obs_rec;                        // per local observation: its record, -1 = an observation of an LDS tile
+    std::vector<int> rec_cam;                        // m+1: camera a's records are [rec_cam[a], rec_cam[a+1])
+    std::vector<int> wk_blk;                         // work items of k_schur_blocks, off-diagonal blocks: upper block id ...
+    std::vector<int64_t> wk_q;                       // ... and its pairs rpair[2 wk_q[w] .. 2 wk_q[w+1])
+    std::vector<uint32_t> rpair;                     // per pair: record of the row camera's observation, record of the column camera's
+    std::vector<int> wk_diag_cam, wk_diag_blk;       // diagonal work items: cameras with records, and their diagonal block
+    int64_t nrow_pts = 0;                            // points on the row path (long ones included)
     int ntile_lds = 0, nbatch_lds = 0;
-    std::vector<int> long_pts;                       // local points with > kWave observations
+    std::vector<int> long_pts;                       // local points with > kWave observations (row path, workgroup per point)
     int max_slots = 0;
 
     int64_t npts_local() const { return pt_end - pt_begin; }
@@ -79,7 +94,8 @@ struct Plan {
 // pt_idx must be non-decreasing.  Returns "" or an error message.
 // extra_pairs: camera pairs (2 ints each) whose block of S must exist although no point links them
 // (parameter couplings between cameras, kernels.h CamLinks)
+// all_rows: every point takes the row path (the deterministic mode: no floating-point atomics anywhere)
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
-                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs = nullptr);
+                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs = nullptr, bool all_rows = false);
 
 } // namespace miba

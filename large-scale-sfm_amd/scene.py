@@ -26,6 +26,9 @@ CONFIGS = {
     "C2": (200, 100_000, 10),
     "C3": (1_000, 1_000_000, 10),
     "micro": (5, 50, 4),
+    # BAL-Ladybug-like (BASELINE config C4): ~1.7k cameras along a closed path, heavy-tailed track lengths 3 .. 120 (a few
+    # longer than a wavefront), camera sets that hardly ever repeat, a wide band in S; ~3.7 M observations
+    "C4": (1_700, 400_000, 120),
 }
 SEED_BASE = 20260
 
@@ -95,9 +98,13 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
                seed: int | None = None, proj_sign: float = -1.0, explicit_centers: int = 1,
                est_focal: int = 1, strides=(1, 2, 3), noise_px: float = 0.25,
                cam_noise: float = 0.005, f_noise: float = 0.01, pt_noise: float = 0.01,
-               undistort: int = 0, nk: int = 2, k_true=(-0.25, 0.12), md_k: float = -1.25e-7) -> Scene:
+               undistort: int = 0, nk: int = 2, k_true=(-0.25, 0.12), md_k: float = -1.25e-7,
+               track_len: np.ndarray | None = None) -> Scene:
     """undistort 1: Bundler's projection distortion with nk coefficients k_true; undistort 2: PBA's measurement
-    distortion x (1 + md_k |x|^2) = projection (SparseBundleCPU.cpp:1188-1193), one coefficient"""
+    distortion x (1 + md_k |x|^2) = projection (SparseBundleCPU.cpp:1188-1193), one coefficient.
+    track_len [n]: per-point number of views (<= d): the point is seen by the first track_len[i] cameras of its stride run"""
+    if name == "C4" and track_len is None and m is None and n is None and d is None:
+        return ladybug_like_scene(seed=seed, proj_sign=proj_sign, explicit_centers=explicit_centers, est_focal=est_focal)
     if name in CONFIGS:
         cm, cn, cd = CONFIGS[name]
         idx = list(CONFIGS).index(name)
@@ -125,15 +132,26 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
     X_true = rng.uniform(-1, 1, (n, 3))
     start = rng.integers(0, m, n)
     stride = rng.choice(np.asarray(strides), n)
-    if m >= d * max(strides):
-        cams = (start[:, None] + stride[:, None] * np.arange(d)[None, :]) % m
-    else:  # tiny scenes: the stride pattern would wrap onto itself -> d distinct random cameras
-        assert d <= m
-        cams = np.argsort(rng.random((n, m)), axis=1)[:, :d]
-    cams.sort(axis=1)
-    obs_cam = cams.reshape(-1).astype(np.int32)
-    pt_ptr = (np.arange(n + 1) * d).astype(np.int32)
-    obs_pt = np.repeat(np.arange(n), d)
+    if track_len is not None:   # ragged tracks: flat arrays only (n x d would not fit for long-tailed lengths)
+        assert m >= d * max(strides) and track_len.max() <= d and track_len.min() >= 1
+        L = np.asarray(track_len, np.int64)
+        pt_ptr64 = np.concatenate([[0], np.cumsum(L)])
+        obs_pt = np.repeat(np.arange(n), L)
+        within = np.arange(pt_ptr64[-1]) - pt_ptr64[:-1][obs_pt]
+        cam = (start[obs_pt] + stride[obs_pt] * within) % m
+        order = np.lexsort((cam, obs_pt))               # cameras ascending inside a point
+        obs_cam = cam[order].astype(np.int32)
+        pt_ptr = pt_ptr64.astype(np.int32)
+    else:
+        if m >= d * max(strides):
+            cams = (start[:, None] + stride[:, None] * np.arange(d)[None, :]) % m
+        else:  # tiny scenes: the stride pattern would wrap onto itself -> d distinct random cameras
+            assert d <= m
+            cams = np.argsort(rng.random((n, m)), axis=1)[:, :d]
+        cams.sort(axis=1)
+        obs_cam = cams.reshape(-1).astype(np.int32)
+        pt_ptr = (np.arange(n + 1) * d).astype(np.int32)
+        obs_pt = np.repeat(np.arange(n), d)
 
     # --- measurements
     Xo = X_true[obs_pt]
@@ -177,3 +195,18 @@ def make_scene(name: str = "C1", *, m: int | None = None, n: int | None = None, 
                  pt_ptr=pt_ptr, obs_cam=obs_cam, x=np.ascontiguousarray(x),
                  R0=np.ascontiguousarray(R0.reshape(m, 9)), f_fixed=np.ascontiguousarray(f_init),
                  p0=p0, p_true=p_true, name=name, meta=dict(d=d, seed=int(SEED_BASE + idx if seed is None else seed)))
+
+
+def ladybug_like_scene(m: int | None = None, n: int | None = None, dmax: int | None = None, seed: int | None = None, **kw) -> Scene:
+    """BASELINE config C4's shape: many cameras along a closed path, every point seen by a run of neighbouring cameras whose
+    length is heavy-tailed (3 .. dmax, 1 % of the tracks at dmax: longer than a wavefront), so the camera sets hardly ever
+    repeat and the reduced camera system is a wide band"""
+    cm, cn, cd = CONFIGS["C4"]
+    m, n, dmax = m or cm, n or cn, dmax or cd
+    seed = SEED_BASE + list(CONFIGS).index("C4") if seed is None else seed
+    rng = np.random.default_rng(seed + 1)
+    L = np.minimum(2 + rng.geometric(0.14, n), dmax)
+    L[rng.random(n) < 0.01] = dmax
+    sc = make_scene("x", m=m, n=n, d=dmax, seed=seed, strides=(1,), track_len=L, **kw)
+    sc.name = "ladybug-like"
+    return sc

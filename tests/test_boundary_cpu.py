@@ -285,13 +285,14 @@ def test_bundler_out_round_trip_and_invisible_points(tmp_path):
     L.mi_model_free(h)
 
 
-def _check_plan(sc, rank=0, world=1, tmb=0):
+def _check_plan(sc, rank=0, world=1, tmb=0, all_rows=False):
     capi = pkg("capi")
-    pl = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam, rank, world, tmb)
+    pl = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam, rank, world, tmb, all_rows=all_rows)
     st = pl.stats()
     g = {k: pl.get(k) for k in ("perm", "obs_cam", "obs_pt", "obs_src", "pt_obs", "batch_obs", "batch_pt", "batch_pair", "tile_batch",
-                                "tile_slot", "slot_gblk", "tile_cslot", "cslot_cam", "pair", "pair_gblk", "obs_cslot", "up_row",
-                                "up_col", "bsr_row", "bsr_col", "bsr_src", "bsr_trans", "tile_mode")}
+                                "tile_slot", "slot_gblk", "tile_cslot", "cslot_cam", "pair", "obs_cslot", "up_row",
+                                "up_col", "bsr_row", "bsr_col", "bsr_src", "bsr_trans", "tile_mode", "obs_rec", "rec_cam", "wk_blk", "wk_q",
+                                "rpair", "wk_diag_cam", "wk_diag_blk", "long_pts")}
     assert sorted(g["perm"]) == list(range(sc.n))
     # observations: a permutation of this shard's original observations, cameras ascending inside a point
     assert np.array_equal(sc.obs_cam[g["obs_src"]], g["obs_cam"])
@@ -312,15 +313,19 @@ def _check_plan(sc, rank=0, world=1, tmb=0):
     # pairs: every (a <= b) pair of every point exactly once, slot / gblk = the (cam_a, cam_b) block
     nb, seen = len(g["batch_obs"]) - 1, 0
     tile_of_batch = np.repeat(np.arange(len(g["tile_batch"]) - 1), np.diff(g["tile_batch"]))
-    npair_lds = int(g["batch_pair"][st["nbatch"] - st["nbatch_direct"]]) if st["nbatch_direct"] < st["nbatch"] or True else 0
+    row_pts = set()
     for b in range(nb):
         o0, o1 = g["batch_obs"][b], g["batch_obs"][b + 1]
         assert 0 < o1 - o0 <= 64 and g["batch_pt"][b + 1] - g["batch_pt"][b] <= 32
         t = tile_of_batch[b]
         lds = g["tile_mode"][t] in (1, 2)
         ents = g["pair"][g["batch_pair"][b]:g["batch_pair"][b + 1]]
-        if lds:
-            assert len(ents) % 64 == 0
+        if not lds:                 # a row tile: no pair entries, every observation has a record
+            assert len(ents) == 0 and np.all(g["obs_rec"][o0:o1] >= 0)
+            row_pts |= set(range(g["batch_pt"][b], g["batch_pt"][b + 1]))
+            seen += o1 - o0
+            continue
+        assert len(ents) % 64 == 0 and np.all(g["obs_rec"][o0:o1] == -1)
         got = set()
         for q, e in enumerate(ents):
             if e == 0xFFFFFFFF:
@@ -329,13 +334,10 @@ def _check_plan(sc, rank=0, world=1, tmb=0):
             la, lb = int(e & 63), int((e >> 6) & 63)
             assert la <= lb < o1 - o0 and g["obs_pt"][o0 + la] == g["obs_pt"][o0 + lb]
             ja, jb = g["obs_cam"][o0 + la], g["obs_cam"][o0 + lb]
-            if lds:
-                blk = g["slot_gblk"][g["tile_slot"][t] + ((e >> 12) & 63)]
-                assert ((e >> 12) & 63) < g["tile_slot"][t + 1] - g["tile_slot"][t] <= 55
-                assert g["obs_pt"][o0 + la] - g["batch_pt"][b] == (e >> 18) & 31
-                assert g["cslot_cam"][g["tile_cslot"][t] + g["obs_cslot"][o0 + la]] == ja
-            else:
-                blk = g["pair_gblk"][g["batch_pair"][b] + q - npair_lds]
+            blk = g["slot_gblk"][g["tile_slot"][t] + ((e >> 12) & 63)]
+            assert ((e >> 12) & 63) < g["tile_slot"][t + 1] - g["tile_slot"][t] <= 55
+            assert g["obs_pt"][o0 + la] - g["batch_pt"][b] == (e >> 18) & 31
+            assert g["cslot_cam"][g["tile_cslot"][t] + g["obs_cslot"][o0 + la]] == ja
             assert blk == up[(ja, jb)]
             got.add((la, lb))
         want = set()
@@ -344,23 +346,54 @@ def _check_plan(sc, rank=0, world=1, tmb=0):
             want |= {(a, c) for a in range(s, e_) for c in range(a, e_)}
         assert got == want
         seen += o1 - o0
-    assert seen + sum(np.diff(g["pt_obs"])[pl.get("long_pts")]) == st["nobs_local"]
+    assert seen + sum(np.diff(g["pt_obs"])[g["long_pts"]]) == st["nobs_local"]
+    # ---- the row path: records camera-major with points ascending inside a camera; every (a < b) pair of every row point
+    # exactly once in the list of its block, in point order; a diagonal item for every camera that has records
+    row_pts |= set(int(p) for p in g["long_pts"])
+    assert len(row_pts) == st["nrow_pts"]
+    rec_of = g["obs_rec"]
+    have = np.flatnonzero(rec_of >= 0)
+    assert len(have) == st["nrec"] == g["rec_cam"][-1] and sorted(rec_of[have]) == list(range(len(have)))
+    rec_obs = np.zeros(len(have), np.int64); rec_obs[rec_of[have]] = have
+    for j in range(sc.m):
+        r = rec_obs[g["rec_cam"][j]:g["rec_cam"][j + 1]]
+        assert np.all(g["obs_cam"][r] == j) and np.all(np.diff(g["obs_pt"][r]) > 0)
+    assert list(g["wk_diag_cam"]) == [j for j in range(sc.m) if g["rec_cam"][j + 1] > g["rec_cam"][j]]
+    assert all(g["wk_diag_blk"][k] == up[(j, j)] for k, j in enumerate(g["wk_diag_cam"]))
+    got = {}
+    assert len(g["wk_q"]) == len(g["wk_blk"]) + 1 and g["wk_q"][-1] * 2 == len(g["rpair"]) and np.all(np.diff(g["wk_q"]) > 0)
+    assert np.all(np.diff(g["wk_blk"]) > 0)
+    for w, blk in enumerate(g["wk_blk"]):
+        pr = g["rpair"][2 * g["wk_q"][w]:2 * g["wk_q"][w + 1]].reshape(-1, 2)
+        oa, ob = rec_obs[pr[:, 0]], rec_obs[pr[:, 1]]
+        assert np.all(g["obs_pt"][oa] == g["obs_pt"][ob]) and np.all(np.diff(g["obs_pt"][oa]) > 0)
+        assert all(up[(a, b)] == blk for a, b in set(zip(g["obs_cam"][oa], g["obs_cam"][ob])))
+        got[blk] = set(g["obs_pt"][oa])
+    want = {}
+    for p in row_pts:
+        cams = g["obs_cam"][g["pt_obs"][p]:g["pt_obs"][p + 1]]
+        for a in range(len(cams)):
+            for b in range(a + 1, len(cams)):
+                want.setdefault(up[(cams[a], cams[b])], set()).add(p)
+    assert got == want
     return st, g
 
 
 def test_plan_tables_coherent_scene():
     sc = pkg("scene").make_scene("C1")
     st, g = _check_plan(sc)
-    assert st["nbatch_direct"] == 0 and st["npts_local"] == sc.n and st["nb_upper"] == len(g["up_col"])
+    assert st["nbatch_rows"] == 0 and st["npts_local"] == sc.n and st["nb_upper"] == len(g["up_col"]) and st["nrec"] == 0
+    st, g = _check_plan(sc, all_rows=True)        # the deterministic mode: every point on the row path
+    assert st["nbatch_rows"] == st["nbatch"] and st["nrec"] == sc.nobs and st["npair"] == 0
 
 
 def test_plan_tables_ragged_scene():
-    """track lengths 1..20 (LDS tiles and direct tiles), tiny tile budget"""
+    """track lengths 1..20 (register tiles and row tiles), tiny tile budget"""
     scene = pkg("scene")
     rng = np.random.default_rng(1)
     base = scene.make_scene("x", m=40, n=500, d=20, seed=2, strides=(1,))
     keep = [np.sort(rng.permutation(np.arange(base.pt_ptr[i], base.pt_ptr[i + 1]))[:rng.integers(1, 21)]) for i in range(base.n)]
-    # a camera set has to repeat to earn a register-accumulated tile (plan.h kMinRunObs): the first 350 points keep a
+    # a camera set has to repeat to earn a register-accumulated tile (plan.h kMinRunPts): the first 350 points keep a
     # prefix of their views whose length depends on the start camera only, so ~9 points share each camera set
     start = base.obs_cam[base.pt_ptr[:-1]]
     for i in range(350):
@@ -369,8 +402,12 @@ def test_plan_tables_ragged_scene():
     sc = scene.Scene(n=base.n, m=base.m, cnp=7, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0,
                      pt_ptr=np.concatenate([[0], np.cumsum([len(k) for k in keep])]).astype(np.int32),
                      obs_cam=base.obs_cam[sel], x=base.x[sel], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true)
-    st, g = _check_plan(sc, tmb=3)
-    assert 0 < st["nbatch_direct"] < st["nbatch"]
+    os.environ["MI_BA_MIN_RUN_PTS"] = "6"
+    try:
+        st, g = _check_plan(sc, tmb=3)
+    finally:
+        del os.environ["MI_BA_MIN_RUN_PTS"]
+    assert 0 < st["nbatch_rows"] < st["nbatch"] and 0 < st["nrow_pts"] < sc.n
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])

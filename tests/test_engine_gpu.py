@@ -261,7 +261,7 @@ def test_camera_links(oracle):
 @pytest.mark.parametrize("d", [5, 13])
 def test_measurement_distortion(oracle, d):
     """undistort 2 = PBA's measurement distortion x (1 + k |x|^2) = projection (SparseBundleCPU.cpp:1188-1193, 1427-1432);
-    LDS tiles (d 5) and direct tiles (d 13); the model is pinned to the reference's own PBA by
+    register tiles (d 5) and the row path (d 13); the model is pinned to the reference's own PBA by
     test_boundary_gpu.py::test_parallelba_against_the_references_own_parallelba[meas_dist]"""
     sc = pkg("scene").make_scene("x", m=40, n=1200, d=d, seed=8, undistort=2, proj_sign=1.0, explicit_centers=0)
     assert sc.cnp == 8 and sc.undistort == 2
@@ -282,11 +282,11 @@ def test_measurement_distortion(oracle, d):
 
 
 def test_long_tracks_use_direct_tiles(oracle):
-    """points with > 10 views bypass the LDS tile and add straight into S"""
+    """points with > 10 views take the row path: records to HBM, the blocks of S summed block-major without atomics"""
     sc = pkg("scene").make_scene("x", m=40, n=600, d=13, seed=5, strides=(1, 2, 3))
     capi = pkg("capi")
     st = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).stats()
-    assert st["nbatch_direct"] == st["nbatch"] and st["npair_direct"] == sc.n * 13 * 14 // 2
+    assert st["nbatch_rows"] == st["nbatch"] and st["npair_rows"] == sc.n * 13 * 12 // 2 and st["nrec"] == sc.nobs
     eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
     lin = oracle.linearize(sc, fd_jacobian=0)
     mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
@@ -349,7 +349,37 @@ def test_tracks_longer_than_a_wavefront(oracle):
     assert ret2 == o2["ret"] and abs(np.sqrt(info2[1] / sub.nobs) - np.sqrt(o2["info"][1] / sub.nobs)) < 1e-6
 
 
-def test_mixed_track_lengths_and_unsorted_cameras(oracle):
+@pytest.mark.parametrize("name", ["C1", "ragged"])
+def test_deterministic_mode_gives_the_same_bits_twice(oracle, name):
+    """mi_ba_config.deterministic: every point on the block-major row path, no floating-point atomics in the linear phase --
+    the reduced system, the trial trace and the answer are bit-identical from run to run (the reference is deterministic,
+    sba_levmar.c:1182-1339), and still the oracle's to the usual tolerances"""
+    if name == "C1":
+        sc, _ = scene_from_golden("C1")
+    else:
+        from helpers import ladybug_like_scene
+        sc = ladybug_like_scene(m=60, n=1500, dmax=80, seed=9)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    S, E, _ = reduced_system(lin, sc, mu)
+    runs = []
+    for rep in range(2):
+        eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, deterministic=1)
+        g = eng.debug_linearize(mu)
+        ret, info = eng.run()
+        runs.append((g["S"].copy(), g["E"].copy(), g["ea"].copy(), np.array(info), eng.packed_params().copy(), eng.trace().copy(), ret))
+        eng.close()
+    a, b = runs
+    for x, y in zip(a[:6], b[:6]):
+        assert np.array_equal(x, y)                        # bit for bit
+    assert a[6] == b[6]
+    assert np.abs(a[0] - S).max() < 1e-10 * np.abs(lin["U"]).max() and rel(a[1].reshape(-1), E) < 1e-9 and rel(a[2], lin["ea"]) < 1e-10
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert a[6] == o["ret"] and a[3][6] == o["info"][6] and abs(a[3][1] - o["info"][1]) < 1e-8 * o["info"][1]
+
+
+@pytest.mark.parametrize("min_run", [1, 12])
+def test_mixed_track_lengths_and_unsorted_cameras(oracle, monkeypatch, min_run):
     """ragged input: track lengths 2..14, cameras NOT sorted inside a point, some points unobserved"""
     scene = pkg("scene")
     rng = np.random.default_rng(3)
@@ -368,8 +398,12 @@ def test_mixed_track_lengths_and_unsorted_cameras(oracle):
                      pt_ptr=np.concatenate([[0], np.cumsum(np.bincount(pt, minlength=base.n))]).astype(np.int32),
                      obs_cam=cam[order], x=xy[order], R0=base.R0, f_fixed=base.f_fixed, p0=base.p0, p_true=base.p_true)
     capi = pkg("capi")
+    monkeypatch.setenv("MI_BA_MIN_RUN_PTS", str(min_run))     # 1: camera sets that never repeat still get LDS tiles (block table)
     modes = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).get("tile_mode")
-    assert (modes == 2).any() and (modes == 0).any()          # LDS block-table tiles (camera sets keep changing) and direct tiles
+    if min_run == 1:
+        assert (modes == 2).any() and (modes == 0).any()      # LDS block-table tiles (camera sets keep changing) and row tiles
+    else:
+        assert (modes == 0).all()                             # default: nothing repeats here, everything takes the row path
     eng = capi.Engine(capi.default_config(pcg_tol=1e-12, pcg_maxit=400))
     m, n, cnp = sc.m, sc.n, sc.cnp
     eng.set_problem(sc.p0[:m * cnp].reshape(m, cnp), sc.R0, sc.f_fixed, sc.p0[m * cnp:].reshape(n, 3), xy, pt, cam)
