@@ -850,7 +850,13 @@ __global__ __launch_bounds__(64, (CNP <= 7 && !DIAG) ? 2 : 1) void k_schur_block
     constexpr int ST = NV | 1;                       // odd row stride: the lanes' ds_write_b64 and the column reads are conflict-free
     __shared__ double sRed[32 * ST];
     if (g.spec && g.spec[0] == 0.0) return;
-    const int lane = threadIdx.x, w = blockIdx.x;
+    const int lane = threadIdx.x;
+    // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one), so XCD x takes the x-th
+    // contiguous eighth of the work list -- the blocks of one camera row, which re-read that camera's records, then meet
+    // in ONE L2 instead of in eight (placement is for speed only: any mapping gives the same sums)
+    const int per = (int)(gridDim.x >> 3);                      // the grid is 8 x ceil(items / 8)
+    const int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (w >= (DIAG ? g.ndiag : g.nwork)) return;
     long long q0, q1;
     int gb, cam = 0;
     if constexpr (DIAG) { cam = g.diag_cam[w]; gb = g.diag_blk[w]; q0 = g.rec_cam[cam]; q1 = g.rec_cam[cam + 1]; }
@@ -1859,8 +1865,8 @@ void launch_long_build(hipStream_t st, int cnp, const LongArgs &a)
 template <int CNP>
 static void launch_schur_blocks_t(hipStream_t st, const SchurArgs &a)
 {
-    if (a.ndiag > 0) hipLaunchKernelGGL((k_schur_blocks<CNP, true>), dim3(a.ndiag), dim3(64), 0, st, a);
-    if (a.nwork > 0) hipLaunchKernelGGL((k_schur_blocks<CNP, false>), dim3(a.nwork), dim3(64), 0, st, a);
+    if (a.ndiag > 0) hipLaunchKernelGGL((k_schur_blocks<CNP, true>), dim3(8 * ((a.ndiag + 7) / 8)), dim3(64), 0, st, a);
+    if (a.nwork > 0) hipLaunchKernelGGL((k_schur_blocks<CNP, false>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
 }
 
 void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a)

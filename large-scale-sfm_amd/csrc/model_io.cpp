@@ -704,7 +704,7 @@ int mi_optimizer_all_main(int argc, char **argv)
     if (!dir.empty() && dir.back() != '/') dir += '/';
     const int A = argc > 2 ? std::atoi(argv[2]) : 0;
     const int B = argc > 3 ? std::atoi(argv[3]) : 50;
-    std::printf("optimizer_all: A=%d (%s), B=%d LM iterations at most; ignored: C=%s D=%s E=%s F=%s (meaning not recoverable: the reference's main_all.cpp is missing)\n",
+    std::printf("optimizer_all: A=%d (%s), B=%d (iteration cap); ignored: C=%s D=%s E=%s F=%s (meaning not recoverable: the reference's main_all.cpp is missing)\n",
                 A, A >= 0 ? "poses, focal lengths and points free" : "focal lengths held", B > 0 ? B : 1,
                 argc > 4 ? argv[4] : "-", argc > 5 ? argv[5] : "-", argc > 6 ? argv[6] : "-", argc > 7 ? argv[7] : "-");
     const std::string nvm = dir + "outputVSFM_GB.nvm";

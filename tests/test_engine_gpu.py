@@ -358,7 +358,7 @@ def test_deterministic_mode_gives_the_same_bits_twice(oracle, name):
         sc, _ = scene_from_golden("C1")
     else:
         from helpers import ladybug_like_scene
-        sc = ladybug_like_scene(m=60, n=1500, dmax=80, seed=9)
+        sc = ladybug_like_scene(m=100, n=1500, dmax=80, seed=9)
     lin = oracle.linearize(sc, fd_jacobian=0)
     mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
     S, E, _ = reduced_system(lin, sc, mu)
