@@ -418,7 +418,10 @@ int mi_model_save_bundler_out(const mi_model *m, const char *path)
         while (je < m->nproj() && m->pt_idx[je] == (int)i) ++je;
         out << m->xyz[3 * i] << ' ' << m->xyz[3 * i + 1] << ' ' << m->xyz[3 * i + 2] << '\n' << m->rgb[3 * i] << ' ' << m->rgb[3 * i + 1] << ' '
             << m->rgb[3 * i + 2] << '\n' << (je - j) << ' ';
-        for (; j < je; ++j) out << m->cam_idx[j] << ' ' << m->feat_id[j] << ' ' << m->xy[2 * j] << ' ' << -m->xy[2 * j + 1] << ' ';
+        // one view per line and an empty line after the point, as SaveBundlerOut lays them out (util_VSFM.h:437-440); the key is
+        // passed through (the reference writes 0).  NOT reproduced: the reference counts a point's views with
+        // `j + npj < point_data.size()` (:433), so once j passes the number of POINTS it writes "0" views for every later point
+        for (; j < je; ++j) out << m->cam_idx[j] << ' ' << m->feat_id[j] << ' ' << m->xy[2 * j] << ' ' << -m->xy[2 * j + 1] << '\n';
         out << '\n';
     }
     std::ofstream listout(list);
