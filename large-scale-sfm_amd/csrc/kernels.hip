@@ -9,6 +9,8 @@
 // accumulation is by f64 atomics into zero-initialised HBM buffers only.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace miba {
 
 // ------------------------------------------------------------------------------------------
@@ -946,6 +948,119 @@ __global__ __launch_bounds__(64, (CNP <= 7 && !DIAG) ? 2 : 1) void k_schur_block
     }
 }
 
+// The off-diagonal blocks, staged: what bounds the kernel above there is the texture addresser -- a lane fetching its own two
+// records issues 22 divergent 16-byte requests per pair, and the addresser retires about one such request per cycle per CU
+// (measured: TA_BUSY 79 %, 22.4 cache accesses per pair, 34 cycles per pair per CU).  Here the wavefront fetches the 64 pairs'
+// records TOGETHER, four lanes per 64-byte line (one request per line: 6 per pair instead of 22), parks them in LDS and every
+// lane then reads its own pair's operands from there (ds_read_b128, conflict-free: 208-byte slots).  All 24 fetches of a round
+// are issued before anything is waited for: one round of memory latency per 64 pairs, as before.
+template <int CNP>
+__global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_pairs(const SchurArgs g)
+{
+    constexpr int BLK = CNP * CNP, ST = BLK | 1;
+    constexpr int SLOT = 26;                                        // doubles per pair and side in the staging buffer: 3 lines (24) + 2 pad = 208 B
+    constexpr int NBUF = (2 * kWave * SLOT > 32 * ST) ? 2 * kWave * SLOT : 32 * ST;
+    __shared__ __attribute__((aligned(16))) double sBuf[NBUF];
+    if (g.spec && g.spec[0] == 0.0) return;
+    const int lane = threadIdx.x;
+    const int per = (int)(gridDim.x >> 3);
+    const int w = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);          // XCD-aware order, as above
+    if (w >= g.nwork) return;
+    const int gb = g.wk_blk[w];
+    const long long q0 = g.wk_q[w], q1 = g.wk_q[w + 1];
+    const uint2 *rp = reinterpret_cast<const uint2 *>(g.rpair);
+    // the quad's pair of a round: consecutive quads take pairs 8 apart, so that the two quads of one 8-lane ds_write_b128 group
+    // hit slots 8 x 208 B = 32 banks apart (consecutive slots would overlap in 4 banks: measured 33 % of the LDS cycles)
+    const int quad = ((lane >> 2) & 1) * 8 + (lane >> 3), piece = lane & 3;
+    double acc[BLK];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
+    // the four pairs whose lines this lane helps to fetch (pair j * 16 + quad of a round), clamped inside the list; one round ahead
+    uint2 ent_next[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const long long q = q0 + j * 16 + quad; ent_next[j] = rp[q < q1 ? q : q1 - 1]; }
+    for (long long qb = q0; qb < q1; qb += kWave) {
+        uint2 ent[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ent[j] = ent_next[j];
+        if (qb + kWave < q1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const long long q = qb + kWave + j * 16 + quad; ent_next[j] = rp[q < q1 ? q : q1 - 1]; }
+        }
+        const bool valid = qb + lane < q1;
+        // all 24 line fetches of the round at once (one round of memory latency), then through LDS to the lanes that own the pairs
+        double2 st[2][12];
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {                          // instruction k: line k / 4 of pairs (k % 4) * 16 + quad
+                const int lj = k >> 2, j = k & 3;
+                const unsigned r = side == 0 ? ent[j].x : ent[j].y;
+                const int line = side == 0 ? (lj == 2 ? 3 : lj) : lj;    // a side: A (lines 0, 1), G (line 3); b side: A, B (line 2)
+                st[side][k] = *reinterpret_cast<const double2 *>(g.rec + (size_t)r * kRec + line * 8 + piece * 2);
+            }
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int lj = k >> 2, j = k & 3;
+                *reinterpret_cast<double2 *>(sBuf + side * (kWave * SLOT) + (j * 16 + quad) * SLOT + lj * 8 + piece * 2) = st[side][k];
+            }
+        wave_lds_sync();
+        double Aa[16], Ab[16], G[6], Bb[6];
+        {
+            const double2 *ma = reinterpret_cast<const double2 *>(sBuf + lane * SLOT);
+            const double2 *mb = reinterpret_cast<const double2 *>(sBuf + kWave * SLOT + lane * SLOT);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const double2 v = ma[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { const double2 v = ma[8 + t]; G[2 * t] = v.x; G[2 * t + 1] = v.y; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const double2 v = mb[t]; Ab[2 * t] = v.x; Ab[2 * t + 1] = v.y; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { const double2 v = mb[8 + t]; Bb[2 * t] = v.x; Bb[2 * t + 1] = v.y; }
+        }
+        wave_lds_sync();                                            // operands are in registers: the buffer is free for the next round
+        if (valid) {
+            const double M00 = -fma(G[2], Bb[2], fma(G[1], Bb[1], G[0] * Bb[0])), M01 = -fma(G[2], Bb[5], fma(G[1], Bb[4], G[0] * Bb[3]));
+            const double M10 = -fma(G[5], Bb[2], fma(G[4], Bb[1], G[3] * Bb[0])), M11 = -fma(G[5], Bb[5], fma(G[4], Bb[4], G[3] * Bb[3]));
+            double T0[CNP], T1[CNP];
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, Ab[8 + c], M00 * Ab[c]); T1[c] = fma(M11, Ab[8 + c], M10 * Ab[c]); }
+#pragma unroll
+            for (int r = 0; r < CNP; ++r)
+#pragma unroll
+                for (int c = 0; c < CNP; ++c) acc[r * CNP + c] = fma(Aa[8 + r], T1[c], fma(Aa[r], T0[c], acc[r * CNP + c]));
+        }
+    }
+    const long long npairs = q1 - q0;
+    if (npairs > 32) {
+        if (lane >= 32) {
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) sBuf[(lane - 32) * ST + i] = acc[i];
+        }
+        wave_lds_sync();
+        if (lane < 32) {
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) acc[i] += sBuf[lane * ST + i];
+        }
+        wave_lds_sync();
+    }
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) sBuf[lane * ST + i] = acc[i];
+    }
+    wave_lds_sync();
+    const int rows = npairs < 32 ? (int)npairs : 32;
+    if (lane < BLK) {
+        double s0 = 0.0, s1 = 0.0;
+        int r = 0;
+        for (; r + 1 < rows; r += 2) { s0 += sBuf[r * ST + lane]; s1 += sBuf[(r + 1) * ST + lane]; }
+        if (r < rows) s0 += sBuf[r * ST + lane];
+        g.S_up[(size_t)gb * (kCP * kCP) + (lane / CNP) * kCP + (lane % CNP)] += s0 + s1;
+    }
+}
+
 template <int CNP>
 __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
 {
@@ -1866,7 +1981,11 @@ template <int CNP>
 static void launch_schur_blocks_t(hipStream_t st, const SchurArgs &a)
 {
     if (a.ndiag > 0) hipLaunchKernelGGL((k_schur_blocks<CNP, true>), dim3(8 * ((a.ndiag + 7) / 8)), dim3(64), 0, st, a);
-    if (a.nwork > 0) hipLaunchKernelGGL((k_schur_blocks<CNP, false>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
+    if (a.nwork > 0) {
+        static const bool direct = std::getenv("MI_BA_SCHUR_DIRECT") != nullptr;   // probes: every lane fetches its own records
+        if (direct) hipLaunchKernelGGL((k_schur_blocks<CNP, false>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_schur_pairs<CNP>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
+    }
 }
 
 void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a)
