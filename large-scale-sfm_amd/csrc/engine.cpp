@@ -527,7 +527,11 @@ PcgArgs Engine::pcg_args()
     double *v = d_pcg_.p;
     p.da = d_dA_.p; p.x = v; p.p = v + vec; p.r0 = v + 2 * vec; p.r1 = v + 3 * vec; p.w0 = v + 4 * vec; p.w1 = v + 5 * vec;
     p.s0 = v + 6 * vec; p.s1 = v + 7 * vec;
-    p.ng = (m_ + 7) / 8; p.nwg = m_ <= kPcgRowPerWorkgroupMax ? m_ : (m_ + 3) / 4;
+    // a block row of S~ gets a whole workgroup (four wavefronts share its blocks) when there are few rows.  (Measured with more
+    // rows, MI_BA_PCG_ROW_WG=1: slower -- C3 0.27 -> 0.37 ms per solve, C4 (1 700 rows of ~240 blocks, S~ = 208 MB) 2.35 -> 2.62.)
+    static const int force_row_wg = std::getenv("MI_BA_PCG_ROW_WG") ? std::atoi(std::getenv("MI_BA_PCG_ROW_WG")) : -1;
+    const bool row_wg = force_row_wg >= 0 ? force_row_wg != 0 : m_ <= kPcgRowPerWorkgroupMax;
+    p.ng = (m_ + 7) / 8; p.nwg = row_wg ? m_ : (m_ + 3) / 4;
     p.rz_hist = d_rzpq_.p; p.alpha_hist = p.rz_hist + (cfg.pcg_maxit + 4); p.gp = p.alpha_hist + (cfg.pcg_maxit + 4); p.dp = p.gp + 2 * (size_t)p.nwg;
     p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = m_; p.it = 0;
     return p;
