@@ -88,9 +88,9 @@ int mi_ba_set_timing_detail(mi_ba_engine *h, int level) { if (!h) return MI_BA_E
 int mi_ba_reset_timing(mi_ba_engine *h)
 {
     if (!h) return MI_BA_ERROR;
-    const double bytes = h->e->timing.build_bytes, flops = h->e->timing.build_flops;
+    const double bytes = h->e->timing.build_bytes, flops = h->e->timing.build_flops, index = h->e->timing.build_index_bytes;
     h->e->timing = mi_ba_timing{};
-    h->e->timing.build_bytes = bytes; h->e->timing.build_flops = flops;
+    h->e->timing.build_bytes = bytes; h->e->timing.build_flops = flops; h->e->timing.build_index_bytes = index;
     return 0;
 }
 

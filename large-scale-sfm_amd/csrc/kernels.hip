@@ -363,8 +363,9 @@ __device__ __forceinline__ void load_batch_level1(const BuildArgs &g, const Tile
 {
     r.o0 = rl(td.obs, k); r.nob = rl(td.obs, k + 1) - r.o0;
     r.p0 = rl(td.pt, k); r.npt = rl(td.pt, k + 1) - r.p0;
-    r.q0 = ((long long)rl(td.pair_hi, k) << 32) | (unsigned)rl(td.pair_lo, k);
-    r.q1 = ((long long)rl(td.pair_hi, k + 1) << 32) | (unsigned)rl(td.pair_lo, k + 1);
+    const long long pq = ((long long)rl(td.pair_hi, k) << 32) | (unsigned)rl(td.pair_lo, k);   // first entry | rounds << 48 (plan.h)
+    r.q0 = pq & 0xFFFFFFFFFFFFll;
+    r.q1 = r.q0 + (pq >> 48) * kWave;
     r.j = 0; r.ip = r.p0; r.cs = 0; r.xy = make_double2(0.0, 0.0);
     if (lane < r.nob) {
         const int o = r.o0 + lane;

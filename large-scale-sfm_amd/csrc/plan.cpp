@@ -297,7 +297,8 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     pl.pair.clear(); pl.slot_gblk.clear(); pl.cslot_cam.clear(); pl.tile_mode.clear();
     pl.long_pts.clear(); pl.max_slots = 0;
     std::fill(pl.obs_cslot.begin(), pl.obs_cslot.end(), 0);
-    pl.batch_obs.assign(1, 0); pl.batch_pt.assign(1, 0); pl.batch_pair.assign(1, 0);
+    pl.batch_obs.assign(1, 0); pl.batch_pt.assign(1, 0); pl.batch_pair.clear();
+    int64_t batch_q0 = 0, prev_q0 = -1, prev_n = 0;   // this batch's first pair entry; the previous batch of the tile: offset, entries
     pl.tile_batch.assign(1, 0); pl.tile_slot.assign(1, 0); pl.tile_cslot.assign(1, 0);
     std::unordered_map<uint64_t, int> smap;
     std::unordered_map<int, int> cmap;
@@ -327,7 +328,18 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         if (rounds_mode) flush_round();
         pl.batch_obs.push_back(pl.pt_obs[t_end]);
         pl.batch_pt.push_back(t_end);
-        pl.batch_pair.push_back((int64_t)pl.pair.size());
+        // Pair TEMPLATES: points of one camera set produce the same entries batch after batch (lane-local indices, slots, local
+        // points), so a batch whose rounds equal the previous batch's of its tile points at those instead of storing its own --
+        // C3: 64 M entries (256 MB streamed per linearisation) -> one or two templates per tile, read from L2
+        int64_t off = batch_q0;
+        const int64_t n_ent = (int64_t)pl.pair.size() - batch_q0;
+        if (!dry && n_ent > 0 && prev_q0 >= 0 && n_ent == prev_n &&
+            std::memcmp(pl.pair.data() + prev_q0, pl.pair.data() + batch_q0, sizeof(uint32_t) * (size_t)n_ent) == 0) {
+            pl.pair.resize((size_t)batch_q0);
+            off = prev_q0;
+        } else { prev_q0 = batch_q0; prev_n = n_ent; }
+        pl.batch_pair.push_back(off | ((n_ent / kWave) << 48));
+        batch_q0 = (int64_t)pl.pair.size();
         cur_obs = 0; pts_in_batch = 0; rounds_in_batch = 0;
         batches_in_tile++;
     };
@@ -345,7 +357,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         if (mode == 1) tile_log.emplace_back(batches_in_tile, batches_in_tile >= tile_max_batches);
         pl.max_slots = std::max(pl.max_slots, (int)smap.size());
         smap.clear(); cmap.clear(); sig_cams = nullptr; sig_d = -1;
-        batches_in_tile = 0;
+        batches_in_tile = 0; prev_q0 = -1; prev_n = 0;
     };
 
     // class 0: LDS-accumulated tiles
@@ -411,7 +423,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     }
     close_batch(t);
     close_tile(1);
-    if (dry) return;
+    if (dry) { pl.batch_pair.push_back(0); return; }
     pl.npair_lds = (int64_t)pl.pair.size();
     pl.ntile_lds = pl.ntile();
     pl.nbatch_lds = pl.nbatch();
@@ -434,6 +446,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
 
     // class 2: long points
     for (; t < npl; ++t) pl.long_pts.push_back(t);
+    pl.batch_pair.push_back(0);                       // nbatch + 1 entries, like batch_obs
     };
 
     stage("local shard arrays");

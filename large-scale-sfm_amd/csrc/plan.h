@@ -31,7 +31,8 @@ constexpr int kWave = 64;        // observations per batch
 constexpr int kNSlot = 55;       // S-block accumulators per LDS tile (55 = pairs of a 10-view point)
 constexpr int kNCSlot = 24;      // camera accumulators per LDS tile
 constexpr int kMaxPtsBatch = 32; // points per batch (bounds the per-point LDS staging)
-constexpr int kMaxTileBatches = 32; // batches per tile (k_build keeps a tile's batch descriptors one per lane)
+constexpr int kMaxTileBatches = 63; // batches per tile (k_build keeps a tile's batch descriptors one per lane: 63 batches + the end);
+                                    // a tile hands its blocks to HBM when it ends -- ~21 KB of f64 atomics -- so longer is cheaper
 constexpr int kTileSlots = 2048;     // concurrently resident k_build workgroups: 256 CUs x 8 (two per SIMD)
 constexpr int kMaxRounds = 8;    // pair rounds per LDS-tile batch (k_build preloads them into registers)
 constexpr uint32_t kPairInvalid = 0xFFFFFFFFu; // padding entry of a pair round
@@ -63,7 +64,7 @@ struct Plan {
     std::vector<uint8_t> obs_cslot;                  // tile-local camera slot (LDS tiles)
     std::vector<int> batch_obs, batch_pt;            // nbatch+1
     std::vector<int> bs_batch_obs, bs_batch_pt;      // batches of k_backsub (same points, packed regardless of tiles)
-    std::vector<int64_t> batch_pair;                 // nbatch+1
+    std::vector<int64_t> batch_pair;                 // nbatch+1: first pair entry of the batch | rounds << 48 (batches of one camera set share entries)
     std::vector<int> tile_batch, tile_slot, tile_cslot; // ntile+1
     std::vector<uint8_t> tile_mode;                  // 1 register-accumulated blocks, 2 blocks summed in an LDS table, 0 row tiles (records to HBM)
     int ntile_table = 0;                             // tiles of mode 2

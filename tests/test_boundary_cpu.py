@@ -319,7 +319,8 @@ def _check_plan(sc, rank=0, world=1, tmb=0, all_rows=False):
         assert 0 < o1 - o0 <= 64 and g["batch_pt"][b + 1] - g["batch_pt"][b] <= 32
         t = tile_of_batch[b]
         lds = g["tile_mode"][t] in (1, 2)
-        ents = g["pair"][g["batch_pair"][b]:g["batch_pair"][b + 1]]
+        off, nr = int(g["batch_pair"][b]) & ((1 << 48) - 1), int(g["batch_pair"][b]) >> 48      # batches of one camera set share their entries
+        ents = g["pair"][off:off + 64 * nr]
         if not lds:                 # a row tile: no pair entries, every observation has a record
             assert len(ents) == 0 and np.all(g["obs_rec"][o0:o1] >= 0)
             row_pts |= set(range(g["batch_pt"][b], g["batch_pt"][b + 1]))
