@@ -224,7 +224,11 @@ def main():
             "kernel_ms_per_step": {"build": build_ms, "pcg": tm2["pcg_ms"] / max(tm2["pcg_timed"], 1),
                                    "backsub": tm2["backsub_ms"] / max(tm2["backsub_launches"], 1),
                                    "note": "build: HIP events in the timed steps; pcg, backsub: the same trials repeated untimed with events around them",
-                                   "allreduce_host": tm["allreduce_ms"] / max(tm["allreduces"], 1) if world > 1 else 0.0},
+                                   "allreduce_host": tm["allreduce_ms"] / max(tm["allreduces"], 1) if world > 1 else 0.0,
+                                   # several ranks: what does not shrink with N -- the exchange itself and the work every rank repeats
+                                   "exchange": tm2["exchange_ms"] / max(tm2["exchanges_timed"], 1) if world > 1 else 0.0,
+                                   "replicated": tm2["replicated_ms"] / max(tm2["replicated_timed"], 1) if world > 1 else None,
+                                   "overlap": 0.0},
             "setup_s": {"scene": t_gen, "plan_upload": t_plan},
             "roofline": {"bound": "hbm", "kernel": "the build: k_build (fused linearise + Schur complement in register tiles) + the row path "
                                                     "(k_build row tiles, k_long_reduce, k_schur_blocks) between one pair of HIP events",

@@ -162,6 +162,11 @@ typedef struct {
     double pcg_timed;                      /* solves that pcg_ms covers (mi_ba_set_timing_detail >= 2) */
     double spec_adopted;                   /* trials whose linear phase had been enqueued behind the previous trial (engine.cpp solve_phase) */
     double build_index_bytes;              /* the engine's own tables and scratch one build launch also moves (pair entries, row-path records) */
+    /* several ranks, mi_ba_set_timing_detail >= 2: device time of the per-trial exchange (the all-reduce of [S_up | camvec | scal] on the
+     * engine's stream) and of what every rank then computes REDUNDANTLY (finalize, block inverses, scaled matrix, the whole CG, camera
+     * update): the part of a trial that does not shrink with the number of GPUs */
+    double exchange_ms, exchanges_timed;
+    double replicated_ms, replicated_timed;
 } mi_ba_timing;
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_reset_timing(mi_ba_engine *e);

@@ -66,6 +66,7 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
     DeviceGuard on_device(cfg.device);
     if (!hipok(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking), "hipStreamCreate")) return;
     for (auto &ev : ev_) if (!hipok(hipEventCreate(&ev), "hipEventCreate")) return;
+    for (auto &ev : evx_) if (!hipok(hipEventCreate(&ev), "hipEventCreate")) return;
     speculate_ = std::getenv("MI_BA_NO_SPECULATION") == nullptr;
     if (!hipok(hipHostMalloc((void **)&h_scal_, sizeof(double) * 1024, hipHostMallocDefault), "hipHostMalloc")) return;
     created_ = true;
@@ -85,6 +86,7 @@ Engine::~Engine()
     if (comm_) ncclCommDestroy((ncclComm_t)comm_);
     if (h_scal_) (void)hipHostFree(h_scal_);
     for (auto &ev : ev_) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : evx_) if (ev) (void)hipEventDestroy(ev);
     if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -427,8 +429,11 @@ bool Engine::allreduce1()
     if (!comm_ && !host_ar_) return true;
     double t0 = now_ms();
     const size_t nsum = nslot_() + (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP + 8;   // slots1, S_up, camvec, scal[0, 8)
+    const int xp = lin_pair_ ? 2 : 0;
+    if (timing_detail >= 2) (void)hipEventRecord(evx_[xp], st_);
     if (!exchange(d_acc_.p, nsum, 0)) return false;
     if (cfg.world > 1) launch_fold_max(st_, slots1_(), cfg.world, scal_() + 8);
+    if (timing_detail >= 2) (void)hipEventRecord(evx_[xp + 1], st_);
     timing.allreduce_ms += now_ms() - t0; timing.allreduces += 1;
     return true;
 }
@@ -697,6 +702,11 @@ int Engine::step()
     if (timing_detail >= 1 && hipEventElapsedTime(&ms, ev_[pair], ev_[pair + 1]) == hipSuccess) { timing.build_ms += ms; timing.build_launches += 1; }
     if (timing_detail >= 2 && hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) { timing.pcg_ms += ms; timing.pcg_timed += 1; }
     if (timing_detail >= 2 && hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) { timing.backsub_ms += ms; timing.backsub_launches += 1; }
+    if (timing_detail >= 2 && (comm_ || host_ar_)) {   // the exchange of this trial's linear phase, and the replicated stretch up to the back-substitution
+        const int xp = pair ? 2 : 0;
+        if (hipEventElapsedTime(&ms, evx_[xp], evx_[xp + 1]) == hipSuccess) { timing.exchange_ms += ms; timing.exchanges_timed += 1; }
+        if (hipEventElapsedTime(&ms, evx_[xp + 1], ev_[4]) == hipSuccess) { timing.replicated_ms += ms; timing.replicated_timed += 1; }
+    }
     timing.pcg_solves += 1;
     const double *s = h_scal_;
     timing.pcg_iters += s[SC_PCG_ITERS];

@@ -92,6 +92,7 @@ private:
 
     bool created_ = false, prepared_ = false, begun_ = false;
     hipStream_t st_ = nullptr;
+    hipEvent_t evx_[4] = {};     // exchange bracket of a linear phase, [0],[1] and [2],[3] alternating like the build's
     hipEvent_t ev_[10] = {};      // build bracket: [0],[1] and [6],[7] alternate from one linear phase to the next (the next trial's
                                   // may be enqueued before this trial's is read); [2..5] reduced solve, back-substitution; [8] scalars copied
     int lin_count_ = 0, lin_pair_ = 0, spec_pair_ = 0;

@@ -23,6 +23,9 @@ def _case(kind):
     if kind == "long":
         from helpers import ladybug_like_scene
         return ladybug_like_scene(m=120, n=3000, dmax=90, seed=9 + off), {}, lambda eng: None
+    if kind == "det":      # deterministic mode: every point on the block-major row path, on both ranks
+        from helpers import ladybug_like_scene
+        return ladybug_like_scene(m=100, n=2500, dmax=80, seed=12 + off), dict(deterministic=1), lambda eng: None
     if kind == "resume":   # every trial's first run of CG iterations falls short (engine.cpp solve_phase): the update phase -- and with
         os.environ["MI_BA_PCG_FIRST_RUN"] = "2"   # it the second exchange and its per-rank maxima slots -- runs twice per trial
         return scene.make_scene("x", m=40, n=6000, d=6, seed=77 + off), {}, lambda eng: None
@@ -69,7 +72,7 @@ def _worker(rank, world, port, outdir, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "plain"), (3, "long"), (2, "extras"), (2, "resume")])
+@pytest.mark.parametrize("world,kind", [(2, "plain"), (3, "long"), (2, "extras"), (2, "resume"), (2, "det")])
 def test_ranks_sharing_one_gpu_reproduce_the_single_rank_solve(tmp_path, world, kind):
     import torch.multiprocessing as mp
     from conftest import pkg
@@ -92,6 +95,54 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_rank_solve(tmp_path, world, 
     assert np.abs(res[0]["p"] - eng.packed_params()).max() < 1e-6
 
 
+def _worker_rccl(rank, world, outdir):
+    """one rank per GPU, the exchange through RCCL itself (ncclAllReduce on the engine's stream); the unique id travels through a file"""
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+    import time
+    from conftest import pkg as _pkg
+    capi = _pkg("capi")
+    sc, kw, extras = _case("long")
+    idfile = os.path.join(outdir, "uid.bin")
+    if rank == 0:
+        uid = capi.comm_unique_id()
+        with open(idfile + ".tmp", "wb") as fo:
+            fo.write(bytes(uid))
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        for _ in range(600):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.1)
+        uid = open(idfile, "rb").read()
+    eng = capi.Engine(capi.default_config(rank=rank, world=world, device=rank, pcg_tol=1e-12, pcg_maxit=400, mcon=1, **kw))
+    eng.comm_init(bytes(uid))
+    eng.load_scene(sc)
+    eng.prepare()
+    ret, info = eng.run()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), ret=ret, info=info, p=eng.packed_params(), trace=eng.trace())
+    eng.close()
+
+
+def test_two_ranks_on_two_gpus_through_rccl(tmp_path):
+    """the real transport: ncclAllReduce between two GPUs (skipped on a one-GPU box -- the driver's 8-GPU node runs it)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: the RCCL exchange between ranks (one-rank communicator: test_engine_gpu.py)")
+    import torch.multiprocessing as mp
+    from conftest import pkg
+    mp.spawn(_worker_rccl, args=(2, str(tmp_path)), nprocs=2, join=True)
+    res = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2)]
+    assert int(res[1]["ret"]) == int(res[0]["ret"]) and np.array_equal(res[1]["info"], res[0]["info"])
+    assert np.array_equal(res[1]["p"], res[0]["p"]) and np.array_equal(res[1]["trace"], res[0]["trace"])
+    capi = pkg("capi")
+    sc, kw, extras = _case("long")
+    eng = capi.Engine(capi.default_config(pcg_tol=1e-12, pcg_maxit=400, mcon=1, **kw))
+    eng.load_scene(sc); eng.prepare()
+    ret, info = eng.run()
+    assert abs(int(res[0]["ret"]) - ret) <= 1 and abs(res[0]["info"][1] - info[1]) < 1e-9 * info[1]
+    assert np.abs(res[0]["p"] - eng.packed_params()).max() < 1e-6
+
+
 def test_bench_with_two_ranks_rehearsed_on_one_gpu(tmp_path):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed here with both ranks on
     the one GPU of the box (MI_BA_BENCH_ONE_GPU: gloo + the engine's host transport instead of RCCL): the sharded engine, the
@@ -109,3 +160,4 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and "rehearsal" in d and d["config"]["parallelism"] == "points/2"
     assert d["rmse_px"]["after_timed_steps"] < 0.5 * d["rmse_px"]["initial"] and d["kernel_ms_per_step"]["allreduce_host"] > 0
+    assert d["kernel_ms_per_step"]["exchange"] > 0 and d["kernel_ms_per_step"]["replicated"] > 0      # what a scaling run has to explain itself with
