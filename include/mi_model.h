@@ -57,7 +57,7 @@ int mi_model_get(const mi_model *mdl, double *f, double *R, double *t, double *d
  * the BAL / Ladybug configuration C4).  NULL or weight <= 0 clears. */
 int mi_model_set_focal_mask(mi_model *mdl, const int *mask /* ncam */, double weight);
 
-/* bundle adjust in place.  cfg: only itmax, opts, pcg_*, est_focal, mcon, device, verbose are read (the
+/* bundle adjust in place.  cfg: only itmax, opts, pcg_*, est_focal, mcon, device, verbose, deterministic are read (the
  * camera convention of the file fixes the rest).  Returns LM iterations or MI_BA_ERROR. */
 int mi_model_optimize(mi_model *mdl, const mi_ba_config *cfg, double info[MI_BA_INFOSZ]);
 /* one rank of a point-sharded solve (one process per GPU): cfg->rank / cfg->world name the shard and cfg->device

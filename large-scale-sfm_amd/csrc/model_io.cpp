@@ -544,6 +544,7 @@ int mi_model_optimize_shard(mi_model *m, const mi_ba_config *user, double info[M
     if (user) {
         cfg.itmax = user->itmax; std::memcpy(cfg.opts, user->opts, sizeof(cfg.opts)); cfg.pcg_maxit = user->pcg_maxit; cfg.pcg_tol = user->pcg_tol;
         cfg.est_focal = user->est_focal; cfg.mcon = user->mcon; cfg.device = user->device; cfg.verbose = user->verbose;
+        cfg.deterministic = user->deterministic;
         if (shard) { cfg.rank = user->rank; cfg.world = user->world; }
     }
     cfg.explicit_centers = 0; cfg.proj_sign = 1.0; // file convention: x^ = f (R X + t).xy / z
@@ -737,6 +738,7 @@ int mi_optimizer_all_main(int argc, char **argv)
     cfg.est_focal = A >= 0 ? 1 : 0;
     cfg.itmax = B > 0 ? B : 1;
     if (const char *dev = std::getenv("MI_BA_DEVICE")) cfg.device = std::atoi(dev);
+    if (const char *det = std::getenv("MI_BA_DETERMINISTIC")) cfg.deterministic = std::atoi(det) != 0;
     const char *gpus = std::getenv("MI_BA_GPUS"), *transport = std::getenv("MI_BA_TRANSPORT");
     const int world = gpus ? std::atoi(gpus) : 1;
     const bool host_transport = transport && std::strcmp(transport, "host") == 0;
