@@ -37,6 +37,17 @@ public:
                                      * 'T' time budget, 0 iteration cap (SparseBundleCPU.cpp:3851-3935)  */
     int __num_lm_success, __num_lm_iteration;
     float __initial_mse, __final_mse;
+    /* data normalisation (SparseBundleCPU.cpp:3141-3345, ConfigBA.cpp:87-92): focal lengths and measurements scaled so that the
+     * median focal length becomes __data_normalize_median, translations and points so that the median depth becomes its inverse;
+     * undone before the result is handed back.  As in the reference's copy, RunBundleAdjustment() switches both requests OFF on
+     * entry (:2583-2584) and the degeneracy rule switches both ON for the run when a point lies closer to a camera's plane than
+     * __depth_check_epsilon of that camera's t_z ("-nodf" disables the rule, :3258-3263).  "-dn" (ours) makes a run honour the two
+     * requests as upstream PBA does.  The Jacobian column scaling that goes with it (:2924-2942) is the block scaling
+     * S~ = L^-1 S L^-T the reduced solve always applies. */
+    bool __focal_normalize, __depth_normalize, __depth_degeneracy_fix, __honour_data_normalize;
+    float __data_normalize_median, __depth_check_epsilon;
+    float __focal_scaling, __depth_scaling;      /* what the last run used (1 = none) */
+    int __num_point_behind, __num_camera_modified;
     ConfigBA();
     char GetBundleReturnCode() const { return __bundle_return_code; }
     const char *GetOutputParam() const { return __output_param; }

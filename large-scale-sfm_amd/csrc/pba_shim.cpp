@@ -18,7 +18,9 @@
 ConfigBA::ConfigBA()
     : __lm_max_iteration(50), __lm_mse_threshold(0.25f), __bundle_time_budget(0), __bundle_mode_next(0), __cg_max_iteration(100), __cg_norm_threshold(1e-3f), __fixed_intrinsics(false),
       __use_radial_distortion(0), __verbose_level(0), __selected_device(0), __bundle_return_code(0), __num_lm_success(0),
-      __num_lm_iteration(0), __initial_mse(0), __final_mse(0)
+      __num_lm_iteration(0), __initial_mse(0), __final_mse(0), __focal_normalize(true), __depth_normalize(true), __depth_degeneracy_fix(true),
+      __honour_data_normalize(false), __data_normalize_median(0.5f), __depth_check_epsilon(0.01f), __focal_scaling(1.0f), __depth_scaling(1.0f),
+      __num_point_behind(0), __num_camera_modified(0)
 {
     __output_param[0] = 0;
 }
@@ -44,6 +46,11 @@ void ConfigBA::ParseParam(int argc, char **argv)
         else if (!std::strcmp(a, "-out") && v) { std::snprintf(__output_param, sizeof(__output_param), "%s", v); ++i; }
         else if (!std::strcmp(a, "-v") && v) { __verbose_level = std::atoi(v); ++i; }
         else if (!std::strcmp(a, "-cali")) __fixed_intrinsics = true;
+        else if (!std::strcmp(a, "-nodn")) { __depth_normalize = false; __focal_normalize = false; }       // ConfigBA.cpp:503-506
+        else if (!std::strcmp(a, "-nodf")) __depth_degeneracy_fix = false;                                  // :507-509
+        else if (!std::strcmp(a, "-norm") && v) { if (std::atof(v) > 0) __data_normalize_median = (float)std::atof(v); ++i; }   // :510-512
+        else if (!std::strcmp(a, "-dce") && v) { if (std::atof(v) > 0 && std::atof(v) <= 0.01) __depth_check_epsilon = (float)std::atof(v); ++i; }
+        else if (!std::strcmp(a, "-dn")) { __honour_data_normalize = true; __depth_normalize = true; __focal_normalize = true; }   // ours: see mi_pba.h
     }
 }
 
@@ -136,9 +143,7 @@ int ParallelBA::RunBundleAdjustment()
             for (size_t q = 0; q < fl.a.size(); ++q) link_wr.push_back(dist != 0 ? fl.w[q] * o.cams[fl.rep[q]].f : 0.0);
         }
     }
-    mi_ba_engine *e = mi_ba_create(&cfg);
-    if (!e) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(nullptr)); c.__bundle_return_code = 'E'; return 0; }
-    const int m = (int)o.ncam, n = (int)o.npt, cnp = mi_ba_cnp(e), kslot = 6 + cfg.est_focal;
+    const int m = (int)o.ncam, n = (int)o.npt, cnp = 6 + cfg.est_focal + (cfg.undistort ? 1 : 0), kslot = 6 + cfg.est_focal;
     std::vector<double> a0((size_t)m * cnp, 0.0), R0((size_t)m * 9), ff(m), xyz((size_t)n * 3), xy(o.nproj * 2);
     std::vector<unsigned char> fixed(m, 0);
     bool some_fixed_intrinsics = false;
@@ -163,6 +168,77 @@ int ParallelBA::RunBundleAdjustment()
             const double g = 1.0 + (double)o.cams[j].radial * (xy[2 * k] * xy[2 * k] + xy[2 * k + 1] * xy[2 * k + 1]);
             xy[2 * k] *= g; xy[2 * k + 1] *= g;
         }
+    // ---- data normalisation, NormalizeDataD then NormalizeDataF (SparseBundleCPU.cpp:2652-2657, 3211-3306, 3141-3209) on the copies
+    // the engine gets; undone after the solve (DenormalizeData, :3311-3345)
+    c.__focal_scaling = c.__depth_scaling = 1.0f; c.__num_point_behind = c.__num_camera_modified = 0;
+    if (!c.__honour_data_normalize) c.__depth_normalize = c.__focal_normalize = false;     // the reference's copy: :2583-2584
+    double depth_scaling = 1.0, focal_scaling = 1.0;
+    {
+        const double dist_bound = 1.0;
+        std::vector<double> oz(o.nproj), cpdist1(m, dist_bound), cpdist2(m, -dist_bound);
+        int bad_point_count = 0;
+        for (size_t k = 0; k < o.nproj; ++k) {
+            const int j = o.camidx[k], i = o.ptidx[k];
+            if (j < 0 || j >= m || i < 0 || i >= n) { oz[k] = 1.0; continue; }   // reported by mi_ba_prepare
+            const double *R = &R0[(size_t)j * 9], *X = &xyz[(size_t)i * 3], *t = &a0[(size_t)j * cnp];
+            oz[k] = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+            if (std::fabs(oz[k] / t[2]) < c.__depth_check_epsilon) {               // a point close to the camera's plane, :3234-3253
+                ++bad_point_count;
+                const double px = ff[j] * (R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0]), py = ff[j] * (R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1]);
+                const double mx = o.meas[k].x, my = o.meas[k].y;
+                const bool checkx = std::fabs(mx) > std::fabs(my);
+                if ((checkx && px * oz[k] * mx < 0 && std::fabs(mx) > 64) || (!checkx && py * oz[k] * my < 0 && std::fabs(my) > 64)) {
+                    if (oz[k] > 0) cpdist2[j] = 0; else cpdist1[j] = 0;
+                }
+                if (oz[k] >= 0) cpdist1[j] = std::min(cpdist1[j], oz[k]); else cpdist2[j] = std::max(cpdist2[j], oz[k]);
+            }
+            if (oz[k] < 0) c.__num_point_behind++;
+        }
+        if (bad_point_count > 0 && c.__depth_degeneracy_fix) {                     // :3258-3263
+            if (!c.__focal_normalize || !c.__depth_normalize) std::printf("Enable data normalization on degeneracy\n");
+            c.__focal_normalize = c.__depth_normalize = true;
+        }
+        if (c.__depth_normalize) {
+            std::nth_element(oz.begin(), oz.begin() + o.nproj / 2, oz.end());
+            const double oz_median = oz[o.nproj / 2];
+            const double shift_min = std::min(oz_median * 0.001, 1.0), dist_threshold = shift_min * 0.1;
+            depth_scaling = (1.0 / oz_median) / c.__data_normalize_median;
+            if (c.__verbose_level > 2) std::printf("Depth normalized by %.9g (%.9g)\n", depth_scaling, oz_median);   // the reference's line, :3272
+            for (int j = 0; j < m; ++j) {
+                double *t = &a0[(size_t)j * cnp];
+                if (c.__depth_degeneracy_fix && (cpdist1[j] < dist_threshold || cpdist2[j] > -dist_threshold)) {   // move the camera a little, :3279-3291
+                    t[2] += std::max(shift_min, std::fabs(t[2] * 1.1920929e-7));
+                    c.__num_camera_modified++;
+                }
+                t[0] *= depth_scaling; t[1] *= depth_scaling; t[2] *= depth_scaling;
+            }
+            for (double &v : xyz) v *= depth_scaling;
+        }
+        if (c.__num_point_behind > 0) std::printf("WARNING: %d points are behind camras.\n", c.__num_point_behind);       // the reference's own words
+        if (c.__num_camera_modified > 0) std::printf("WARNING: %d camera moved to avoid degeneracy.\n", c.__num_camera_modified);
+        if (c.__focal_normalize) {
+            std::vector<double> fv(ff);
+            std::nth_element(fv.begin(), fv.begin() + m / 2, fv.end());
+            const double median_f = fv[m / 2];
+            focal_scaling = c.__data_normalize_median / median_f;
+            if (c.__verbose_level > 2) std::printf("Focal length normalized by %.9g\n", focal_scaling);                 // :3180
+            const double radial_factor = median_f * median_f * 4.0;                // = 1 / focal_scaling^2 at the default median, :3157
+            (void)radial_factor;
+            for (double &v : xy) v *= focal_scaling;
+            for (double &v : ff) v *= focal_scaling;
+            // the engine's camera parameters are f * f_scale and k * k_scale: instead of scaling the parameters, scale the
+            // scales -- a6 and a7 keep their values (and their O(1) size, which the additive damping wants), the focal lengths
+            // they stand for are the normalised ones, and a measurement distortion, which multiplies |x|^2, the normalised
+            // k / focal_scaling^2 = k * radial_factor
+            cfg.f_scale /= focal_scaling;
+            if (cfg.undistort == 2) cfg.k_scale *= focal_scaling * focal_scaling;
+        }
+        c.__focal_scaling = (float)focal_scaling; c.__depth_scaling = (float)depth_scaling;
+    }
+    const double mse_unscale = 1.0 / (focal_scaling * focal_scaling);               // GetMeanSquaredError, :2573-2576
+    mi_ba_engine *e = mi_ba_create(&cfg);
+    if (!e) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(nullptr)); c.__bundle_return_code = 'E'; return 0; }
+    if (mi_ba_cnp(e) != cnp) { std::fprintf(stderr, "[mi_pba] internal: camera block size\n"); c.__bundle_return_code = 'E'; mi_ba_destroy(e); return 0; }
     int ret = 0;
     double info[MI_BA_INFOSZ] = { 0 };
     std::vector<double> link_w(fl.a.size() * (size_t)cnp, 0.0);
@@ -183,7 +259,7 @@ int ParallelBA::RunBundleAdjustment()
         return 0;
     }
     mi_ba_get_info(e, info);
-    c.__initial_mse = (float)(info[0] / (double)o.nproj);
+    c.__initial_mse = (float)(info[0] / (double)o.nproj * mse_unscale);
     o.mse.store(c.__initial_mse);
     int st = 0;
     char early = 0;
@@ -192,7 +268,7 @@ int ParallelBA::RunBundleAdjustment()
         st = mi_ba_step(e);
         if (st == MI_BA_ERROR) break;
         mi_ba_get_info(e, info);
-        o.mse.store((float)(info[1] / (double)o.nproj));
+        o.mse.store((float)(info[1] / (double)o.nproj * mse_unscale));
         o.iteration.store((int)info[5]);
         c.__num_lm_iteration = (int)info[9];
         if (st == 1) {
@@ -218,13 +294,14 @@ int ParallelBA::RunBundleAdjustment()
     if (mi_ba_get_params(e, a.data(), xyz.data()) == 0 && mi_ba_get_rotations(e, R.data()) == 0) {
         for (int j = 0; j < m; ++j) {
             CameraT &cam = o.cams[j];
-            for (int r = 0; r < 3; ++r) cam.t[r] = (float)a[(size_t)j * cnp + r];
+            // DenormalizeData, SparseBundleCPU.cpp:3311-3345
+            for (int r = 0; r < 3; ++r) cam.t[r] = (float)(a[(size_t)j * cnp + r] / depth_scaling);
             for (int r = 0; r < 9; ++r) cam.m[r / 3][r % 3] = (float)R[(size_t)j * 9 + r];
-            if (cfg.est_focal) cam.f = (float)(a[(size_t)j * cnp + 6] / cfg.f_scale);
+            if (cfg.est_focal) cam.f = (float)(a[(size_t)j * cnp + 6] / cfg.f_scale / focal_scaling);   // f_scale carries the normalisation
             if (cfg.undistort == 1 && !fixed_projection_distortion) cam.SetProjectionDistortion(a[(size_t)j * cnp + kslot] / cfg.k_scale);
-            if (cfg.undistort == 2) cam.SetMeasumentDistortion(a[(size_t)j * cnp + kslot] / cfg.k_scale);
+            if (cfg.undistort == 2) cam.SetMeasumentDistortion(a[(size_t)j * cnp + kslot] / cfg.k_scale * focal_scaling * focal_scaling);
         }
-        for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) o.pts[i].xyz[r] = (float)xyz[(size_t)i * 3 + r];
+        for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) o.pts[i].xyz[r] = (float)(xyz[(size_t)i * 3 + r] / depth_scaling);
         ret = c.__num_lm_success;
     }
     c.__final_mse = o.mse.load();

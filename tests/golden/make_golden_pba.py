@@ -31,7 +31,13 @@ def main():
             sc, kw = helpers.pba_case(name)
             prob = os.path.join(wd, name + ".txt")
             helpers.write_pba_problem(prob, sc, **kw)
+            os.environ["PBA_CLIENT_ARGS"] = "-v 3" if name == "degenerate" else ""    # its normalisation factors are printed at this level
             r = helpers.run_pba_client(exe, prob, wd, -3, sc.m, sc.n)     # -3 = PBA_CPU_DOUBLE
+            for line in r["stdout"].splitlines():
+                if line.startswith("Depth normalized by"):
+                    out[name + "_depth_scaling"] = np.float64(line.split()[3]); out[name + "_depth_median"] = np.float64(line.split()[4].strip("()"))
+                if line.startswith("Focal length normalized by"):
+                    out[name + "_focal_scaling"] = np.float64(line.split()[4])
             print(name, "iters", r["iters"], "mse", r["mse"], "f[:3]", r["f"][:3], "radial[2:5]", r["radial"][2:5])
             for k in ("iters", "mse", "f", "t", "R", "radial", "pts"):
                 out[name + "_" + k] = np.asarray(r[k])

@@ -185,7 +185,7 @@ def run_pba_client(exe, problem, workdir, device, m, n):
 
 
 PBA_CASES = ("plain", "early_stop", "proj_dist", "meas_dist", "fixed_intr_md", "fixed_intr_pd", "motion_only", "structure_only",
-             "shared_focal", "shared_focal_groups_pd")
+             "shared_focal", "shared_focal_groups_pd", "degenerate")
 
 
 def pba_case(name):
@@ -212,6 +212,22 @@ def pba_case(name):
         m, cnp = sc.m, sc.cnp
         a = sc.p0[:m * cnp].reshape(m, cnp)[:, :6]
         sc.p0 = np.concatenate([a.reshape(-1), sc.p0[m * cnp:]]); sc.cnp = 6; sc.undistort = 0
+    elif name == "degenerate":
+        # one point a twentieth of a unit in front of camera 5 (t_z ~ 10): closer to its plane than 1 % of t_z, which switches the
+        # reference's data normalisation on for the run (the degeneracy rule, SparseBundleCPU.cpp:3234-3263) -- the one way its
+        # NormalizeData is live in this copy
+        sc = vsfm_scene(m=16, n=1500, d=5, seed=36)
+        m, cnp = sc.m, sc.cnp
+        a = sc.p0[:m * cnp].reshape(m, cnp)
+        R = np.einsum("mij,mjk->mik", rodrigues(a[:, 3:6]), sc.R0.reshape(m, 3, 3))
+        i = int(np.flatnonzero(sc.obs_cam == 5)[0]); i = int(sc.obs_pt()[i])          # a point camera 5 sees
+        C5 = -R[5].T @ a[5, :3]
+        X = C5 + 0.05 * R[5][2]                                                      # on the optical axis, depth 0.05
+        sc.p0[m * cnp + 3 * i:m * cnp + 3 * i + 3] = X
+        for o in range(sc.pt_ptr[i], sc.pt_ptr[i + 1]):                              # its measurements: the exact projections
+            j = sc.obs_cam[o]
+            q = R[j] @ X + a[j, :3]
+            sc.x[o] = (a[j, 6] / 0.001) * q[:2] / q[2]
     elif name == "motion_only":
         sc = vsfm_scene(m=16, n=1500, d=5, seed=35, pt_noise=0.0); kw.update(mode=1, nconst=0)
     elif name == "structure_only":

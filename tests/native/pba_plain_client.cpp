@@ -10,6 +10,7 @@
 // problem.txt:  m n k / fixed_intrinsics distortion nconst mode use_mask lmi lme / cameras / points / obs / [mask]
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "mi_pba.h"
 
@@ -52,6 +53,13 @@ int main(int argc, char **argv)
     std::snprintf(a3, sizeof a3, "%g", lme);
     char *args[] = { a0, a1, a2, a3, a4, a5 };
     pba->ParseParam(6, args);
+    if (const char *extra = std::getenv("PBA_CLIENT_ARGS")) {      // further options of the library under test, blank separated
+        static char buf[512];
+        std::snprintf(buf, sizeof buf, "%s", extra);
+        std::vector<char *> more;
+        for (char *tok = std::strtok(buf, " "); tok; tok = std::strtok(nullptr, " ")) more.push_back(tok);
+        if (!more.empty()) pba->ParseParam((int)more.size(), &more[0]);
+    }
     pba->SetFixedIntrinsics(fixed_intr != 0);
     pba->EnableRadialDistortion((ParallelBA::DistortionT)distortion);
     pba->SetCameraData(cams.size(), &cams[0]);

@@ -231,7 +231,11 @@ def test_parallelba_against_the_references_own_parallelba(name, pba_mi_client):
     assert abs(np.abs(sc.x).sum() - float(z[name + "_xsum"])) < 1e-6 * float(z[name + "_xsum"])    # same input as the golden run
     prob = os.path.join(str(wd), name + ".txt")
     write_pba_problem(prob, sc, **kw)
-    r = run_pba_client(exe, prob, wd, -1, sc.m, sc.n)
+    os.environ["PBA_CLIENT_ARGS"] = "-v 3" if name == "degenerate" else ""
+    try:
+        r = run_pba_client(exe, prob, wd, -1, sc.m, sc.n)
+    finally:
+        os.environ.pop("PBA_CLIENT_ARGS", None)
     ref = {k: z[name + "_" + k] for k in ("iters", "mse", "f", "t", "R", "radial", "pts")}
     print(name, "iters", r["iters"], int(ref["iters"]), "mse", r["mse"], float(ref["mse"]),
           "df", np.abs(r["f"] - ref["f"]).max(), "dt", np.abs(r["t"] - ref["t"]).max(), "dR", np.abs(r["R"] - ref["R"]).max(),
@@ -241,6 +245,22 @@ def test_parallelba_against_the_references_own_parallelba(name, pba_mi_client):
         assert r["iters"] <= 3 and r["mse"] <= 0.25
         return
     rm, rw = np.sqrt(r["mse"]), np.sqrt(float(ref["mse"]))
+    if name == "degenerate":
+        # SURVEY row a18.  A point a twentieth of a unit in front of a camera: the reference's degeneracy rule switches its data
+        # normalisation on for the run (SparseBundleCPU.cpp:3234-3263 -- the one way NormalizeData is live in this copy), and so
+        # does the shim: the same two lines on stdout with the same factors (median depth, median focal length).  The reference
+        # then crawls to its iteration cap; the engine reaches a minimum at least as low, with no camera moved.
+        lines = r["stdout"].splitlines()
+        assert "Enable data normalization on degeneracy" in lines
+        dep = [l for l in lines if l.startswith("Depth normalized by")][0].split()
+        foc = [l for l in lines if l.startswith("Focal length normalized by")][0].split()
+        assert abs(float(dep[3]) - float(z[name + "_depth_scaling"])) < 2e-6 * float(dep[3])      # the reference prints 6 digits
+        assert abs(float(dep[4].strip("()")) - float(z[name + "_depth_median"])) < 2e-5 * float(z[name + "_depth_median"])
+        assert abs(float(foc[4]) - float(z[name + "_focal_scaling"])) < 2e-6 * float(foc[4])
+        assert not any("camera moved" in l for l in lines)
+        assert rm <= rw * (1 + 2e-4) and int(ref["iters"]) == 100
+        assert np.abs(r["f"] / ref["f"] - 1).max() < 5e-3 and np.abs(r["pts"] - ref["pts"]).max() < 5e-2
+        return
     if name.startswith("shared_focal"):
         # SetFocalMask.  The reference crawls on these (74-94 iterations, stopped by the cap / a float step test before
         # the distortion group has moved), so: at least as good a minimum, and the groups really share their intrinsics
@@ -267,6 +287,47 @@ def test_parallelba_against_the_references_own_parallelba(name, pba_mi_client):
     if kw.get("distortion") and not kw.get("fixed_intr"):
         scale = np.abs(ref["radial"]).max()
         assert np.abs(r["radial"] - ref["radial"])[nc:].max() < 0.03 * scale
+
+
+@pytest.mark.parametrize("name", ["plain", "meas_dist", "proj_dist"])
+def test_parallelba_data_normalisation_leaves_the_minimum_alone(name, pba_mi_client):
+    """"-dn" makes a run honour ConfigBA's __focal_normalize / __depth_normalize as upstream PBA does (the
+    reference's copy forces both off on entry, SparseBundleCPU.cpp:2583-2584): median focal length -> 0.5, median depth -> 2, the
+    measurement distortion by 1 / focal_scaling^2 (:3141-3306), undone on the way out (:3311-3345).  The factors against a numpy
+    restatement, the answer against the reference's minimum of the un-normalised problem (the same golden as above)."""
+    from helpers import pba_case, run_pba_client, write_pba_problem
+    exe, wd = pba_mi_client
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_pba.npz"))
+    sc, kw = pba_case(name)
+    prob = os.path.join(str(wd), name + "_dn.txt")
+    write_pba_problem(prob, sc, **kw)
+    os.environ["PBA_CLIENT_ARGS"] = "-dn -v 3"
+    try:
+        r = run_pba_client(exe, prob, wd, -1, sc.m, sc.n)
+    finally:
+        os.environ.pop("PBA_CLIENT_ARGS", None)
+    m, cnp = sc.m, sc.cnp
+    a = sc.p0[:m * cnp].reshape(m, cnp)
+    R = np.einsum("mij,mjk->mik", rodrigues(a[:, 3:6]), sc.R0.reshape(m, 3, 3)).astype(np.float32).astype(float)   # as the CameraT holds them
+    X = sc.p0[m * cnp:].reshape(sc.n, 3).astype(np.float32).astype(float)
+    t = a[:, :3].astype(np.float32).astype(float)
+    oz = np.einsum("kj,kj->k", R[sc.obs_cam][:, 2, :], X[sc.obs_pt()]) + t[sc.obs_cam, 2]
+    oz_median = np.sort(oz)[len(oz) // 2]
+    f_median = np.sort((a[:, 6] / 0.001).astype(np.float32).astype(float))[m // 2]
+    lines = r["stdout"].splitlines()
+    dep = [l for l in lines if l.startswith("Depth normalized by")][0].split()
+    foc = [l for l in lines if l.startswith("Focal length normalized by")][0].split()
+    assert abs(float(dep[3]) - 2.0 / oz_median) < 1e-8 * 2.0 / oz_median and abs(float(foc[4]) - 0.5 / f_median) < 1e-8 * 0.5 / f_median
+    assert "Enable data normalization" not in r["stdout"]
+    ref = {k: z[name + "_" + k] for k in ("mse", "f", "t", "R", "radial", "pts")}
+    rm, rw = np.sqrt(r["mse"]), np.sqrt(float(ref["mse"]))
+    assert abs(rm - rw) <= 1e-4 * rw
+    nc = kw["nconst"]
+    assert np.array_equal(r["f"][:nc], ref["f"][:nc])
+    assert np.abs(r["R"] - ref["R"]).max() < 1e-4 and np.abs(r["t"] - ref["t"]).max() < 5e-3 and np.abs(r["f"] - ref["f"]).max() < 0.5
+    assert np.abs(r["pts"] - ref["pts"]).max() < 5e-4
+    if kw.get("distortion"):
+        assert np.abs(r["radial"] - ref["radial"])[nc:].max() < 0.03 * np.abs(ref["radial"]).max()
 
 
 def test_config_c4_ladybug_like_through_the_bal_loader(tmp_path, oracle):
