@@ -40,8 +40,8 @@ typedef struct mi_ba_plan mi_ba_plan;
 typedef struct {
     /* model (sfm.c:598-617 arguments of run_sfm) */
     int est_focal;          /* 1: focal length is a parameter (cnp 7), 0: fixed (cnp 6) */
-    int undistort;          /* 1: the radial coefficient k1 is a parameter (Bundler's projection distortion,
-                             * sfm.c:360-373, with k2 held at 0 = the one-coefficient model of PBA's CameraT);
+    int undistort;          /* 1: radial coefficients are parameters (Bundler's projection distortion, sfm.c:360-373): k1 alone
+                             * (nk = 1, the one-coefficient model of PBA's CameraT) or k1 and k2 (nk = 2);
                              * 2: PBA's measurement distortion, residual x (1 + k |x|^2) - f q.xy / q.z
                              * (SparseBundleCPU.cpp:1188-1193), k in the same parameter slot */
     int explicit_centers;   /* 1: camera params hold the centre C, 0: the translation t */
@@ -71,7 +71,11 @@ typedef struct {
      * points whose camera set repeats accumulate their blocks in registers and hand them over with f64 atomics (faster on
      * such scenes; results differ from run to run at rounding level). */
     int deterministic;
-    int reserved[5];
+    /* radial coefficients that are parameters with undistort == 1: 1 (default; 0 means 1) = k1, 2 = k1 and k2, Bundler's full
+     * model (sfm.c:360-373, 648-649).  With the focal length that is NINE camera parameters (cnp 9): the engine then keeps camera j
+     * as two rows of its 8-wide camera-side arrays (parameters 0-7, parameter 8) and every point takes the row path. */
+    int nk;
+    int reserved[4];
 } mi_ba_config;
 
 /* fills the defaults above (Bundler's run_sfm settings, cnp 7, explicit centres) */

@@ -10,11 +10,12 @@
  *                             a device cannot call back into a host `proj` function pointer.
  * camera_params_t / v3_t are layout-compatible with sfm.h:29-51 and matrix/vector.h:65-67.
  *
- * Supported this round: est_focal_length 0/1, explicit_camera_centers 0/1, ncons >= 0, fix_points
- * (motion-only, sba_mot_levmar), use_constraints, use_point_constraints (Bundler's soft constraints).
- * Not yet:
- * optimize_for_fisheye, undistort, const_focal_length, the Vout/Sout/Uout/Wout exports -- asking
- * for any of them makes mi_run_sfm return MI_BA_ERROR (run_sfm prints the reason and returns).
+ * Supported: est_focal_length 0/1, undistort 0/1 (k1 and k2 as parameters, sfm.c:648-649: 8 or 9 parameters per camera),
+ * explicit_camera_centers 0/1, ncons >= 0, fix_points (motion-only, sba_mot_levmar), use_constraints,
+ * use_point_constraints (Bundler's soft constraints).
+ * Not supported: optimize_for_fisheye, const_focal_length ("not implemented" in the reference itself, sfm.c:394-397), the
+ * Vout/Sout/Uout/Wout exports -- asking for any of them makes mi_run_sfm return MI_BA_ERROR (run_sfm prints the reason
+ * and returns).
  */
 #ifndef MI_SFM_H
 #define MI_SFM_H

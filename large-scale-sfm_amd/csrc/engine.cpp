@@ -52,8 +52,11 @@ bool Engine::hipok(hipError_t e, const char *what)
 
 Engine::Engine(const mi_ba_config &c) : cfg(c)
 {
-    cnp = 6 + (cfg.est_focal ? 1 : 0) + (cfg.undistort ? 1 : 0);
-    if (cfg.undistort < 0 || cfg.undistort > 2) { err = "undistort must be 0, 1 (projection distortion k1) or 2 (measurement distortion)"; return; }
+    if (cfg.undistort < 0 || cfg.undistort > 2) { err = "undistort must be 0, 1 (projection distortion) or 2 (measurement distortion)"; return; }
+    if (cfg.nk != 0 && cfg.nk != 1 && cfg.nk != 2) { err = "nk must be 1 (k1) or 2 (k1 and k2)"; return; }
+    if (cfg.nk == 0) cfg.nk = 1;
+    cnp = 6 + (cfg.est_focal ? 1 : 0) + (cfg.undistort == 1 ? cfg.nk : cfg.undistort == 2 ? 1 : 0);
+    split_ = cnp == 9;       // Bundler's full camera (sfm.c:648-649): blocks wider than the 8 x 8 the camera-side kernels are shaped for
     if (cfg.mode < 0 || cfg.mode > 2) { err = "bad bundle mode"; return; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -95,6 +98,7 @@ ModelCfg Engine::model() const
     ModelCfg mc;
     mc.explicit_centers = cfg.explicit_centers; mc.est_focal = cfg.est_focal; mc.undistort = cfg.undistort;
     mc.mcon = cfg.mcon; mc.points_fixed = cfg.mode == 1; mc.proj_sign = cfg.proj_sign; mc.f_scale = cfg.f_scale; mc.k_scale = cfg.k_scale;
+    mc.nk = cfg.undistort == 1 ? cfg.nk : 1; mc.split = split_ ? 1 : 0;
     return mc;
 }
 
@@ -102,7 +106,7 @@ int Engine::set_cameras(int m, const double *a0, const double *R0, const double 
 {
     if (m <= 0 || !a0 || !R0) { err = "set_cameras: bad arguments"; return MI_BA_ERROR; }
     if (!cfg.est_focal && !f_fixed) { err = "set_cameras: f_fixed is required when the focal length is not estimated"; return MI_BA_ERROR; }
-    m_ = m;
+    m_ = m; mv_ = split_ ? 2 * m : m;
     h_a0_.assign(a0, a0 + (size_t)m * cnp);
     h_R0_.assign(R0, R0 + (size_t)m * 9);
     have_ff_ = f_fixed != nullptr;
@@ -126,7 +130,7 @@ int Engine::set_fixed_params(const unsigned char *mask)
     if (mask)
         for (int j = 0; j < m_; ++j)
             for (int r = 0; r < cnp; ++r)
-                if (mask[(size_t)j * cnp + r]) h_pfix_[j] |= (unsigned char)(1u << r);
+                if (mask[(size_t)j * cnp + r]) h_pfix_[j] |= (unsigned short)(1u << r);
     prepared_ = begun_ = false;
     return 0;
 }
@@ -228,7 +232,7 @@ int Engine::prepare()
     }
     if (!h_link_cam_.empty() && cfg.mode == 2) { err = "prepare: camera links make no sense in a structure-only bundle"; return MI_BA_ERROR; }
     std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches,
-                                  h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic != 0);
+                                  h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic != 0, split_);
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
     const Plan &pl = plan_;
 #define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
@@ -240,13 +244,14 @@ int Engine::prepare()
     UP(d_pair_, pl.pair);
     UP(d_obs_rec_, pl.obs_rec); UP(d_rec_cam_, pl.rec_cam); UP(d_wk_blk_, pl.wk_blk); UP(d_rpair_, pl.rpair);
     UP(d_wk_diag_cam_, pl.wk_diag_cam); UP(d_wk_diag_blk_, pl.wk_diag_blk);
-    if (!hipok(d_rec_.alloc((size_t)pl.rec_cam[m_] * kRec), "alloc observation records")) return MI_BA_ERROR;
+    UP(d_wk_vblk_, pl.wk_vblk); UP(d_wk_diag_vblk_, pl.wk_diag_vblk);
+    if (!hipok(d_rec_.alloc((size_t)pl.rec_cam[m_] * (split_ ? kRec9 : kRec)), "alloc observation records")) return MI_BA_ERROR;
     UP(d_bsr_row_, pl.bsr_row); UP(d_bsr_col_, pl.bsr_col); UP(d_bsr_src_, pl.bsr_src); UP(d_bsr_trans_, pl.bsr_trans);
     {
         std::vector<long long> bp(pl.batch_pair.begin(), pl.batch_pair.end()), wq(pl.wk_q.begin(), pl.wk_q.end());
         UP(d_batch_pair_, bp); UP(d_wk_q_, wq);
-        std::vector<int> rowidx(pl.nb_full()), diag(m_, -1);
-        for (int j = 0; j < m_; ++j)
+        std::vector<int> rowidx(pl.nb_full()), diag(mv_, -1);
+        for (int j = 0; j < mv_; ++j)
             for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) { rowidx[q] = j; if (pl.bsr_col[q] == j) diag[j] = q; }
         UP(d_bsr_rowidx_, rowidx); UP(d_bsr_diag_, diag);
         const int64_t nol = pl.nobs_local();
@@ -258,10 +263,10 @@ int Engine::prepare()
     {   // soft constraints: camera side always present (zeros = none), point side only when set
         if (!h_pt_cw_.empty() && cfg.mode != 0) { err = "prepare: point constraints need the full bundle (mode 0)"; return MI_BA_ERROR; }
         if (!h_cam_cw_.empty() && cfg.mode == 2) { err = "prepare: camera constraints make no sense in a structure-only bundle"; return MI_BA_ERROR; }
-        std::vector<double> cw((size_t)m_ * kCP, 0.0), cv((size_t)m_ * kCP, 0.0);
+        std::vector<double> cw((size_t)mv_ * kCP, 0.0), cv((size_t)mv_ * kCP, 0.0);
         if (!h_cam_cw_.empty())
             for (int j = 0; j < m_; ++j)
-                for (int r = 0; r < cnp; ++r) { cw[(size_t)j * kCP + r] = h_cam_cw_[(size_t)j * cnp + r]; cv[(size_t)j * kCP + r] = h_cam_cv_[(size_t)j * cnp + r]; }
+                for (int r = 0; r < cnp; ++r) { cw[slot_(j, r)] = h_cam_cw_[(size_t)j * cnp + r]; cv[slot_(j, r)] = h_cam_cv_[(size_t)j * cnp + r]; }
         UP(d_cam_cw_, cw); UP(d_cam_cv_, cv);
         d_pt_cw_.release(); d_pt_cv_.release();
         if (!h_pt_cw_.empty()) {
@@ -278,20 +283,22 @@ int Engine::prepare()
     links_ = CamLinks{};
     if (!h_link_cam_.empty()) { // camera links: CSR over cameras (each link at both ends), summed weight per linked pair
         const int nl = (int)h_link_cam_.size() / 2;
-        std::vector<int> row(m_ + 1, 0), other(2 * (size_t)nl), fill;
+        // (links couple parameters 0-7: with nine parameters they sit on the even rows, camera j = row 2j)
+        const int vs = split_ ? 2 : 1;
+        std::vector<int> row(mv_ + 1, 0), other(2 * (size_t)nl), fill;
         std::vector<double> w(2 * (size_t)nl * kCP, 0.0), pw;
-        for (int q = 0; q < 2 * nl; ++q) row[h_link_cam_[q] + 1]++;
-        for (int j = 0; j < m_; ++j) row[j + 1] += row[j];
+        for (int q = 0; q < 2 * nl; ++q) row[vs * h_link_cam_[q] + 1]++;
+        for (int j = 0; j < mv_; ++j) row[j + 1] += row[j];
         fill.assign(row.begin(), row.end() - 1);
         std::unordered_map<uint64_t, int> pairs;
         for (int q = 0; q < nl; ++q) {
-            const int a = h_link_cam_[2 * q], b = h_link_cam_[2 * q + 1];
+            const int a = vs * h_link_cam_[2 * q], b = vs * h_link_cam_[2 * q + 1];
             const int ea = fill[a]++, eb = fill[b]++;
             other[ea] = b; other[eb] = a;
             const uint64_t key = ((uint64_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b);
             auto it = pairs.find(key);
             if (it == pairs.end()) { it = pairs.emplace(key, (int)pairs.size()).first; pw.resize(pairs.size() * kCP, 0.0); }
-            for (int r = 0; r < cnp; ++r) {
+            for (int r = 0; r < cnp_cam_(); ++r) {
                 const double wr = h_link_w_[(size_t)q * cnp + r];
                 if (!(wr >= 0.0)) { err = "prepare: camera link weights must be >= 0"; return MI_BA_ERROR; }
                 w[(size_t)ea * kCP + r] = wr; w[(size_t)eb * kCP + r] = wr;
@@ -299,7 +306,7 @@ int Engine::prepare()
             }
         }
         std::vector<int> blk(pl.nb_full(), -1);
-        for (int j = 0; j < m_; ++j)
+        for (int j = 0; j < mv_; ++j)
             for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) {
                 const int k = pl.bsr_col[q];
                 if (k == j) continue;
@@ -316,29 +323,36 @@ int Engine::prepare()
         std::vector<unsigned char> fx(h_fixed_);
         for (int j = 0; j < cfg.mcon && j < m_; ++j) fx[j] = 1; // sba's leading mcon cameras
         if (cfg.mode == 2) std::fill(fx.begin(), fx.end(), (unsigned char)1); // structure-only: A_ij := 0 everywhere
-        UP(d_fixed_, fx);
+        UP(d_fixed_real_, fx);
         h_fixed_eff_ = fx;
         if ((int)h_pfix_.size() != m_) h_pfix_.assign(m_, 0);
-        UP(d_pfix_, h_pfix_);
+        std::vector<unsigned char> fxv(mv_), pfv(mv_);
+        for (int j = 0; j < m_; ++j) {
+            if (!split_) { fxv[j] = fx[j]; pfv[j] = (unsigned char)(h_pfix_[j] & 0xFF); continue; }
+            fxv[2 * j] = fxv[2 * j + 1] = fx[j];
+            pfv[2 * j] = (unsigned char)(h_pfix_[j] & 0xFF);
+            pfv[2 * j + 1] = (unsigned char)(0xFE | ((h_pfix_[j] >> 8) & 1));     // row 2j + 1: parameter 8 in column 0, the other columns are padding
+        }
+        UP(d_fixed_, fxv); UP(d_pfix_, pfv);
         nfree_cams_ = 0;
         for (unsigned char f : fx) nfree_cams_ += f ? 0 : 1;
     }
 #undef UP
     const size_t npl = (size_t)pl.npts_local();
     for (int b = 0; b < 2; ++b) {
-        if (!hipok(d_cam_a_[b].alloc((size_t)m_ * kCP), "alloc cam_a")) return MI_BA_ERROR;
+        if (!hipok(d_cam_a_[b].alloc((size_t)mv_ * kCP), "alloc cam_a")) return MI_BA_ERROR;
         if (!hipok(d_cam_lin_[b].alloc((size_t)m_ * kCamLin), "alloc cam_lin")) return MI_BA_ERROR;
         if (!hipok(d_pts_[b].alloc(npl * 3), "alloc pts")) return MI_BA_ERROR;
     }
-    const size_t acc_n = 2 * nslot_() + (size_t)pl.nb_up() * 64 + (size_t)3 * m_ * kCP + kScalCount;
+    const size_t acc_n = 2 * nslot_() + (size_t)pl.nb_up() * 64 + (size_t)3 * mv_ * kCP + kScalCount;
     if (!hipok(d_ptout_.alloc(npl * kPtOut), "alloc ptout") || !hipok(d_acc_.alloc(acc_n), "alloc acc") ||
-        !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Linv_.alloc((size_t)m_ * 64), "alloc Linv") || !hipok(d_S_pcg_.alloc((size_t)pl.nb_full() * 64), "alloc S~") ||
-        !hipok(d_E_.alloc((size_t)m_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)m_ * kCP), "alloc dA") ||
-        !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)m_ * kCP * 8), "alloc pcg") ||
-        !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)m_), "alloc rz/pq") ||
+        !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Linv_.alloc((size_t)mv_ * 64), "alloc Linv") || !hipok(d_S_pcg_.alloc((size_t)pl.nb_full() * 64), "alloc S~") ||
+        !hipok(d_E_.alloc((size_t)mv_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)mv_ * kCP), "alloc dA") ||
+        !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)mv_ * kCP * 8), "alloc pcg") ||
+        !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)mv_), "alloc rz/pq") ||
         !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGrid) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
         !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage") ||
-        !hipok(d_cam_part_.alloc((size_t)((m_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
+        !hipok(d_cam_part_.alloc((size_t)((mv_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
         !hipok(d_cam_part2_.alloc((size_t)((m_ + 63) / 64 + 1) * kPartW), "alloc camera partials"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
@@ -373,9 +387,9 @@ int Engine::set_params(const double *a, const double *xyz)
 {
     DeviceGuard on_device(cfg.device);
     if (!prepared_) { err = "set_params: prepare first"; return MI_BA_ERROR; }
-    std::vector<double> ap((size_t)m_ * kCP, 0.0);
+    std::vector<double> ap((size_t)mv_ * kCP, 0.0);
     for (int j = 0; j < m_; ++j)
-        for (int r = 0; r < cnp; ++r) ap[(size_t)j * kCP + r] = a[(size_t)j * cnp + r];
+        for (int r = 0; r < cnp; ++r) ap[slot_(j, r)] = a[(size_t)j * cnp + r];
     const Plan &pl = plan_;
     const size_t npl = (size_t)pl.npts_local();
     std::vector<double> pp(npl * 3);
@@ -428,7 +442,7 @@ bool Engine::allreduce1()
 {
     if (!comm_ && !host_ar_) return true;
     double t0 = now_ms();
-    const size_t nsum = nslot_() + (size_t)plan_.nb_up() * 64 + (size_t)3 * m_ * kCP + 8;   // slots1, S_up, camvec, scal[0, 8)
+    const size_t nsum = nslot_() + (size_t)plan_.nb_up() * 64 + (size_t)3 * mv_ * kCP + 8;   // slots1, S_up, camvec, scal[0, 8)
     const int xp = lin_pair_ ? 2 : 0;
     if (timing_detail >= 2) (void)hipEventRecord(evx_[xp], st_);
     if (!exchange(d_acc_.p, nsum, 0)) return false;
@@ -450,7 +464,7 @@ LongArgs Engine::long_args(double mu, double *dB_dev, int part_row0)
 {
     LongArgs a{};
     a.long_pts = d_long_pts_.p; a.pt_obs = d_pt_obs_.p; a.obs_cam = d_obs_cam_.p; a.obs_rec = d_obs_rec_.p;
-    a.cam_fixed = d_fixed_.p; a.obs_xy = d_obs_xy_.p;
+    a.cam_fixed = d_fixed_real_.p; a.obs_xy = d_obs_xy_.p;
     a.cam_lin = d_cam_lin_[cur_].p; a.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; a.pts = d_pts_[cur_].p; a.dA = d_dA_.p;
     a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
     a.rec = d_rec_.p; a.ptout = d_ptout_.p; a.part = d_part_.p;
@@ -473,9 +487,9 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     a.tile_mode = d_tile_mode_.p; a.has_table = pl.ntile_table > 0;
     a.slot_gblk = d_slot_gblk_.p; a.cslot_cam = d_cslot_cam_.p;
     a.batch_obs = d_batch_obs_.p; a.batch_pt = d_batch_pt_.p; a.batch_pair = d_batch_pair_.p; a.pt_obs = d_pt_obs_.p;
-    a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p; a.cam_fixed = d_fixed_.p;
+    a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p; a.cam_fixed = d_fixed_real_.p;
     a.pair = d_pair_.p; a.obs_rec = d_obs_rec_.p; a.rec = d_rec_.p;
-    a.m = m_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
+    a.m = mv_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
     a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc; a.spec = spec;
     a.dbg = d_dbg_.p; a.want_diag = want_diag ? 1 : 0;
     a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
@@ -493,7 +507,8 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
         SchurArgs sa{};
         sa.rec = d_rec_.p; sa.wk_blk = d_wk_blk_.p; sa.wk_q = d_wk_q_.p; sa.rpair = d_rpair_.p;
         sa.diag_cam = d_wk_diag_cam_.p; sa.diag_blk = d_wk_diag_blk_.p; sa.rec_cam = d_rec_cam_.p;
-        sa.nwork = (int)pl.wk_blk.size(); sa.ndiag = (int)pl.wk_diag_cam.size(); sa.m = m_; sa.want_diag = want_diag ? 1 : 0;
+        sa.nwork = (int)pl.wk_blk.size(); sa.ndiag = (int)pl.wk_diag_cam.size(); sa.m = m_; sa.mv = mv_; sa.want_diag = want_diag ? 1 : 0;
+        sa.wk_vblk = d_wk_vblk_.p; sa.diag_vblk = d_wk_diag_vblk_.p;
         sa.S_up = S_up_(); sa.camvec = camvec_(); sa.spec = spec;
         launch_schur_blocks(st_, cnp, sa);
     }
@@ -501,7 +516,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST,
                            cfg.world > 1 ? slots1_() + (size_t)cfg.rank * 8 : scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
-    launch_finalize(st_, cnp, m_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
+    launch_finalize(st_, cnp_cam_(), mv_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
                     d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag /* a linear phase on its own (begin, parity hooks) */, pcg_start());
     cg_start_fresh_ = true;
@@ -526,7 +541,7 @@ PcgStart Engine::pcg_start()
 
 PcgArgs Engine::pcg_args()
 {
-    const size_t vec = (size_t)m_ * kCP;
+    const size_t vec = (size_t)mv_ * kCP;
     PcgArgs p{};
     p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_pcg_.p; p.Linv = d_Linv_.p; p.E = d_E_.p;
     double *v = d_pcg_.p;
@@ -535,10 +550,10 @@ PcgArgs Engine::pcg_args()
     // a block row of S~ gets a whole workgroup (four wavefronts share its blocks) when there are few rows.  (Measured with more
     // rows, MI_BA_PCG_ROW_WG=1: slower -- C3 0.27 -> 0.37 ms per solve, C4 (1 700 rows of ~240 blocks, S~ = 208 MB) 2.35 -> 2.62.)
     static const int force_row_wg = std::getenv("MI_BA_PCG_ROW_WG") ? std::atoi(std::getenv("MI_BA_PCG_ROW_WG")) : -1;
-    const bool row_wg = force_row_wg >= 0 ? force_row_wg != 0 : m_ <= kPcgRowPerWorkgroupMax;
-    p.ng = (m_ + 7) / 8; p.nwg = row_wg ? m_ : (m_ + 3) / 4;
+    const bool row_wg = force_row_wg >= 0 ? force_row_wg != 0 : mv_ <= kPcgRowPerWorkgroupMax;
+    p.ng = (mv_ + 7) / 8; p.nwg = row_wg ? mv_ : (mv_ + 3) / 4;
     p.rz_hist = d_rzpq_.p; p.alpha_hist = p.rz_hist + (cfg.pcg_maxit + 4); p.gp = p.alpha_hist + (cfg.pcg_maxit + 4); p.dp = p.gp + 2 * (size_t)p.nwg;
-    p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = m_; p.it = 0;
+    p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = mv_; p.it = 0;
     return p;
 }
 
@@ -631,7 +646,7 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
                       d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part2_.p);
     BacksubArgs b{};
     b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
-    b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
+    b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_real_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
     b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, kBacksubGrid); b.cfg = mc; b.scal = scal_();
     if (timing_detail >= 2) (void)hipEventRecord(ev_[4], st_);
@@ -640,7 +655,7 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     if (timing_detail >= 2) (void)hipEventRecord(ev_[5], st_);
     launch_reduce_final(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
                         cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT,
-                        m_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, peek_args(mu));
+                        m_, mv_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, peek_args(mu));
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }
@@ -812,10 +827,10 @@ int Engine::get_params(double *a, double *xyz)
     if (!prepared_) { err = "get_params: prepare first"; return MI_BA_ERROR; }
     const Plan &pl = plan_;
     if (a) {
-        std::vector<double> ap((size_t)m_ * kCP);
+        std::vector<double> ap((size_t)mv_ * kCP);
         if (!hipok(hipMemcpy(ap.data(), d_cam_a_[cur_].p, ap.size() * sizeof(double), hipMemcpyDeviceToHost), "download cam_a")) return MI_BA_ERROR;
         for (int j = 0; j < m_; ++j)
-            for (int r = 0; r < cnp; ++r) a[(size_t)j * cnp + r] = ap[(size_t)j * kCP + r];
+            for (int r = 0; r < cnp; ++r) a[(size_t)j * cnp + r] = ap[slot_(j, r)];
     }
     if (xyz) {
         const size_t npl = (size_t)pl.npts_local();
@@ -862,21 +877,29 @@ int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double 
     if (!linear_phase(mu, true) || !read_scalars()) return MI_BA_ERROR;
     const Plan &pl = plan_;
     if (cost) *cost = h_scal_[SC_COST];
-    const size_t vec = (size_t)m_ * kCP;
+    const size_t vec = (size_t)mv_ * kCP;
     std::vector<double> tmp;
     auto unpad = [&](const double *src, double *dst) {
-        for (int j = 0; j < m_; ++j) for (int r = 0; r < cnp; ++r) dst[(size_t)j * cnp + r] = src[(size_t)j * kCP + r];
+        for (int j = 0; j < m_; ++j) for (int r = 0; r < cnp; ++r) dst[(size_t)j * cnp + r] = src[slot_(j, r)];
     };
     if (S) {
         tmp.resize((size_t)pl.nb_full() * 64);
         if (!hipok(hipMemcpy(tmp.data(), d_S_full_.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost), "download S")) return MI_BA_ERROR;
         const size_t N = (size_t)m_ * cnp;
         std::fill(S, S + N * N, 0.0);
-        for (int j = 0; j < m_; ++j)
+        // row / column of the dense matrix a (row of the camera-side arrays, parameter) pair stands for, -1 = padding
+        auto dense = [&](int v, int r) -> long long {
+            if (!split_) return r < cnp ? (long long)v * cnp + r : -1;
+            return (v & 1) ? (r == 0 ? (long long)(v >> 1) * cnp + 8 : -1) : (long long)(v >> 1) * cnp + r;
+        };
+        for (int j = 0; j < mv_; ++j)
             for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) {
                 const int k = pl.bsr_col[q];
-                for (int r = 0; r < cnp; ++r)
-                    for (int c = 0; c < cnp; ++c) S[((size_t)j * cnp + r) * N + (size_t)k * cnp + c] = tmp[(size_t)q * 64 + r * 8 + c];
+                for (int r = 0; r < kCP; ++r)
+                    for (int c = 0; c < kCP; ++c) {
+                        const long long R = dense(j, r), Cc = dense(k, c);
+                        if (R >= 0 && Cc >= 0) S[(size_t)R * N + (size_t)Cc] = tmp[(size_t)q * 64 + r * 8 + c];
+                    }
             }
     }
     if (E) { tmp.resize(vec); if (!hipok(hipMemcpy(tmp.data(), d_E_.p, vec * sizeof(double), hipMemcpyDeviceToHost), "download E")) return MI_BA_ERROR; unpad(tmp.data(), E); }
@@ -920,9 +943,9 @@ int Engine::debug_solve(double mu, double *da, double *db, double *cost_new)
     const Plan &pl = plan_;
     if (cost_new) *cost_new = h_scal_[SC_COST_NEW];
     if (da) {
-        std::vector<double> tmp((size_t)m_ * kCP);
+        std::vector<double> tmp((size_t)mv_ * kCP);
         if (!hipok(hipMemcpy(tmp.data(), d_dA_.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost), "download dA")) return MI_BA_ERROR;
-        for (int j = 0; j < m_; ++j) for (int r = 0; r < cnp; ++r) da[(size_t)j * cnp + r] = h_fixed_eff_[j] ? 0.0 : tmp[(size_t)j * kCP + r];
+        for (int j = 0; j < m_; ++j) for (int r = 0; r < cnp; ++r) da[(size_t)j * cnp + r] = h_fixed_eff_[j] ? 0.0 : tmp[slot_(j, r)];
     }
     if (db) {
         const size_t npl = (size_t)pl.npts_local();

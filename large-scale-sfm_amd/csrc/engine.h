@@ -108,10 +108,15 @@ private:
 
     // host problem
     int m_ = 0, n_ = 0;
+    int mv_ = 0;               // rows of every camera-side array and of the reduced system: m_, or 2 m_ with nine camera parameters
+    bool split_ = false;       // cnp == 9 (kernels.h ModelCfg.split)
+    int cnp_cam_() const { return cnp < kCP ? cnp : kCP; }   // parameters per row of the camera-side arrays
+    size_t slot_(int j, int r) const { return split_ ? (r < kCP ? (size_t)(2 * j) * kCP + r : (size_t)(2 * j + 1) * kCP) : (size_t)j * kCP + r; }   // parameter r of camera j
     int64_t nobs_ = 0;
     std::vector<double> h_a0_, h_R0_, h_ff_, h_xyz_, h_xy_;
     std::vector<int> h_pt_, h_cam_;
-    std::vector<unsigned char> h_fixed_, h_fixed_eff_, h_pfix_;
+    std::vector<unsigned char> h_fixed_, h_fixed_eff_;
+    std::vector<unsigned short> h_pfix_;                          // per camera, bit r = parameter r held constant (r < 9)
     std::vector<double> h_cam_cw_, h_cam_cv_, h_pt_cw_, h_pt_cv_; // soft constraints (empty = none)
     std::vector<int> h_link_cam_;                                 // camera links: 2 ints per link
     std::vector<double> h_link_w_;                                // cnp weights per link
@@ -125,7 +130,9 @@ private:
     DevBuf<int> d_tile_batch_, d_tile_slot_, d_tile_cslot_, d_slot_gblk_, d_cslot_cam_, d_batch_obs_, d_batch_pt_, d_pt_obs_,
         d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_;
     DevBuf<long long> d_batch_pair_;
-    DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_, d_pfix_;   // d_pfix_: per camera, bit r = parameter r held constant
+    DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_, d_pfix_;   // per ROW of the camera-side arrays: held camera; bit r = parameter r held constant
+    DevBuf<unsigned char> d_fixed_real_;                                    // per real camera (the point-side kernels)
+    DevBuf<int> d_wk_vblk_, d_wk_diag_vblk_;
     DevBuf<unsigned> d_pair_, d_rpair_;
     DevBuf<int> d_obs_rec_, d_rec_cam_, d_wk_blk_, d_wk_diag_cam_, d_wk_diag_blk_;   // row path (plan.h)
     DevBuf<long long> d_wk_q_;
@@ -153,7 +160,7 @@ private:
     double *slots1_() { return d_acc_.p; }
     double *S_up_() { return d_acc_.p + nslot_(); }
     double *camvec_() { return S_up_() + (size_t)plan_.nb_up() * 64; }
-    double *scal_() { return camvec_() + (size_t)3 * m_ * kCP; }
+    double *scal_() { return camvec_() + (size_t)3 * mv_ * kCP; }
     double *slots2_() { return scal_() + kScalCount; }
 
     // LM state (names follow sba_levmar.c:596-613)

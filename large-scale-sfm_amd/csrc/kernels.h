@@ -25,6 +25,8 @@ constexpr int kReduceStage = 64;      // first-stage workgroups of k_reduce_part
 
 struct ModelCfg {
     int explicit_centers, est_focal, undistort, mcon;
+    int nk;             // radial coefficients that are parameters with undistort == 1: 1 (k1) or 2 (k1, k2: Bundler, sfm.c:648-649)
+    int split;          // 9 camera parameters: camera j is rows 2j (parameters 0-7) and 2j + 1 (parameter 8) of every camera-side array
     int points_fixed;   // motion-only bundle: B_ij := 0 (sba_mot_levmar_x has no structure block)
     double proj_sign, f_scale, k_scale;
 };
@@ -119,6 +121,8 @@ struct SchurArgs {
     const unsigned *rpair;        // 2 per pair: record of the row camera, record of the column camera
     const int *diag_cam, *diag_blk, *rec_cam;   // diagonal work items: camera, its diagonal block, its record range
     int nwork, ndiag, m, want_diag;
+    int mv;                       // rows of the camera-side arrays (2 m with nine camera parameters: ModelCfg.split)
+    const int *wk_vblk, *diag_vblk;   // split: the 4 virtual blocks of every work item (diagonal items: 0, 1 and 3 used)
     double *S_up, *camvec;
     const double *spec;           // as in BuildArgs
 };
@@ -162,7 +166,8 @@ struct PeekArgs {
 };
 void launch_lm_peek(hipStream_t st, double *scal, const PeekArgs &pk, double *spec);
 void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
-                         int m, const double *fv_part, const double *cu_part, double *scal, double *spec /* or nullptr */, const PeekArgs &pk);
+                         int m /* real cameras */, int mv /* rows of the camera-side arrays */, const double *fv_part, const double *cu_part,
+                         double *scal, double *spec /* or nullptr */, const PeekArgs &pk);
  // out8[c] = max over the ranks' slots, which are zeroed
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const PcgArgs &pa,
                        double *dA, const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,

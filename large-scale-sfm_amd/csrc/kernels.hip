@@ -13,6 +13,13 @@
 
 namespace miba {
 
+// layout of a row-path observation record (doubles): A row 0 | A row 1 (AP each) | B (6) | e (2) | G = B V*^-1 (6) | e - B h (2)
+template <int CNP>
+struct RecL {
+    static constexpr int AP = CNP <= 8 ? 8 : 10, A0 = 0, A1 = AP, B = 2 * AP, E = 2 * AP + 6, G = 2 * AP + 8, ER = 2 * AP + 14, SIZE = 2 * AP + 16;
+};
+static_assert(RecL<7>::SIZE == kRec && RecL<9>::SIZE == kRec9, "record sizes (plan.h)");
+
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
@@ -179,6 +186,11 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
                                      : s * f * mr * r2 / cfg.k_scale;
                 if (idx == 6) A[r][6] = dk;
                 if constexpr (CNP >= 8) { if (idx == 7) A[r][7] = dk; }
+                if (!md && cfg.nk == 2) {                                              // Bundler's second coefficient: d D / d k2 = r^4
+                    const double dk2 = s * f * mr * r2 * r2 / cfg.k_scale;
+                    if constexpr (CNP >= 8) { if (idx == 6) A[r][7] = dk2; }
+                    if constexpr (CNP >= 9) { if (idx == 7) A[r][8] = dk2; }
+                }
             }
         }
     }
@@ -194,12 +206,12 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
 // through its product with the camera's update.  With the per-camera vectors v0 = dq/d(centre or translation) . dC
 // (= -R dC with explicit centres, dt otherwise) and u = J_l(w) dw, A da = Pq (v0 - qr x u) + the intrinsics columns,
 // so neither A nor M = -[qr]x J_l is formed (a third of linearize_obs' arithmetic).
-struct CamDelta { double v0[3], u[3], df, dk; };   // df, dk: the updates of the focal-length and distortion parameters (internal units)
+struct CamDelta { double v0[3], u[3], df, dk, dk2; };   // df, dk, dk2: the updates of the focal-length and distortion parameters (internal units)
 
 __device__ __forceinline__ CamDelta cam_delta(const ModelCfg &cfg, const double *__restrict__ cl, const double *__restrict__ da, bool fixed_cam, bool full)
 {
     CamDelta d;
-    if (fixed_cam) { d.v0[0] = d.v0[1] = d.v0[2] = d.u[0] = d.u[1] = d.u[2] = d.df = d.dk = 0.0; return d; }
+    if (fixed_cam) { d.v0[0] = d.v0[1] = d.v0[2] = d.u[0] = d.u[1] = d.u[2] = d.df = d.dk = d.dk2 = 0.0; return d; }
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         d.v0[r] = cfg.explicit_centers ? -(cl[3 * r] * da[0] + cl[3 * r + 1] * da[1] + cl[3 * r + 2] * da[2]) : da[r];
@@ -208,6 +220,7 @@ __device__ __forceinline__ CamDelta cam_delta(const ModelCfg &cfg, const double 
     const bool has_f = !full || cfg.est_focal;
     d.df = has_f ? da[6] : 0.0;
     d.dk = (full && cfg.undistort) ? da[has_f ? 7 : 6] : 0.0;
+    d.dk2 = (full && cfg.undistort == 1 && cfg.nk == 2) ? da[has_f ? 8 : 7] : 0.0;   // da holds 9 entries (the ninth through the split rows)
     return d;
 }
 
@@ -253,6 +266,7 @@ __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *_
         if constexpr (CNP >= 7) {
             w[r] = fma(s * mr * D / cfg.f_scale, cd.df, w[r]);       // zero update when the focal length is not a parameter
             if (FULL) w[r] = fma(md ? -m2k * (r == 0 ? xy.x : xy.y) / cfg.k_scale : s * f * mr * r2 / cfg.k_scale, cd.dk, w[r]);
+            if (FULL) w[r] = fma(s * f * mr * r2 * r2 / cfg.k_scale, cd.dk2, w[r]);   // zero update unless k2 is a parameter
         }
     }
     if (cfg.points_fixed) { t[0] = t[1] = t[2] = 0.0; return; }      // a motion-only bundle has no structure block
@@ -262,6 +276,15 @@ __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *_
         const double B1 = Pq[1][0] * cl[c] + Pq[1][1] * cl[3 + c] + Pq[1][2] * cl[6 + c];
         t[c] = B0 * w[0] + B1 * w[1];
     }
+}
+
+// the parameters of REAL camera j out of a camera-side array of kCP-double rows: row j, or -- nine parameters -- rows 2j and 2j + 1
+__device__ __forceinline__ void load_cam_params(const ModelCfg &cfg, const double *__restrict__ arr, int j, double a[9])
+{
+    const double *row = arr + (size_t)(cfg.split ? 2 * j : j) * kCP;
+#pragma unroll
+    for (int r = 0; r < kCP; ++r) a[r] = row[r];
+    a[8] = cfg.split ? row[kCP] : 0.0;
 }
 
 // exp([w]x) R0 exactly as rot_update (sfm.c:78-117), and the left Jacobian of SO(3) at w
@@ -308,7 +331,7 @@ __device__ __forceinline__ void cam_record(const ModelCfg &cfg, int cnp, const d
     cl[18] = a[0]; cl[19] = a[1]; cl[20] = a[2];
     cl[21] = cfg.est_focal ? a[6] / cfg.f_scale : f_fix;
     cl[22] = cfg.undistort ? a[cfg.est_focal ? 7 : 6] / cfg.k_scale : 0.0; // k1 (sfm.c:364, TEST_FOCAL scaling)
-    cl[23] = 0.0;                                                          // k2 is not a parameter here
+    cl[23] = (cfg.undistort == 1 && cfg.nk == 2) ? a[cfg.est_focal ? 8 : 7] / cfg.k_scale : 0.0;   // k2 (a: 9 entries then)
     (void)cnp;
 }
 
@@ -317,7 +340,9 @@ __global__ void k_cam_prep(int m, int cnp, ModelCfg cfg, const double *__restric
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
-    cam_record(cfg, cnp, cam_a + (size_t)j * kCP, R0 + (size_t)j * 9, f_fixed ? f_fixed[j] : 1.0, cam_lin + (size_t)j * kCamLin);
+    double a[9];
+    load_cam_params(cfg, cam_a, j, a);
+    cam_record(cfg, cnp, a, R0 + (size_t)j * 9, f_fixed ? f_fixed[j] : 1.0, cam_lin + (size_t)j * kCamLin);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -702,15 +727,16 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
                     G[r][1] = fma(B[r][2], i12, fma(B[r][1], i11, B[r][0] * i01));
                     G[r][2] = fma(B[r][2], i22, fma(B[r][1], i12, B[r][0] * i02));
                 }
-                double out[kRec];
+                using L = RecL<CNP>;
+                double out[L::SIZE];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) { out[t] = t < CNP ? A[0][t] : 0.0; out[8 + t] = t < CNP ? A[1][t] : 0.0; }
+                for (int t = 0; t < L::AP; ++t) { out[L::A0 + t] = t < CNP ? A[0][t < CNP ? t : 0] : 0.0; out[L::A1 + t] = t < CNP ? A[1][t < CNP ? t : 0] : 0.0; }
 #pragma unroll
-                for (int t = 0; t < 3; ++t) { out[16 + t] = B[0][t]; out[19 + t] = B[1][t]; out[24 + t] = G[0][t]; out[27 + t] = G[1][t]; }
-                out[22] = e[0]; out[23] = e[1]; out[30] = er[0]; out[31] = er[1];
-                double2 *dst = reinterpret_cast<double2 *>(g.rec + (size_t)my_rec * kRec);
+                for (int t = 0; t < 3; ++t) { out[L::B + t] = B[0][t]; out[L::B + 3 + t] = B[1][t]; out[L::G + t] = G[0][t]; out[L::G + 3 + t] = G[1][t]; }
+                out[L::E] = e[0]; out[L::E + 1] = e[1]; out[L::ER] = er[0]; out[L::ER + 1] = er[1];
+                double2 *dst = reinterpret_cast<double2 *>(g.rec + (size_t)my_rec * L::SIZE);
 #pragma unroll
-                for (int t = 0; t < kRec / 2; ++t) dst[t] = make_double2(out[2 * t], out[2 * t + 1]);
+                for (int t = 0; t < L::SIZE / 2; ++t) dst[t] = make_double2(out[2 * t], out[2 * t + 1]);
             }
         }
         wave_lds_sync();
@@ -765,6 +791,7 @@ __device__ __forceinline__ double block_sum_256(double v, double *sh)
 template <int CNP>
 __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
 {
+    using L = RecL<CNP>;
     __shared__ double sh[4], sVh[9];
     if (g.spec && g.spec[0] == 0.0) return;
     const double mu_lin = g.spec ? g.spec[1] : g.mu;
@@ -782,12 +809,12 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
         v[4] += B[0][1] * B[0][2] + B[1][1] * B[1][2]; v[5] += B[0][2] * B[0][2] + B[1][2] * B[1][2];
 #pragma unroll
         for (int r = 0; r < 3; ++r) v[6 + r] += B[0][r] * e[0] + B[1][r] * e[1];
-        double *row = g.rec + (size_t)g.obs_rec[o] * kRec;
+        double *row = g.rec + (size_t)g.obs_rec[o] * L::SIZE;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { row[t] = t < CNP ? A[0][t] : 0.0; row[8 + t] = t < CNP ? A[1][t] : 0.0; }
+        for (int t = 0; t < L::AP; ++t) { row[L::A0 + t] = t < CNP ? A[0][t < CNP ? t : 0] : 0.0; row[L::A1 + t] = t < CNP ? A[1][t < CNP ? t : 0] : 0.0; }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { row[16 + t] = B[0][t]; row[19 + t] = B[1][t]; }
-        row[22] = e[0]; row[23] = e[1];
+        for (int t = 0; t < 3; ++t) { row[L::B + t] = B[0][t]; row[L::B + 3 + t] = B[1][t]; }
+        row[L::E] = e[0]; row[L::E + 1] = e[1];
     }
 #pragma unroll
     for (int c = 0; c < 9; ++c) v[c] = block_sum_256(v[c], sh);
@@ -828,13 +855,14 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
     __syncthreads();
     const double i00 = sVh[0], i01 = sVh[1], i02 = sVh[2], i11 = sVh[3], i12 = sVh[4], i22 = sVh[5];
     for (int o = os + tid; o < oe; o += 256) {
-        double *row = g.rec + (size_t)g.obs_rec[o] * kRec; // written by this same thread above
-        const double B0[3] = { row[16], row[17], row[18] }, B1[3] = { row[19], row[20], row[21] };
-        row[24] = B0[0] * i00 + B0[1] * i01 + B0[2] * i02; row[25] = B0[0] * i01 + B0[1] * i11 + B0[2] * i12;
-        row[26] = B0[0] * i02 + B0[1] * i12 + B0[2] * i22; row[27] = B1[0] * i00 + B1[1] * i01 + B1[2] * i02;
-        row[28] = B1[0] * i01 + B1[1] * i11 + B1[2] * i12; row[29] = B1[0] * i02 + B1[1] * i12 + B1[2] * i22;
-        row[30] = row[22] - (B0[0] * sVh[6] + B0[1] * sVh[7] + B0[2] * sVh[8]);
-        row[31] = row[23] - (B1[0] * sVh[6] + B1[1] * sVh[7] + B1[2] * sVh[8]);
+        double *row = g.rec + (size_t)g.obs_rec[o] * L::SIZE; // written by this same thread above
+        const double B0[3] = { row[L::B], row[L::B + 1], row[L::B + 2] }, B1[3] = { row[L::B + 3], row[L::B + 4], row[L::B + 5] };
+        double *G = row + L::G;
+        G[0] = B0[0] * i00 + B0[1] * i01 + B0[2] * i02; G[1] = B0[0] * i01 + B0[1] * i11 + B0[2] * i12;
+        G[2] = B0[0] * i02 + B0[1] * i12 + B0[2] * i22; G[3] = B1[0] * i00 + B1[1] * i01 + B1[2] * i02;
+        G[4] = B1[0] * i01 + B1[1] * i11 + B1[2] * i12; G[5] = B1[0] * i02 + B1[1] * i12 + B1[2] * i22;
+        row[L::ER] = row[L::E] - (B0[0] * sVh[6] + B0[1] * sVh[7] + B0[2] * sVh[8]);
+        row[L::ER + 1] = row[L::E + 1] - (B1[0] * sVh[6] + B1[1] * sVh[7] + B1[2] * sVh[8]);
     }
 }
 
@@ -848,7 +876,8 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
 template <int CNP, bool DIAG>
 __global__ __launch_bounds__(64, (CNP <= 7 && !DIAG) ? 2 : 1) void k_schur_blocks(const SchurArgs g)
 {
-    constexpr int BLK = CNP * CNP;
+    using L = RecL<CNP>;
+    constexpr int BLK = CNP * CNP, AP = L::AP;
     constexpr int NV = DIAG ? BLK + 3 * CNP : BLK;
     constexpr int ST = NV | 1;                       // odd row stride: the lanes' ds_write_b64 and the column reads are conflict-free
     __shared__ double sRed[32 * ST];
@@ -874,21 +903,21 @@ __global__ __launch_bounds__(64, (CNP <= 7 && !DIAG) ? 2 : 1) void k_schur_block
         size_t ra, rb;
         if constexpr (DIAG) { ra = rb = (size_t)q; }
         else { ra = ent_next.x; rb = ent_next.y; if (q + kWave < q1) ent_next = rp[q + kWave]; }
-        const double2 *pa = reinterpret_cast<const double2 *>(g.rec + ra * kRec);
-        const double2 *pb = reinterpret_cast<const double2 *>(g.rec + rb * kRec);
-        double Aa[16], Ab[16], G[6], Bb[6];
+        const double2 *pa = reinterpret_cast<const double2 *>(g.rec + ra * L::SIZE);
+        const double2 *pb = reinterpret_cast<const double2 *>(g.rec + rb * L::SIZE);
+        double Aa[2 * AP], Ab[2 * AP], G[6], Bb[6];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const double2 v = pa[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
+        for (int t = 0; t < AP; ++t) { const double2 v = pa[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { const double2 v = pa[12 + t]; G[2 * t] = v.x; G[2 * t + 1] = v.y; }
+        for (int t = 0; t < 3; ++t) { const double2 v = pa[L::G / 2 + t]; G[2 * t] = v.x; G[2 * t + 1] = v.y; }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) { const double2 v = pb[8 + t]; Bb[2 * t] = v.x; Bb[2 * t + 1] = v.y; }
+        for (int t = 0; t < 3; ++t) { const double2 v = pb[L::B / 2 + t]; Bb[2 * t] = v.x; Bb[2 * t + 1] = v.y; }
         if constexpr (DIAG) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) Ab[t] = Aa[t];
+            for (int t = 0; t < 2 * AP; ++t) Ab[t] = Aa[t];
         } else {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { const double2 v = pb[t]; Ab[2 * t] = v.x; Ab[2 * t + 1] = v.y; }
+            for (int t = 0; t < AP; ++t) { const double2 v = pb[t]; Ab[2 * t] = v.x; Ab[2 * t + 1] = v.y; }
         }
         // M = delta_ab I - G_a B_b^T;  G = [G0 (3) | G1 (3)], B = [B0 (3) | B1 (3)]
         double M00 = fma(G[2], Bb[2], fma(G[1], Bb[1], G[0] * Bb[0])), M01 = fma(G[2], Bb[5], fma(G[1], Bb[4], G[0] * Bb[3]));
@@ -897,18 +926,18 @@ __global__ __launch_bounds__(64, (CNP <= 7 && !DIAG) ? 2 : 1) void k_schur_block
         M00 = dg - M00; M01 = -M01; M10 = -M10; M11 = dg - M11;
         double T0[CNP], T1[CNP];
 #pragma unroll
-        for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, Ab[8 + c], M00 * Ab[c]); T1[c] = fma(M11, Ab[8 + c], M10 * Ab[c]); }
+        for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, Ab[AP + c], M00 * Ab[c]); T1[c] = fma(M11, Ab[AP + c], M10 * Ab[c]); }
 #pragma unroll
         for (int r = 0; r < CNP; ++r)
 #pragma unroll
-            for (int c = 0; c < CNP; ++c) acc[r * CNP + c] = fma(Aa[8 + r], T1[c], fma(Aa[r], T0[c], acc[r * CNP + c]));
+            for (int c = 0; c < CNP; ++c) acc[r * CNP + c] = fma(Aa[AP + r], T1[c], fma(Aa[r], T0[c], acc[r * CNP + c]));
         if constexpr (DIAG) {
-            const double2 ee = pa[11], rr = pa[15];
+            const double2 ee = pa[L::E / 2], rr = pa[L::ER / 2];
 #pragma unroll
             for (int r = 0; r < CNP; ++r) {
-                acc[BLK + r] = fma(Aa[8 + r], ee.y, fma(Aa[r], ee.x, acc[BLK + r]));
-                acc[BLK + CNP + r] = fma(Aa[8 + r], rr.y, fma(Aa[r], rr.x, acc[BLK + CNP + r]));
-                acc[BLK + 2 * CNP + r] = fma(Aa[8 + r], Aa[8 + r], fma(Aa[r], Aa[r], acc[BLK + 2 * CNP + r]));
+                acc[BLK + r] = fma(Aa[AP + r], ee.y, fma(Aa[r], ee.x, acc[BLK + r]));
+                acc[BLK + CNP + r] = fma(Aa[AP + r], rr.y, fma(Aa[r], rr.x, acc[BLK + CNP + r]));
+                acc[BLK + 2 * CNP + r] = fma(Aa[AP + r], Aa[AP + r], fma(Aa[r], Aa[r], acc[BLK + 2 * CNP + r]));
             }
         }
     }
@@ -940,11 +969,25 @@ __global__ __launch_bounds__(64, (CNP <= 7 && !DIAG) ? 2 : 1) void k_schur_block
         if (r < rows) s0 += sRed[r * ST + c];
         const double v = s0 + s1;
         if (c < BLK) {
-            double *dst = g.S_up + (size_t)gb * (kCP * kCP) + (c / CNP) * kCP + (c % CNP);
-            *dst += v;        // the register tiles of the same linearisation (an earlier kernel on this stream) may have added here already
+            const int br = c / CNP, bc = c % CNP;
+            if constexpr (CNP <= kCP) {
+                // (the register tiles of the same linearisation -- an earlier kernel on this stream -- may have added here already)
+                g.S_up[(size_t)gb * (kCP * kCP) + br * kCP + bc] += v;
+            } else {
+                // nine parameters: the block lands in the blocks of the two virtual cameras of each side (kernels.h ModelCfg.split):
+                // (2a, 2b) parameters 0-7 x 0-7, (2a, 2b+1) x parameter 8, (2a+1, 2b) parameter 8 x, (2a+1, 2b+1) the corner
+                const int *vb = (DIAG ? g.diag_vblk : g.wk_vblk) + (size_t)w * 4;
+                const int hi_r = br == kCP, hi_c = bc == kCP;
+                const int which = 2 * hi_r + hi_c;
+                if (!(DIAG && which == 2))                                   // the diagonal item's lower corner block is its upper one mirrored
+                    g.S_up[(size_t)vb[which] * (kCP * kCP) + (hi_r ? 0 : br) * kCP + (hi_c ? 0 : bc)] += v;
+            }
         } else if constexpr (DIAG) {
             const int which = (c - BLK) / CNP, t = (c - BLK) % CNP;
-            if (which < 2 || g.want_diag) g.camvec[((size_t)which * g.m + cam) * kCP + t] += v;
+            if (which < 2 || g.want_diag) {
+                const int vcam = CNP <= kCP ? cam : 2 * cam + (t == kCP), vt = (CNP > kCP && t == kCP) ? 0 : t;
+                g.camvec[((size_t)which * g.mv + vcam) * kCP + vt] += v;
+            }
         }
     }
 }
@@ -1071,14 +1114,17 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
     const int os = g.pt_obs[ip], oe = g.pt_obs[ip + 1];
     const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
     double t3[3] = { 0, 0, 0 };
+    using L = RecL<CNP>;
     for (int o = os + tid; o < oe; o += 256) {
         const int j = g.obs_cam[o];
-        const double *row = g.rec + (size_t)g.obs_rec[o] * kRec; // A, B, e of this trial's k_long_reduce
+        const double *row = g.rec + (size_t)g.obs_rec[o] * L::SIZE; // A, B, e of this trial's k_long_reduce
+        double da[9];
+        load_cam_params(g.cfg, g.dA, j, da);
         double w0 = 0.0, w1 = 0.0;
 #pragma unroll
-        for (int t = 0; t < CNP; ++t) { const double dd = g.dA[j * kCP + t]; w0 += row[t] * dd; w1 += row[8 + t] * dd; }
+        for (int t = 0; t < CNP; ++t) { w0 += row[L::A0 + t] * da[t]; w1 += row[L::A1 + t] * da[t]; }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) t3[t] += row[16 + t] * w0 + row[19 + t] * w1;
+        for (int t = 0; t < 3; ++t) t3[t] += row[L::B + t] * w0 + row[L::B + 3 + t] * w1;
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) t3[c] = block_sum_256(t3[c], sh);
@@ -1099,11 +1145,11 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
     double cn = 0.0, pct = 0.0;
     for (int o = os + tid; o < oe; o += 256) {
         const int j = g.obs_cam[o];
-        const double *row = g.rec + (size_t)g.obs_rec[o] * kRec;
+        const double *row = g.rec + (size_t)g.obs_rec[o] * L::SIZE;
         const double2 xy = g.obs_xy[o];
         double u, v;
         project_obs<true>(g.cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, xy, u, v);
-        const double en0 = xy.x - u, en1 = xy.y - v, e0 = row[22], e1 = row[23];
+        const double en0 = xy.x - u, en1 = xy.y - v, e0 = row[L::E], e1 = row[L::E + 1];
         cn += en0 * en0 + en1 * en1;
         double pc = 0.0;
         if (!(e0 < g.eps5 && en0 < g.eps5)) pc = fmax(pc, fabs((e0 - en0) / e0));
@@ -1643,26 +1689,35 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
                              const double *__restrict__ R0, const double *__restrict__ f_fixed, const CamLinks lk,
                              double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ part)
 {
+    // one thread per REAL camera; its parameters sit in row j of the camera-side arrays, or -- nine parameters, cfg.split -- in
+    // rows 2j (parameters 0-7) and 2j + 1 (parameter 8, the rest of that row is padding held at zero)
     if (pa.tail && blockIdx.x == 0) pcg_tail(pa);
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double dl = 0.0, dp2 = 0.0, lc = 0.0;
     if (j < m) {
-        double an[kCP];
+        const int vb = cfg.split ? 2 * j : j, nrow = cfg.split ? 2 : 1;
+        double an[9];
+        an[8] = 0.0;
+        for (int row = 0; row < nrow; ++row) {
+            const int v = vb + row;
 #pragma unroll
-        for (int r = 0; r < kCP; ++r) {
-            const double dj = scaled_back(pa, j, r);
-            dA[j * kCP + r] = dj;
-            const double d = (r < cnp && !fixed[j]) ? dj : 0.0;
-            an[r] = cam_a[j * kCP + r] + d;
-            cam_a_new[j * kCP + r] = an[r];
-            dl += d * (mu * d + camvec[j * kCP + r]);
-            dp2 += d * d;
+            for (int r = 0; r < kCP; ++r) {
+                const double dj = scaled_back(pa, v, r);
+                dA[v * kCP + r] = dj;
+                const bool live = (row == 0 ? r < cnp : r == 0) && !fixed[v];
+                const double d = live ? dj : 0.0;
+                const double a_new = cam_a[v * kCP + r] + d;
+                cam_a_new[v * kCP + r] = a_new;
+                dl += d * (mu * d + camvec[v * kCP + r]);
+                dp2 += d * d;
+                if (row == 0) an[r] = a_new; else if (r == 0) an[8] = a_new;
+            }
         }
         cam_record(cfg, cnp, an, R0 + (size_t)j * 9, f_fixed ? f_fixed[j] : 1.0, cam_lin_new + (size_t)j * kCamLin);
-        if (lk.row)                                            // link penalty at the trial point
-            for (int q = lk.row[j]; q < lk.row[j + 1]; ++q) {
+        if (lk.row)                                            // link penalty at the trial point (links couple parameters 0-7: row vb)
+            for (int q = lk.row[vb]; q < lk.row[vb + 1]; ++q) {
                 const int k = lk.other[q];
-                for (int r = 0; r < cnp; ++r) {
+                for (int r = 0; r < (cnp < kCP ? cnp : kCP); ++r) {
                     const double ak = cam_a[k * kCP + r] + (fixed[k] ? 0.0 : scaled_back(pa, k, r)), dq = ak - an[r];
                     lc = fma(0.5 * lk.w[(size_t)q * kCP + r], dq * dq, lc);
                 }
@@ -1733,16 +1788,17 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
             if (j != jc) {
                 const double2 *s0 = reinterpret_cast<const double2 *>(g.cam_lin + (size_t)j * kCamLin);
                 const double2 *s1 = reinterpret_cast<const double2 *>(g.cam_lin_new + (size_t)j * kCamLin);
-                const double2 *s2 = reinterpret_cast<const double2 *>(g.dA + (size_t)j * kCP);
+                const double2 *s2 = reinterpret_cast<const double2 *>(g.dA + (size_t)(cfg.split ? 2 * j : j) * kCP);
 #pragma unroll
                 for (int k = 0; k < kCamLin / 2; ++k) { const double2 v = s0[k]; cl[2 * k] = v.x; cl[2 * k + 1] = v.y; }
 #pragma unroll
                 for (int k = 0; k < 5; ++k) { const double2 v = s1[k]; cln[2 * k] = v.x; cln[2 * k + 1] = v.y; }       // R (9)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { const double2 v = s1[9 + k]; cln[10 + 2 * k] = v.x; cln[11 + 2 * k] = v.y; } // c f k1 k2
-                double da[kCP];
+                double da[9];
 #pragma unroll
                 for (int k = 0; k < kCP / 2; ++k) { const double2 v = s2[k]; da[2 * k] = v.x; da[2 * k + 1] = v.y; }
+                da[8] = (CNP > kCP && cfg.split) ? g.dA[(size_t)(2 * j + 1) * kCP] : 0.0;
                 cd = cam_delta(cfg, cl, da, g.cam_fixed[j] != 0, FULL);
                 jc = j;
             }
@@ -1831,6 +1887,7 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
     if (ntiles <= 0) return;
     // the lean instantiation unless the problem carries soft point constraints or measurement distortion
     const bool full = a.pt_cw != nullptr || a.cfg.undistort != 0;
+    if (cnp == 9) { if (!lds_mode) hipLaunchKernelGGL((k_build<9, false, true, false>), dim3(ntiles), dim3(64), 0, st, a); return; }   // row tiles only (plan.h cam_split)
     if (cnp == 8) { if (full) launch_build_t<8, true>(st, lds_mode, ntiles, a); else launch_build_t<8, false>(st, lds_mode, ntiles, a); }
     else if (cnp == 7) { if (full) launch_build_t<7, true>(st, lds_mode, ntiles, a); else launch_build_t<7, false>(st, lds_mode, ntiles, a); }
     else { if (full) launch_build_t<6, true>(st, lds_mode, ntiles, a); else launch_build_t<6, false>(st, lds_mode, ntiles, a); }
@@ -1946,7 +2003,7 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, cons
 
 // last stage of the back-substitution's reduction (its first stage first when there are many rows) + the camera-side sums + peek
 void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
-                         int m, const double *fv_part, const double *cu_part, double *scal, double *spec, const PeekArgs &pk)
+                         int m, int mv, const double *fv_part, const double *cu_part, double *scal, double *spec, const PeekArgs &pk)
 {
     FinalReduceArgs a;
     a.bs_part = bs_part; a.bs_rows = bs_rows;
@@ -1955,8 +2012,8 @@ void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, dou
         a.bs_part = stage; a.bs_rows = kReduceStage;
     }
     a.bs_sum = bs_sum; a.bs_max = bs_max;
-    a.fv_part = fv_part; a.fv_rows = (m * kCP + 63) / 64;
-    a.cu_part = cu_part; a.cu_rows = (m + 63) / 64;
+    a.fv_part = fv_part; a.fv_rows = (mv * kCP + 63) / 64;     // k_finalize_vec: a row per wavefront of (virtual camera, parameter) threads
+    a.cu_part = cu_part; a.cu_rows = (m + 63) / 64;            // k_cam_update: a thread per real camera
     a.scal = scal; a.spec = spec; a.pk = pk;
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, st, a);
 }
@@ -1965,6 +2022,7 @@ void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
 {
     if (a.nbatch <= 0) return;
     const bool full = a.cfg.undistort != 0;
+    if (cnp == 9) { hipLaunchKernelGGL((k_backsub<9, true>), dim3(a.ngrid), dim3(64), 0, st, a); return; }
     if (cnp == 8) { if (full) hipLaunchKernelGGL((k_backsub<8, true>), dim3(a.ngrid), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_backsub<8, false>), dim3(a.ngrid), dim3(64), 0, st, a); }
     else if (cnp == 7) { if (full) hipLaunchKernelGGL((k_backsub<7, true>), dim3(a.ngrid), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_backsub<7, false>), dim3(a.ngrid), dim3(64), 0, st, a); }
     else hipLaunchKernelGGL((k_backsub<6, false>), dim3(a.ngrid), dim3(64), 0, st, a);
@@ -1973,7 +2031,8 @@ void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
 void launch_long_build(hipStream_t st, int cnp, const LongArgs &a)
 {
     if (a.nlong <= 0) return;
-    if (cnp == 8) hipLaunchKernelGGL((k_long_reduce<8>), dim3(a.nlong), dim3(256), 0, st, a);
+    if (cnp == 9) hipLaunchKernelGGL((k_long_reduce<9>), dim3(a.nlong), dim3(256), 0, st, a);
+    else if (cnp == 8) hipLaunchKernelGGL((k_long_reduce<8>), dim3(a.nlong), dim3(256), 0, st, a);
     else if (cnp == 7) hipLaunchKernelGGL((k_long_reduce<7>), dim3(a.nlong), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_long_reduce<6>), dim3(a.nlong), dim3(256), 0, st, a);
 }
@@ -1991,7 +2050,10 @@ static void launch_schur_blocks_t(hipStream_t st, const SchurArgs &a)
 
 void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a)
 {
-    if (cnp == 8) launch_schur_blocks_t<8>(st, a);
+    if (cnp == 9) {   // nine parameters: every lane fetches its own (288-byte) records
+        if (a.ndiag > 0) hipLaunchKernelGGL((k_schur_blocks<9, true>), dim3(8 * ((a.ndiag + 7) / 8)), dim3(64), 0, st, a);
+        if (a.nwork > 0) hipLaunchKernelGGL((k_schur_blocks<9, false>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
+    } else if (cnp == 8) launch_schur_blocks_t<8>(st, a);
     else if (cnp == 7) launch_schur_blocks_t<7>(st, a);
     else launch_schur_blocks_t<6>(st, a);
 }
@@ -1999,7 +2061,8 @@ void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a)
 void launch_long_backsub(hipStream_t st, int cnp, const LongArgs &a)
 {
     if (a.nlong <= 0) return;
-    if (cnp == 8) hipLaunchKernelGGL((k_long_backsub<8>), dim3(a.nlong), dim3(256), 0, st, a);
+    if (cnp == 9) hipLaunchKernelGGL((k_long_backsub<9>), dim3(a.nlong), dim3(256), 0, st, a);
+    else if (cnp == 8) hipLaunchKernelGGL((k_long_backsub<8>), dim3(a.nlong), dim3(256), 0, st, a);
     else if (cnp == 7) hipLaunchKernelGGL((k_long_backsub<7>), dim3(a.nlong), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_long_backsub<6>), dim3(a.nlong), dim3(256), 0, st, a);
 }

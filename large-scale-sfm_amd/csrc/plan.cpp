@@ -51,8 +51,9 @@ static void parallel_ranges(int n, F fn)
 }
 
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
-                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs, bool all_rows)
+                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs, bool all_rows, bool cam_split)
 {
+    if (cam_split) all_rows = true;    // nine-parameter blocks exist on the row path only
     if (n <= 0 || m <= 0 || nobs < 0) return "empty problem";
     if (world < 1 || rank < 0 || rank >= world) return "bad rank/world";
     if ((int64_t)m * m / 8 > (int64_t)1 << 30) return "more than ~92k cameras is not supported yet";
@@ -60,7 +61,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     const bool auto_tile = tile_max_batches <= 0;
     if (auto_tile || tile_max_batches > kMaxTileBatches) tile_max_batches = kMaxTileBatches;
     pl = Plan();
-    pl.n = n; pl.m = m; pl.nobs = nobs; pl.rank = rank; pl.world = world;
+    pl.n = n; pl.m = m; pl.mv = m; pl.nobs = nobs; pl.rank = rank; pl.world = world;
     // MI_BA_PLAN_TIMING=1: where the planner's time goes, stage by stage, to stderr
     const bool timing = std::getenv("MI_BA_PLAN_TIMING") != nullptr;
     auto t_prev = std::chrono::steady_clock::now();
@@ -555,6 +556,56 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         for (int j = 0; j < m; ++j)
             if (pl.rec_cam[j + 1] > pl.rec_cam[j]) { pl.wk_diag_cam.push_back(j); pl.wk_diag_blk.push_back(pl.upper_block(j, j)); }
         stage("row path: records + pair lists");
+    }
+    if (cam_split) {
+        // nine camera parameters: the pattern of S over VIRTUAL cameras.  Real row a = [a = b_0 < b_1 < ...] (n_a entries) becomes
+        //   row 2a    : (2a,2a) (2a,2a+1) (2a,2b_1) (2a,2b_1+1) ...          2 n_a entries, entry k of the real row at 2k, 2k + 1
+        //   row 2a + 1: (2a+1,2a+1) (2a+1,2b_1) (2a+1,2b_1+1) ...            2 n_a - 1 entries, entry k >= 1 at 2k - 1, 2k
+        const std::vector<int> rrow = pl.up_row, rcol = pl.up_col;
+        const int mv = 2 * m;
+        std::vector<int> vrow(mv + 1, 0);
+        for (int a = 0; a < m; ++a) { const int na = rrow[a + 1] - rrow[a]; vrow[2 * a + 1] = vrow[2 * a] + 2 * na; vrow[2 * a + 2] = vrow[2 * a + 1] + 2 * na - 1; }
+        std::vector<int> vcol(vrow[mv]);
+        for (int a = 0; a < m; ++a)
+            for (int k = 0; k < rrow[a + 1] - rrow[a]; ++k) {
+                const int b = rcol[rrow[a] + k];
+                vcol[vrow[2 * a] + 2 * k] = 2 * b; vcol[vrow[2 * a] + 2 * k + 1] = 2 * b + 1;
+                if (k == 0) vcol[vrow[2 * a + 1]] = 2 * a + 1;
+                else { vcol[vrow[2 * a + 1] + 2 * k - 1] = 2 * b; vcol[vrow[2 * a + 1] + 2 * k] = 2 * b + 1; }
+            }
+        auto vblocks = [&](int g, int a, int out[4]) {      // real upper block g of real row a
+            const int k = g - rrow[a];
+            out[0] = vrow[2 * a] + 2 * k; out[1] = out[0] + 1;
+            out[2] = k == 0 ? -1 : vrow[2 * a + 1] + 2 * k - 1; out[3] = k == 0 ? vrow[2 * a + 1] : vrow[2 * a + 1] + 2 * k;
+        };
+        std::vector<int> row_of(rcol.size());
+        for (int a = 0; a < m; ++a) for (int q = rrow[a]; q < rrow[a + 1]; ++q) row_of[q] = a;
+        pl.wk_vblk.resize(pl.wk_blk.size() * 4); pl.wk_diag_vblk.resize(pl.wk_diag_blk.size() * 4);
+        for (size_t w = 0; w < pl.wk_blk.size(); ++w) vblocks(pl.wk_blk[w], row_of[pl.wk_blk[w]], &pl.wk_vblk[4 * w]);
+        for (size_t w = 0; w < pl.wk_diag_blk.size(); ++w) vblocks(pl.wk_diag_blk[w], pl.wk_diag_cam[w], &pl.wk_diag_vblk[4 * w]);
+        pl.up_row = vrow; pl.up_col = vcol; pl.mv = mv;
+        // full pattern of the virtual cameras, as above
+        std::vector<int> lowcnt(mv, 0);
+        for (int j = 0; j < mv; ++j)
+            for (int q = pl.up_row[j]; q < pl.up_row[j + 1]; ++q) if (pl.up_col[q] != j) lowcnt[pl.up_col[q]]++;
+        pl.bsr_row.assign(mv + 1, 0);
+        for (int j = 0; j < mv; ++j) pl.bsr_row[j + 1] = pl.bsr_row[j] + lowcnt[j] + (pl.up_row[j + 1] - pl.up_row[j]);
+        const int nbf = pl.bsr_row[mv];
+        pl.bsr_col.assign(nbf, 0); pl.bsr_src.assign(nbf, 0); pl.bsr_trans.assign(nbf, 0);
+        std::vector<int> fill(pl.bsr_row.begin(), pl.bsr_row.end() - 1);
+        for (int j = 0; j < mv; ++j)
+            for (int q = pl.up_row[j]; q < pl.up_row[j + 1]; ++q) {
+                const int k = pl.up_col[q];
+                if (k == j) continue;
+                const int pos = fill[k]++;
+                pl.bsr_col[pos] = j; pl.bsr_src[pos] = q; pl.bsr_trans[pos] = 1;
+            }
+        for (int j = 0; j < mv; ++j)
+            for (int q = pl.up_row[j]; q < pl.up_row[j + 1]; ++q) {
+                const int pos = fill[j]++;
+                pl.bsr_col[pos] = pl.up_col[q]; pl.bsr_src[pos] = q; pl.bsr_trans[pos] = 0;
+            }
+        stage("virtual cameras");
     }
     return "";
 }

@@ -43,10 +43,13 @@ constexpr int kMinRunPts = 12;          // a camera set shared by fewer consecut
                                         // per-point work and no atomics; break-even ~14 points.  MI_BA_MIN_RUN_PTS overrides (probes);
                                         // mi_ba_config.deterministic sends EVERY point down the row path
 constexpr int kRec = 32;                // doubles per observation record: A (2 x 8) | B (6) | e (2) | G = B V*^-1 (6) | e - B h (2)
+constexpr int kRec9 = 36;               // the same with nine camera parameters: A (2 x 10)
 constexpr int kCP = 8;           // padded camera block dimension (cnp <= 8)
 
 struct Plan {
     int n = 0, m = 0, rank = 0, world = 1;
+    int mv = 0;                  // rows of the reduced system's block pattern: m, or 2 m with nine camera parameters (cam_split): camera j
+                                 // = rows 2j (parameters 0-7) and 2j + 1 (parameter 8) -- up_*, bsr_* then describe the VIRTUAL cameras
     int64_t nobs = 0;
     int n_active = 0;            // points with >= 1 observation (internal order: actives first)
     int pt_begin = 0, pt_end = 0;// this rank's points, internal order
@@ -78,6 +81,7 @@ struct Plan {
     std::vector<int64_t> wk_q;                       // ... and its pairs rpair[2 wk_q[w] .. 2 wk_q[w+1])
     std::vector<uint32_t> rpair;                     // per pair: record of the row camera's observation, record of the column camera's
     std::vector<int> wk_diag_cam, wk_diag_blk;       // diagonal work items: cameras with records, and their diagonal block
+    std::vector<int> wk_vblk, wk_diag_vblk;          // cam_split: 4 virtual blocks per work item: (2a,2b) (2a,2b+1) (2a+1,2b) (2a+1,2b+1)
     int64_t nrow_pts = 0;                            // points on the row path (long ones included)
     int ntile_lds = 0, nbatch_lds = 0;
     std::vector<int> long_pts;                       // local points with > kWave observations (row path, workgroup per point)
@@ -97,6 +101,7 @@ struct Plan {
 // (parameter couplings between cameras, kernels.h CamLinks)
 // all_rows: every point takes the row path (the deterministic mode: no floating-point atomics anywhere)
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
-                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs = nullptr, bool all_rows = false);
+                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs = nullptr, bool all_rows = false,
+                       bool cam_split = false);
 
 } // namespace miba

@@ -12,12 +12,14 @@ namespace {
 
 struct Constraints { const double *cam_w = nullptr, *cam_v = nullptr, *pt_w = nullptr, *pt_v = nullptr; };
 
+// cnp 6 / 7: pose (+ focal length); undistort: + k1, k2 (cnp 8 / 9), Bundler's projection distortion (sfm.c:360-373, 648-649)
 int solve(int n, int m, int mcon, const char *vmask, double *p, int cnp, const double *x, const double *R0,
           const double *f_fixed, int explicit_centers, int itmax, int verbose, const double opts[6], double info[10], int mode = 0,
-          const Constraints &cons = Constraints())
+          const Constraints &cons = Constraints(), int undistort = 0)
 {
-    if (n <= 0 || m <= 0 || !vmask || !p || !x || !R0 || (cnp != 6 && cnp != 7)) {
-        std::fprintf(stderr, "mi_sba_motstr_levmar: bad arguments (cnp must be 6 or 7)\n");
+    const int est_focal = undistort ? cnp == 9 : cnp == 7;
+    if (n <= 0 || m <= 0 || !vmask || !p || !x || !R0 || (undistort ? (cnp != 8 && cnp != 9) : (cnp != 6 && cnp != 7))) {
+        std::fprintf(stderr, "mi_sba_motstr_levmar: bad arguments (cnp must be 6 or 7, with distortion 8 or 9)\n");
         return MI_BA_ERROR;
     }
     std::vector<int> pt, cam;
@@ -26,7 +28,8 @@ int solve(int n, int m, int mcon, const char *vmask, double *p, int cnp, const d
             if (vmask[(size_t)i * m + j]) { pt.push_back(i); cam.push_back(j); }
     mi_ba_config cfg;
     mi_ba_default_config(&cfg);
-    cfg.est_focal = cnp == 7; cfg.explicit_centers = explicit_centers; cfg.mcon = mcon; cfg.proj_sign = -1.0;
+    cfg.est_focal = est_focal; cfg.explicit_centers = explicit_centers; cfg.mcon = mcon; cfg.proj_sign = -1.0;
+    cfg.undistort = undistort ? 1 : 0; cfg.nk = undistort ? 2 : 1;
     cfg.itmax = itmax; cfg.verbose = verbose; cfg.mode = mode;
     if (opts) std::memcpy(cfg.opts, opts, sizeof(cfg.opts));
     mi_ba_engine *e = mi_ba_create(&cfg);
@@ -60,19 +63,20 @@ int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *pro
                v3_t *pt_constraints, double pt_constraint_weight, int fix_points, int optimize_for_fisheye,
                double eps2, double *Vout, double *Sout, double *Uout, double *Wout, double info_out[10])
 {
-    if (const_focal_length || undistort || optimize_for_fisheye || Vout || Sout || Uout || Wout ||
+    if (const_focal_length || optimize_for_fisheye || Vout || Sout || Uout || Wout ||
         (use_point_constraints && (fix_points || !pt_constraints))) {
-        std::fprintf(stderr, "[run_sfm] this build supports est_focal_length / explicit_camera_centers / ncons / fix_points / "
-                             "use_constraints / use_point_constraints (no distortion, fisheye or Vout/Sout/Uout/Wout)\n");
+        std::fprintf(stderr, "[run_sfm] this build supports est_focal_length / undistort / explicit_camera_centers / ncons / fix_points / "
+                             "use_constraints / use_point_constraints (no fisheye, const_focal_length or Vout/Sout/Uout/Wout)\n");
         return MI_BA_ERROR;
     }
-    const int m = num_cameras, n = num_pts, cnp = est_focal_length ? 7 : 6;
-    const double f_scale = 0.001; // sfm.c:640 (TEST_FOCAL)
+    const int m = num_cameras, n = num_pts, cnp = (est_focal_length ? 7 : 6) + (undistort ? 2 : 0), kc = est_focal_length ? 7 : 6;
+    const double f_scale = 0.001, k_scale = 5.0; // sfm.c:640-641 (TEST_FOCAL)
     std::vector<double> p((size_t)m * cnp + 3 * (size_t)n), R0((size_t)m * 9), ff(m);
     for (int j = 0; j < m; ++j) {                                   // sfm.c:657-702
         for (int r = 0; r < 3; ++r) p[(size_t)j * cnp + r] = cams[j].t[r];
         for (int r = 3; r < 6; ++r) p[(size_t)j * cnp + r] = 0.0;
         if (est_focal_length) p[(size_t)j * cnp + 6] = cams[j].f * f_scale;
+        if (undistort) { p[(size_t)j * cnp + kc] = cams[j].k[0] * k_scale; p[(size_t)j * cnp + kc + 1] = cams[j].k[1] * k_scale; }   // :687-699
         std::memcpy(&R0[(size_t)j * 9], cams[j].R, 9 * sizeof(double));
         ff[j] = cams[j].f;
     }
@@ -87,7 +91,8 @@ int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *pro
             for (int r = 0; r < cnp; ++r) {
                 if (!cams[j].constrained[r]) continue;
                 double w = cams[j].weights[r], v = cams[j].constraints[r];
-                if (r == 6) { v *= f_scale; w *= 1.0 / (f_scale * f_scale); }                                        // :745-749
+                if (est_focal_length && r == 6) { v *= f_scale; w *= 1.0 / (f_scale * f_scale); }                  // :745-749
+                if (undistort && (r == 7 || r == 8)) { v *= k_scale; w *= 1.0 / (k_scale * k_scale); }             // :751-757 (entries 7, 8 as written there)
                 cw[(size_t)j * cnp + r] = w; cv[(size_t)j * cnp + r] = v;
             }
         cons.cam_w = cw.data(); cons.cam_v = cv.data();
@@ -104,7 +109,7 @@ int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *pro
     }
     double info[10] = { 0 };
     const int ret = solve(n, m, ncons, vmask, p.data(), cnp, projections, R0.data(), ff.data(), explicit_camera_centers,
-                          150 /* MAX_ITERS, sfm.c:820 */, 0, opts, info, fix_points ? 1 : 0 /* sba_mot_levmar, sfm.c:845-852 */, cons);
+                          150 /* MAX_ITERS, sfm.c:820 */, 0, opts, info, fix_points ? 1 : 0 /* sba_mot_levmar, sfm.c:845-852 */, cons, undistort);
     if (info_out) std::memcpy(info_out, info, sizeof(info));
     if (ret == MI_BA_ERROR) return ret;
     std::printf("[run_sfm] Number of iterations: %d\n", (int)info[5]);
@@ -130,6 +135,7 @@ int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *pro
             std::memcpy(cams[j].R, Rn, sizeof(Rn));
         }
         if (est_focal_length) cams[j].f = a[6] / f_scale;
+        if (undistort) { cams[j].k[0] = a[kc] / k_scale; cams[j].k[1] = a[kc + 1] / k_scale; }               // :911-920
     }
     for (int i = 0; i < n; ++i) for (int r = 0; r < 3; ++r) pts[i].p[r] = p[(size_t)m * cnp + 3 * (size_t)i + r];
     return ret;

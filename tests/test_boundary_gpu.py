@@ -53,9 +53,47 @@ def test_run_sfm_matches_the_references_run_sfm(name):
     assert np.abs(f - z["sfm_f"]).max() < 0.5 and np.abs(pts.reshape(n, 3) - z["sfm_pts"]).max() < 5e-3
     rm, rw = np.sqrt(info[1] / sc.nobs), np.sqrt(z["info_final"][1] / sc.nobs)
     assert abs(rm - rw) <= max(1e-3, 0.005 * rw)
-    # unsupported options are refused, not silently ignored
-    assert L.mi_run_sfm(n, m, 0, vmask.ctypes.data, x.ctypes.data, 1, 0, 1, 1, C.addressof(cams), pts.ctypes.data,
+    # unsupported options are refused, not silently ignored (const_focal_length: "not implemented" in the reference itself, sfm.c:394-397)
+    assert L.mi_run_sfm(n, m, 0, vmask.ctypes.data, x.ctypes.data, 1, 1, 0, 1, C.addressof(cams), pts.ctypes.data,
                         0, 0, None, 0.0, 0, 0, 1e-12, None, None, None, None, None) == -1
+    assert L.mi_run_sfm(n, m, 0, vmask.ctypes.data, x.ctypes.data, 1, 0, 0, 1, C.addressof(cams), pts.ctypes.data,
+                        0, 0, None, 0.0, 0, 1, 1e-12, None, None, None, None, None) == -1
+
+
+@pytest.mark.parametrize("est_focal", [1, 0])
+def test_run_sfm_with_both_radial_coefficients(est_focal):
+    """run_sfm(undistort = 1): k1 and k2 are parameters, 9 per camera with the focal length (8 without) -- against the REAL
+    reference's run_sfm and sba_motstr_levmar on the same seeded scene (tests/golden/ref_k2.npz, make_golden_k2.py)"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_k2.npz"))
+    tag = "f%d_" % est_focal
+    sc = pkg("scene").make_scene("x", m=14, n=900, d=5, seed=3, undistort=1, nk=2, est_focal=est_focal)
+    assert abs(np.abs(sc.x).sum() - float(z[tag + "xsum"])) < 1e-9 * float(z[tag + "xsum"]) and sc.cnp == 8 + est_focal
+    L = pkg("capi").lib()
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    a = sc.p0[:m * cnp].reshape(m, cnp)
+    cams = (CameraParams * m)()
+    for j in range(m):
+        cams[j].R[:] = list(sc.R0[j]); cams[j].t[:] = list(a[j, :3]); cams[j].f = a[j, 6] / 0.001 if est_focal else sc.f_fixed[j]
+        cams[j].k[:] = [0.0, 0.0]
+    pts = np.ascontiguousarray(sc.p0[m * cnp:]).copy()
+    vmask, x = _dense_inputs(sc)
+    info = np.zeros(10)
+    L.mi_run_sfm.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                             C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    ret = L.mi_run_sfm(n, m, 0, vmask.ctypes.data, x.ctypes.data, est_focal, 0, 1, sc.explicit_centers, C.addressof(cams),
+                       pts.ctypes.data, 0, 0, None, 0.0, 0, 0, 1e-12, None, None, None, None, info.ctypes.data)
+    want = z[tag + "info"]
+    assert ret == int(z[tag + "ret"]) and info[6] == want[6] and info[9] == want[9]
+    assert abs(info[0] - want[0]) < 1e-9 * want[0]
+    rm, rw = np.sqrt(info[1] / sc.nobs), np.sqrt(want[1] / sc.nobs)
+    assert abs(rm - rw) <= max(1e-3, 0.005 * rw) and abs(rm - rw) < 1e-5          # stated tolerance; measured
+    R = np.array([list(c.R) for c in cams]).reshape(m, 3, 3)
+    t = np.array([list(c.t) for c in cams]); f = np.array([c.f for c in cams]); k = np.array([list(c.k) for c in cams])
+    # no camera is held: the answers agree up to the gauge the two solvers drift in -- compare what the gauge leaves alone
+    assert np.abs(f - z[tag + "sfm_f"]).max() < (1.0 if est_focal else 1e-12)
+    assert np.abs(k - z[tag + "sfm_k"]).max() < 0.02
+    assert np.abs(R - z[tag + "sfm_R"]).max() < 1e-3 and np.abs(t - z[tag + "sfm_t"]).max() < 2e-2
 
 
 @pytest.mark.parametrize("name", ["C1", "C1t"])

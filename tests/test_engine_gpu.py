@@ -214,6 +214,44 @@ def test_radial_distortion_k1(oracle, est_focal):
     assert abs(eng.debug_linearize(mu)["cost"] - oracle.cost(sc, eng.packed_params())) < 1e-9 * info[1]
 
 
+@pytest.mark.parametrize("est_focal,mcon", [(0, 0), (1, 0), (1, 2)])
+def test_radial_distortion_k1_k2(oracle, est_focal, mcon):
+    """Bundler's full camera, run_sfm(undistort = 1): k1 AND k2 are parameters (sfm.c:360-373, 648-649).  Focal length held:
+    8 parameters, one 8 x 8 block per camera pair as ever; with the focal length NINE -- the engine keeps camera j as two
+    rows of its 8-wide camera-side arrays (parameters 0-7 | parameter 8), every point takes the row path, a 9 x 9 block of
+    S lands in four blocks of the virtual cameras.  The oracle's nine-parameter solve is itself pinned to the real sba
+    (test_oracle_golden.py::test_radial_models_match_the_reference[2])."""
+    sc = pkg("scene").make_scene("x", m=20, n=2000, d=5, seed=4, undistort=1, nk=2, est_focal=est_focal)
+    assert sc.cnp == 8 + est_focal
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, nk=2, mcon=mcon)
+    lin = oracle.linearize(sc, fd_jacobian=0, mcon=mcon)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    g = eng.debug_linearize(mu)
+    assert abs(g["cost"] - lin["cost"]) <= 1e-11 * lin["cost"]
+    assert rel(g["ea"][mcon:], lin["ea"][mcon:]) < 1e-10 and rel(g["eb"], lin["eb"]) < 1e-10
+    assert rel(g["diagU"][mcon:], np.einsum("jrr->jr", lin["U"])[mcon:]) < 1e-10
+    if mcon == 0:
+        S, E, Vinv = reduced_system(lin, sc, mu)
+        assert np.abs(g["S"] - S).max() < 1e-10 * np.abs(lin["U"]).max()
+        assert rel(g["E"].reshape(-1), E) < 1e-9
+        sol = eng.debug_solve(mu)
+        da = np.linalg.solve(S, E).reshape(sc.m, sc.cnp)
+        assert rel(sol["da"], da) < 1e-7
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0, mcon=mcon)
+    assert ret == o["ret"] and info[6] == o["info"][6] and info[9] == o["info"][9]
+    assert abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
+    assert np.allclose(eng.trace()[:, 3], o["trace"][:, 3], rtol=1e-7)
+    if mcon:
+        assert np.abs(eng.packed_params() - o["p"]).max() < 1e-6
+    a, _ = eng.params()
+    k1, k2 = a[mcon:, 6 + est_focal] / 5.0, a[mcon:, 7 + est_focal] / 5.0
+    assert abs(k1.mean() + 0.25) < 0.08 and abs(k2.mean() - 0.12) < 0.25      # the generator's coefficients (k2 is weakly observed)
+    assert abs(oracle.cost(sc, eng.packed_params()) - info[1]) < 1e-9 * info[1]
+    eng.set_params(*eng.params())                             # non-zero coefficients through the camera record
+    assert abs(eng.debug_linearize(mu)["cost"] - oracle.cost(sc, eng.packed_params())) < 1e-9 * info[1]
+
+
 def test_camera_links(oracle):
     """quadratic couplings between cameras (the engine side of ParallelBA::SetFocalMask): U gets diagonal and
     off-diagonal entries, the gradient and the cost the matching terms; checked against numpy on the oracle's blocks"""
