@@ -1627,8 +1627,13 @@ __global__ __launch_bounds__(256) void k_pcg_iter(const PcgArgs a)
     const double *__restrict__ rc = par ? a.r1 : a.r0, *__restrict__ wc = par ? a.w1 : a.w0, *__restrict__ so = par ? a.s1 : a.s0;
     // round 1
     const double st = a.scal[SC_PCG_STATUS], dn = a.scal[SC_PCG_DONE];
+    // the two dot products of the last launch, one partial per workgroup: with a wavefront per block row every wavefront adds
+    // them up itself; with a workgroup per row (as many partials as cameras) the first wavefront does and hands the totals to
+    // the other three through LDS -- four times fewer partial loads, which at 1 700 rows were as many bytes as a fifth of S~
+    __shared__ double sgd[2];
     double gs = 0.0, ds = 0.0;
-    for (int i = lane; i < a.nwg; i += 64) { gs += a.gp[(size_t)par * a.nwg + i]; ds += a.dp[(size_t)par * a.nwg + i]; }
+    if (ROWS == 4 || threadIdx.x < 64)
+        for (int i = lane; i < a.nwg; i += 64) { gs += a.gp[(size_t)par * a.nwg + i]; ds += a.dp[(size_t)par * a.nwg + i]; }
     const double g_prev = a.rz_hist[prev], g_zero = a.rz_hist[0], a_prev = a.alpha_hist[prev];
     const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
     const double r_own = rc[idx], w_own = wc[idx], s_own = so[idx], p_own = a.p[idx], x_own = a.x[idx];
@@ -1636,8 +1641,12 @@ __global__ __launch_bounds__(256) void k_pcg_iter(const PcgArgs a)
     // rounds 2 and 3
     const double *const vec[3] = { rc, wc, so };
     double S3[3];
+    if (ROWS != 4 && threadIdx.x < 64) {             // (the barrier inside workgroup_row_products<1> orders this against the reads below)
+        const double gsum = wave_sum(gs), dsum = wave_sum(ds);
+        if (lane == 0) { sgd[0] = gsum; sgd[1] = dsum; }
+    }
     const bool mine = workgroup_row_products<ROWS, 3>(a, q0, q1, vec, S3, red);
-    const double gamma = wave_sum(gs), delta = wave_sum(ds);
+    const double gamma = ROWS == 4 ? wave_sum(gs) : sgd[0], delta = ROWS == 4 ? wave_sum(ds) : sgd[1];
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (first) a.rz_hist[a.it] = gamma;
     const bool conv = a.it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < a.tol);
