@@ -19,6 +19,9 @@ constexpr double kEpsilonSq = 1E-12 * 1E-12; // SBA_EPSILON_SQ, sba_levmar.c:37-
 constexpr double kOneThird = 0.3333333334;   // SBA_ONE_THIRD, sba_levmar.c:40
 constexpr int kPcgChunk = 8;                 // PCG iterations launched between two host checks
 constexpr int kPcgRowPerWorkgroupMax = 512; // up to this many cameras a block row of S~ gets a whole workgroup (4 wavefronts), above: a wavefront
+constexpr int kTwoLevelMinCams = 400;       // the coarse space is considered from this many cameras on (fewer: the CG needs few iterations anyway)
+constexpr int kTwoLevelFrom = 12;           // ... and built from the first trial after a solve that took this many iterations (per trial it
+                                            // costs ~35 us: coarse matrix, its inverse, the band S~Z~)
 
 // Every public entry point runs with the engine's device current and puts the caller's back afterwards: buffers are allocated
 // and copied on "the current device" of the calling THREAD, which another engine, another library or another thread of the host
@@ -258,6 +261,39 @@ int Engine::prepare()
         std::vector<double2> xy(nol);
         for (int64_t o = 0; o < nol; ++o) { xy[o].x = h_xy_[2 * pl.obs_src[o]]; xy[o].y = h_xy_[2 * pl.obs_src[o] + 1]; }
         UP(d_obs_xy_, xy);
+    }
+    {   // two-level preconditioner: aggregates of consecutive block rows (whole workgroups of four), their coarse blocks, the band slots
+        co_ = CoarseArgs{};
+        co_on_ = co_active_ = false;
+        const char *ev = std::getenv("MI_BA_TWO_LEVEL");
+        co_force_ = ev ? std::atoi(ev) : 0;      // opt-in (fewer iterations, no faster on the bench scenes)
+        const int nwg4 = (mv_ + 3) / 4;
+        bool want = co_force_ != 0 && !split_ && cfg.mode != 2 && nwg4 >= 2 && (co_force_ == 1 || mv_ >= kTwoLevelMinCams);
+        if (want) {
+            const int wpa = (nwg4 + kCoarseMax - 1) / kCoarseMax, ng = (nwg4 + wpa - 1) / wpa, cpa = wpa * 4;
+            std::vector<int> bc((size_t)mv_ * kBcSlots, -1);
+            for (int j = 0; j < mv_ && want; ++j) {
+                int used = 0;
+                auto add = [&](int H) {
+                    for (int t = 0; t < used; ++t) if (bc[(size_t)j * kBcSlots + t] == H) return true;
+                    if (used == kBcSlots) return false;
+                    bc[(size_t)j * kBcSlots + used++] = H;
+                    return true;
+                };
+                for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1] && want; ++q) want = add(pl.bsr_col[q] / cpa);
+            }
+            if (want) {
+                UP(d_bc_agg_, bc);
+                const int nc = 8 * ng;
+                if (!hipok(d_Ac_.alloc((size_t)nc * nc), "alloc coarse matrix") || !hipok(d_Acinv_.alloc((size_t)nc * nc), "alloc coarse inverse") ||
+                    !hipok(d_Bc_.alloc((size_t)mv_ * kBcSlots * 64), "alloc coarse band") || !hipok(d_U_.alloc((size_t)mv_ * kBcSlots * 64), "alloc coarse row sums") || !hipok(d_Lfac_.alloc((size_t)mv_ * 64), "alloc L") ||
+                    !hipok(d_z_.alloc((size_t)mv_ * kCP), "alloc z") || !hipok(d_cpart_.alloc((size_t)2 * 3 * nwg4 * 8), "alloc coarse partials"))
+                    return MI_BA_ERROR;
+                co_.ng = ng; co_.nc = nc; co_.wg_per_agg = wpa;
+                co_.bc_agg = d_bc_agg_.p; co_.U = d_U_.p;
+                co_.Ac = d_Ac_.p; co_.Acinv = d_Acinv_.p; co_.Bc = d_Bc_.p; co_.Lfac = d_Lfac_.p; co_.z = d_z_.p; co_.cpart = d_cpart_.p;
+            }
+        }
     }
     UP(d_R0_, h_R0_); UP(d_ff_, h_ff_);
     {   // soft constraints: camera side always present (zeros = none), point side only when set
@@ -516,9 +552,13 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST,
                            cfg.world > 1 ? slots1_() + (size_t)cfg.rank * 8 : scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
+    // the coarse space is built from the first trial after a solve that needed many iterations, and then for the rest of the run
+    if (co_.ng && !co_on_ && (co_force_ == 1 || pcg_pred_ >= kTwoLevelFrom)) co_on_ = true;
+    co_active_ = co_.ng && co_on_;
     launch_finalize(st_, cnp_cam_(), mv_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
-                    d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag /* a linear phase on its own (begin, parity hooks) */, pcg_start());
+                    d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag /* a linear phase on its own (begin, parity hooks) */, pcg_start(),
+                    co_active_ ? co_ : CoarseArgs{}, d_bsr_row_.p);
     cg_start_fresh_ = true;
     return hipok(hipGetLastError(), "launch (linear phase)");
 }
@@ -550,10 +590,11 @@ PcgArgs Engine::pcg_args()
     // a block row of S~ gets a whole workgroup (four wavefronts share its blocks) when there are few rows.  (Measured with more
     // rows, MI_BA_PCG_ROW_WG=1: slower -- C3 0.27 -> 0.37 ms per solve, C4 (1 700 rows of ~240 blocks, S~ = 208 MB) 2.35 -> 2.62.)
     static const int force_row_wg = std::getenv("MI_BA_PCG_ROW_WG") ? std::atoi(std::getenv("MI_BA_PCG_ROW_WG")) : -1;
-    const bool row_wg = force_row_wg >= 0 ? force_row_wg != 0 : mv_ <= kPcgRowPerWorkgroupMax;
+    const bool row_wg = co_.ng ? false : force_row_wg >= 0 ? force_row_wg != 0 : mv_ <= kPcgRowPerWorkgroupMax;   // (the coarse space is laid out for four rows per workgroup)
     p.ng = (mv_ + 7) / 8; p.nwg = row_wg ? mv_ : (mv_ + 3) / 4;
     p.rz_hist = d_rzpq_.p; p.alpha_hist = p.rz_hist + (cfg.pcg_maxit + 4); p.gp = p.alpha_hist + (cfg.pcg_maxit + 4); p.dp = p.gp + 2 * (size_t)p.nwg;
     p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = mv_; p.it = 0;
+    if (co_active_) p.co = co_;
     return p;
 }
 
@@ -672,6 +713,7 @@ int Engine::begin()
     if (!prepared_) { err = "begin: prepare first"; return MI_BA_ERROR; }
     mu_ = 0; nu_ = 2; itno_ = 0; stop_ = 0; nfev_ = 1; njev_ = 0; nlss_ = 0; dp_L2_ = DBL_MAX; new_outer_ = true;
     pcg_pred_ = pcg_pred_prev_ = 0;      // a new solve: nothing to extrapolate from
+    co_on_ = false;
     spec_ready_ = spec_enqueued_ = false;
     trace.clear();
     // probe pass: cost at p0 and the largest diagonal entry of U, V -> mu0 = tau * max (sba_levmar.c:1124-1128)

@@ -99,6 +99,13 @@ private:
     // the next trial's linear phase enqueued before the host has seen this trial's outcome (solve_phase)
     bool speculate_ = true, spec_enqueued_ = false, spec_ready_ = false;
     PcgArgs upd_p_{};               // the solve k_cam_update ends (it, last, tail set by solve_phase)
+    // two-level preconditioner of the reduced solve (kernels.h CoarseArgs)
+    CoarseArgs co_{};               // ng == 0: this problem has none (few cameras, rows reaching too many aggregates, nine parameters)
+    bool co_on_ = false;            // switched on for the rest of this LM run (once a solve needed kTwoLevelFrom iterations)
+    bool co_active_ = false;        // the last linear phase built the coarse space: the next solve uses it
+    int co_force_ = 0;              // MI_BA_TWO_LEVEL: 0 off (default), 1 from the first trial, -1 once a solve ran long (>= kTwoLevelMinCams cameras)
+    DevBuf<int> d_bc_agg_;
+    DevBuf<double> d_Ac_, d_Acinv_, d_Bc_, d_U_, d_Lfac_, d_z_, d_cpart_;
     bool cg_start_fresh_ = false;   // the last linear phase's k_block_inv has set up the CG start and no solve has used it yet
     void *comm_ = nullptr; // ncclComm_t
     mi_ba_host_allreduce_fn host_ar_ = nullptr;   // test transport: the exchange through a host callback instead of RCCL

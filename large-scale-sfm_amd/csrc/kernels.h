@@ -130,6 +130,20 @@ struct SchurArgs {
 // where the CG starts: written by k_block_inv, which holds L^-1 of every camera's diagonal block anyway
 struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; };
 
+// Two-level preconditioner of the reduced solve: block-Jacobi (the scaling) + an additive coarse correction on aggregates of
+// consecutive cameras, M~^-1 = I + Z~ (Z'SZ)^-1 Z~', Z~ = L'Z -- applied INSIDE the one launch an iteration is (kernels.hip, k_pcg2_*).
+constexpr int kBcSlots = 4;     // aggregates a block row may reach (its own included); more -> the coarse space is not used
+constexpr int kCoarseMax = 16;  // aggregates at most: the coarse matrix (8 ng)^2 is inverted by one workgroup, in registers
+struct CoarseArgs {
+    int ng, nc, wg_per_agg;           // aggregates (0 = off), coarse unknowns = 8 ng, workgroups (4 block rows each) per aggregate
+    const int *bc_agg;                // [m][kBcSlots]: the aggregates row j's blocks reach, -1 = unused
+    double *Ac, *Acinv;               // Z'SZ and its inverse, nc x nc
+    double *U, *Bc;                   // per row and slot: U = sum of the row's blocks of S in that aggregate, Bc = L^-1 U (= S~ Z~): [m][kBcSlots][64]
+    double *Lfac;                     // L_j of S_jj = L_j L_j', [m][64]
+    double *z;                        // preconditioned residual, own rows only
+    double *cpart;                    // [2][3][nwg][8]: per workgroup the coarse projections Z~'(r | w | s) of its rows
+};
+
 struct PcgArgs {
     const int *bsr_row, *bsr_col;
     const double *S, *Linv, *E;                        // S = the scaled matrix S~ (k_scale_blocks)
@@ -140,6 +154,7 @@ struct PcgArgs {
     int tail;                                          // k_cam_update: do k_pcg_tail's work as well
     int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init); product kernels: nwg = m (one block row per
                                                        // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
+    CoarseArgs co;                                     // co.ng == 0: plain block-Jacobi
 };
 
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
@@ -150,7 +165,7 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg,
                      bool reduce_now /* false: the camera-side sums are taken by launch_reduce_final at the end of the trial */,
-                     const PcgStart &ps);
+                     const PcgStart &ps, const CoarseArgs &co /* co.ng != 0: also Z'SZ, its inverse, S~Z~ */, const int *bsr_row);
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);  // w_0 = S~ r_0 and the first partials (r_0: k_block_inv)
 void launch_pcg_reinit(hipStream_t st, const PcgArgs &a); // r_0, x~_0 again, for a second solve on the same linearisation
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one launch

@@ -1378,7 +1378,7 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
 // one wavefront per camera: the 64 lanes fetch the diagonal block's 64 finalised elements at once (one round of memory
 // latency instead of 36 dependent ones), lane 0 factors it from LDS and writes L^-1
 __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict__ bsr_diag, const FinalizeArgs f,
-                                                  double *__restrict__ Linv, double *__restrict__ scal, const PcgStart ps)
+                                                  double *__restrict__ Linv, double *__restrict__ scal, const PcgStart ps, double *__restrict__ Lfac)
 {
     __shared__ double sb[4][64], so[4][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv;
@@ -1416,6 +1416,7 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
     wave_lds_sync();
     if (live) {
         Linv[(size_t)j * 64 + lane] = so[wv][lane];
+        if (Lfac) Lfac[(size_t)j * 64 + lane] = c <= r ? sb[wv][lane] : 0.0;   // the factor itself, for the coarse space (k_pcg2_*)
         if (lane < 8) { // the start of the CG on the scaled system: r_0 = E~ = L^-1 E, x~_0 = 0 (this camera's rows)
             const double *Ej = ps.E + (size_t)j * 8;
             double rr = 0.0;
@@ -1588,6 +1589,319 @@ __global__ __launch_bounds__(256) void k_pcg_start(const PcgArgs a)
         g = rr * rr; d = w[0] * rr;
     }
     publish_partials(a, 0, g, d, sh);
+}
+
+// ------------------------------------------------------------------------------------------
+// Two-level preconditioner (kernels.h CoarseArgs): block-Jacobi -- the scaling S~ = L^-1 S L^-T -- plus an additive coarse
+// correction on ng aggregates of consecutive cameras (8 coarse unknowns each: the camera parameters summed over the aggregate),
+//   M~^-1 = I + Z~ Ac^-1 Z~',   Z~ = L' Z,   Ac = Z' S Z = sums of the unscaled blocks of S over pairs of aggregates.
+// The slow modes of the reduced system are smooth along the camera path (profiles/r02_pcg_two_level_proto.txt: 3-6x fewer
+// iterations once the damping is small).  It costs NO second grid-wide synchronisation per iteration: everything a launch
+// needs about the coarse space is linear in vectors the previous launch left behind -- c_{i+1} = Z~'r_{i+1} = cr - alpha (cw + beta cs)
+// from per-workgroup partial sums, y = Ac^-1 c by every workgroup for itself (nc <= 128), z = r + Z~ y on its own rows, and
+// S~ z = S~ r + (S~ Z~) y with the band S~ Z~ = L^-1 (S Z) formed once per trial.
+// Per trial: k_coarse_bc (per-row sums), k_coarse_assemble (fixed-order sums: the replicated solve must give the same bits on every rank), k_coarse_invert
+// (Gauss-Jordan by one workgroup, the matrix in registers), after k_coarse_bc's per-row sums.
+// ------------------------------------------------------------------------------------------
+// U_j[slot] = sum_{k in aggregate bc_agg[j][slot]} S_jk and Bc_j[slot] = L_j^-1 U_j[slot] (= (S~ Z~)_j restricted to that
+// aggregate), one wavefront per row, one pass over the row's blocks
+__global__ __launch_bounds__(256) void k_coarse_bc(int m, const int *__restrict__ bsr_row, const FinalizeArgs f, const double *__restrict__ Linv,
+                                                  const CoarseArgs co)
+{
+    __shared__ double sh[4][2][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7, j = blockIdx.x * 4 + wv;
+    if (j >= m) return;
+    const int cams_per_agg = co.wg_per_agg * 4;
+    sh[wv][1][lane] = Linv[(size_t)j * 64 + lane];
+    int H[kBcSlots];
+    double u[kBcSlots];
+#pragma unroll
+    for (int s = 0; s < kBcSlots; ++s) { H[s] = co.bc_agg[j * kBcSlots + s]; u[s] = 0.0; }
+    for (int q = bsr_row[j]; q < bsr_row[j + 1]; ++q) {
+        const int g = f.col[q] / cams_per_agg;
+        const double v = finalized_element(f, q, lane);
+#pragma unroll
+        for (int s = 0; s < kBcSlots; ++s) u[s] += g == H[s] ? v : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < kBcSlots; ++s) {
+        co.U[((size_t)j * kBcSlots + s) * 64 + lane] = u[s];
+        wave_lds_sync();
+        sh[wv][0][lane] = u[s];
+        wave_lds_sync();
+        double t = 0.0;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) t = fma(sh[wv][1][r * 8 + a], sh[wv][0][a * 8 + c], t);
+        co.Bc[((size_t)j * kBcSlots + s) * 64 + lane] = t;
+    }
+}
+
+// Ac[G][H] = sum over the rows j of aggregate G of U_j[slot of H], in a fixed order (the replicated solve must give the same
+// bits on every rank): one workgroup per coarse block, four wavefronts stride the rows, LDS sums them in order
+__global__ __launch_bounds__(256) void k_coarse_assemble(int m, const CoarseArgs co)
+{
+    __shared__ double part[4][64];
+    const int cb = blockIdx.x, G = cb / co.ng, Hc = cb - G * co.ng, wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+    const int cams_per_agg = co.wg_per_agg * 4, j0 = G * cams_per_agg, j1 = min(m, j0 + cams_per_agg);
+    double acc = 0.0;
+    for (int j = j0 + wv; j < j1; j += 4) {
+        const int4 hs = *reinterpret_cast<const int4 *>(co.bc_agg + (size_t)j * kBcSlots);
+        const int s = hs.x == Hc ? 0 : hs.y == Hc ? 1 : hs.z == Hc ? 2 : hs.w == Hc ? 3 : -1;
+        if (s >= 0) acc += co.U[((size_t)j * kBcSlots + s) * 64 + lane];
+    }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0) co.Ac[(size_t)(G * 8 + r) * co.nc + Hc * 8 + c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// Ac -> Ac^-1 (symmetric positive definite: Gauss-Jordan without pivoting), one workgroup, the matrix in registers (a 4x4
+// tile per thread), row k and column k of each step handed round through LDS; a pivot that is not positive switches the coarse
+// correction off for this trial (Acinv = 0: the iteration is then plain block-Jacobi CG)
+__global__ __launch_bounds__(1024) void k_coarse_invert(const CoarseArgs co)
+{
+    static_assert(kCoarseMax * 8 == 128, "the register tiling covers 128 x 128");
+    __shared__ double sRow[2][128], sCol[2][128];
+    const int n = co.nc, tid = threadIdx.x, i0 = (tid >> 5) * 4, j0 = (tid & 31) * 4;
+    double a[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int i = i0 + x, j = j0 + y;
+            a[x][y] = i < n && j < n ? 0.5 * (co.Ac[(size_t)i * n + j] + co.Ac[(size_t)j * n + i]) : 0.0;
+        }
+    bool fail = false;
+    for (int k = 0; k < n; ++k) {
+        const int b = k & 1, kr = k - i0, kc = k - j0;
+        if ((unsigned)kr < 4u) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (x == kr) {
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) sRow[b][j0 + y] = a[x][y];
+                }
+        }
+        if ((unsigned)kc < 4u) {
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                if (y == kc) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) sCol[b][i0 + x] = a[x][y];
+                }
+        }
+        __syncthreads();                                                  // (one barrier a step: the buffers alternate)
+        const double piv = sRow[b][k];
+        if (!(piv > 0.0) || !isfinite(piv)) { fail = true; break; }       // uniform: every thread reads the same pivot
+        const double ip = 1.0 / piv;
+        double rw[4], cl[4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) rw[y] = sRow[b][j0 + y];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) cl[x] = sCol[b][i0 + x] * ip;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                double v = fma(-cl[x], rw[y], a[x][y]);
+                if (x == kr) v = y == kc ? ip : rw[y] * ip;
+                else if (y == kc) v = -cl[x];
+                a[x][y] = v;
+            }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+            if (i0 + x < n && j0 + y < n) co.Acinv[(size_t)(i0 + x) * n + j0 + y] = fail ? 0.0 : a[x][y];
+}
+
+// The coarse part of one launch, by the whole workgroup: coarse projections of up to three vectors from the per-workgroup
+// partial sums (cpart[par]), combined as cr - alpha (cw + beta cs); y = Ac^-1 c for the aggregates this workgroup's rows reach
+// (its own and the band's: a handful of the ng), left in sY[aggregate * 8 + r].
+__device__ __forceinline__ void coarse_solve(const PcgArgs &a, int par, int nvec, double alpha, double beta, const double *E0,
+                                             double *sC /* [3][128] */, double *sY /* [128] */, int *sList /* [kCoarseMax + 1] */)
+{
+    const CoarseArgs &co = a.co;
+    const int tid = threadIdx.x, nc = co.nc;
+    if (E0) {   // the first residual: c_0 = aggregate sums of the unscaled right-hand side
+        for (int o = tid; o < nc; o += 256) {
+            const int G = o >> 3, rr = o & 7, j0 = G * co.wg_per_agg * 4, j1 = min(a.m, j0 + co.wg_per_agg * 4);
+            double s0 = 0.0, s1 = 0.0;
+            int k = j0;
+            for (; k + 1 < j1; k += 2) { s0 += E0[(size_t)k * 8 + rr]; s1 += E0[(size_t)(k + 1) * 8 + rr]; }
+            if (k < j1) s0 += E0[(size_t)k * 8 + rr];
+            sC[o] = s0 + s1;
+        }
+    } else {
+        const double *cp = co.cpart + (size_t)par * 3 * a.nwg * 8;
+        for (int o = tid; o < nvec * nc; o += 256) {
+            const int v = o / nc, idx = o - v * nc, G = idx >> 3, rr = idx & 7;
+            const int w0 = G * co.wg_per_agg, w1 = min(a.nwg, w0 + co.wg_per_agg);
+            double s0 = 0.0, s1 = 0.0;
+            int w = w0;
+            for (; w + 1 < w1; w += 2) { s0 += cp[((size_t)v * a.nwg + w) * 8 + rr]; s1 += cp[((size_t)v * a.nwg + w + 1) * 8 + rr]; }
+            if (w < w1) s0 += cp[((size_t)v * a.nwg + w) * 8 + rr];
+            sC[v * 128 + idx] = s0 + s1;
+        }
+    }
+    if (tid == 0) {   // the aggregates this workgroup needs y for: a short list (own first)
+        int n = 0;
+        const int *bc = co.bc_agg + (size_t)blockIdx.x * 4 * kBcSlots;
+        const int rows = min(4, a.m - (int)blockIdx.x * 4);
+        sList[1 + n++] = (int)blockIdx.x / co.wg_per_agg;
+        for (int t = 0; t < rows * kBcSlots; ++t) {
+            const int H = bc[t];
+            bool have = H < 0;
+            for (int u = 0; u < n && !have; ++u) have = sList[1 + u] == H;
+            if (!have) sList[1 + n++] = H;
+        }
+        sList[0] = n;
+    }
+    __syncthreads();
+    if (!E0 && tid < nc) {
+        const double cn = nvec == 3 ? sC[tid] - alpha * (sC[128 + tid] + beta * sC[256 + tid]) : sC[tid];
+        sC[tid] = cn;                                        // (only thread tid reads sC[.][tid] here)
+    }
+    __syncthreads();
+    // y_o = sum_k Acinv[o][k] c_k for the listed aggregates: 8 lanes per output (k = part, part + 8, ...: independent loads), 32 outputs a pass
+    const int nout = sList[0] * 8, part = tid & 7;
+    for (int oi = tid >> 3; oi < ((nout + 31) & ~31); oi += 32) {    // (uniform trip count: the DPP sums below need whole rows of lanes)
+        const bool on = oi < nout;
+        const int o = on ? sList[1 + (oi >> 3)] * 8 + (oi & 7) : 0;
+        double acc = 0.0;
+        if (on)
+            for (int k = part; k < nc; k += 8) acc = fma(co.Acinv[(size_t)k * nc + o], sC[k], acc);   // symmetric: column o instead of row o
+        acc += dpp_move<0xB1>(acc); acc += dpp_move<0x4E>(acc); acc += dpp_move<0x141>(acc);
+        if (on && part == 0) sY[o] = acc;
+    }
+    __syncthreads();
+}
+
+// per block row: z_j = r_j + L_j' y_G, the band term (S~ Z~)_j y, and the coarse projections L_j (r | w | s)_j of the new vectors;
+// lane (rr, cc), values of the 8 new components live in sV[wave][vec][8]
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_pcg2_start(const PcgArgs a)
+{
+    __shared__ double sh[4][2], red[4][1][8], sC[3 * 128], sY[128], sV[4][3][8], sP[4][3][8];
+    __shared__ int sList[kCoarseMax + 1];
+    const CoarseArgs &co = a.co;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv, r = lane >> 3, c = lane & 7;
+    const bool live = j < a.m;
+    const int jj = live ? j : 0;
+    const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
+    // c_0 = Z~' r_0 = aggregate sums of the unscaled right-hand side E (r_0 = L^-1 E): straight from E, every workgroup for itself
+    coarse_solve(a, 0, 1, 0.0, 0.0, a.E, sC, sY, sList);
+    const double *const vec[1] = { a.r0 };
+    double w[1];
+    (void)workgroup_row_products<4, 1>(a, q0, q1, vec, w, red);      // (S~ r_0)_j[r] in every lane of row r
+    const int G = blockIdx.x / co.wg_per_agg;
+    const double *Lj = co.Lfac + (size_t)jj * 64;
+    // z = r + L' y_G ; band term
+    double zt = Lj[c * 8 + r] * sY[G * 8 + c];
+    double bt = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBcSlots; ++sl) {
+        const int H = co.bc_agg[jj * kBcSlots + sl];
+        if (H >= 0) bt = fma(co.Bc[((size_t)jj * kBcSlots + sl) * 64 + lane], sY[H * 8 + c], bt);
+    }
+    zt += dpp_move<0xB1>(zt); zt += dpp_move<0x4E>(zt); zt += dpp_move<0x141>(zt);
+    bt += dpp_move<0xB1>(bt); bt += dpp_move<0x4E>(bt); bt += dpp_move<0x141>(bt);
+    double g = 0.0, d = 0.0;
+    const double rr = live ? a.r0[jj * 8 + r] : 0.0;
+    const double z_new = rr + zt, w_new = w[0] + bt;
+    if (c == 0) { sV[wv][0][r] = live ? rr : 0.0; sV[wv][1][r] = live ? w_new : 0.0; sV[wv][2][r] = 0.0; }
+    if (live && c == 0) {
+        a.w0[j * 8 + r] = w_new; co.z[j * 8 + r] = z_new;
+        g = rr * z_new; d = w_new * z_new;
+    }
+    wave_lds_sync();
+    // coarse projections of the new r, w (s = 0) for the first iteration: (L_j v)_r, then summed over the workgroup's rows
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        double t = live ? Lj[r * 8 + c] * sV[wv][v][c] : 0.0;
+        t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t); t += dpp_move<0x141>(t);
+        if (c == 0) sP[wv][v][r] = t;
+    }
+    publish_partials(a, 0, g, d, sh);                                 // (its barrier orders sP)
+    if (threadIdx.x < 24) {
+        const int v = threadIdx.x >> 3, rr8 = threadIdx.x & 7;
+        co.cpart[((size_t)0 * 3 + v) * a.nwg * 8 + (size_t)blockIdx.x * 8 + rr8] = (sP[0][v][rr8] + sP[1][v][rr8]) + (sP[2][v][rr8] + sP[3][v][rr8]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pcg2_iter(const PcgArgs a)
+{
+    __shared__ double sh[4][2], red[4][3][8], sC[3 * 128], sY[128], sV[4][3][8], sP[4][3][8];
+    __shared__ int sList[kCoarseMax + 1];
+    const CoarseArgs &co = a.co;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv, r = lane >> 3, c = lane & 7;
+    const int par = a.it & 1, prev = a.it ? a.it - 1 : 0;
+    const bool live = j < a.m;
+    const int jj = live ? j : 0, idx = jj * 8 + r;
+    const double *__restrict__ rc = par ? a.r1 : a.r0, *__restrict__ wc = par ? a.w1 : a.w0, *__restrict__ so = par ? a.s1 : a.s0;
+    const double st = a.scal[SC_PCG_STATUS], dn = a.scal[SC_PCG_DONE];
+    double gs = 0.0, ds = 0.0;
+    for (int i = lane; i < a.nwg; i += 64) { gs += a.gp[(size_t)par * a.nwg + i]; ds += a.dp[(size_t)par * a.nwg + i]; }
+    const double g_prev = a.rz_hist[prev], g_zero = a.rz_hist[0], a_prev = a.alpha_hist[prev];
+    const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
+    const double r_own = rc[idx], w_own = wc[idx], s_own = so[idx], p_own = a.p[idx], x_own = a.x[idx], z_own = co.z[idx];
+    if (st != 0.0 || dn != 0.0) return;
+    const double *const vec[3] = { rc, wc, so };
+    double S3[3];
+    (void)workgroup_row_products<4, 3>(a, q0, q1, vec, S3, red);
+    const double gamma = wave_sum(gs), delta = wave_sum(ds);           // gamma = r.z, delta = w.z (w = S~ z)
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0;
+    if (first) a.rz_hist[a.it] = gamma;
+    const bool conv = a.it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < a.tol);
+    if (conv) {
+        if (first) a.scal[SC_PCG_DONE] = 1.0;
+        return;
+    }
+    const double beta = a.it ? gamma / g_prev : 0.0;
+    const double den = a.it ? delta - beta * gamma / a_prev : delta;
+    if (!(den > 0.0) || !isfinite(den)) {
+        if (first) a.scal[SC_PCG_STATUS] = 2.0;
+        return;
+    }
+    const double alpha = gamma / den;
+    // the coarse state of the NEXT residual, from what the last launch left: y = Ac^-1 (cr - alpha (cw + beta cs))
+    coarse_solve(a, par, 3, alpha, beta, nullptr, sC, sY, sList);
+    const int G = blockIdx.x / co.wg_per_agg;
+    const double *Lj = co.Lfac + (size_t)jj * 64;
+    double zt = Lj[c * 8 + r] * sY[G * 8 + c];
+    double bt = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < kBcSlots; ++sl) {
+        const int H = co.bc_agg[jj * kBcSlots + sl];
+        if (H >= 0) bt = fma(co.Bc[((size_t)jj * kBcSlots + sl) * 64 + lane], sY[H * 8 + c], bt);
+    }
+    zt += dpp_move<0xB1>(zt); zt += dpp_move<0x4E>(zt); zt += dpp_move<0x141>(zt);
+    bt += dpp_move<0xB1>(bt); bt += dpp_move<0x4E>(bt); bt += dpp_move<0x141>(bt);
+    double *rn = par ? a.r0 : a.r1, *wn = par ? a.w0 : a.w1, *sn = par ? a.s0 : a.s1;
+    const double s_new = fma(beta, s_own, w_own), r_new = fma(-alpha, s_new, r_own), p_new = fma(beta, p_own, z_own);
+    const double z_new = r_new + zt;
+    const double w_new = fma(-alpha, fma(beta, S3[2], S3[1]), S3[0]) + bt;
+    double g = 0.0, d = 0.0;
+    if (c == 0) { sV[wv][0][r] = live ? r_new : 0.0; sV[wv][1][r] = live ? w_new : 0.0; sV[wv][2][r] = live ? s_new : 0.0; }
+    if (live && c == 0) {
+        sn[idx] = s_new; rn[idx] = r_new; wn[idx] = w_new; co.z[idx] = z_new;
+        a.p[idx] = p_new;
+        a.x[idx] = fma(alpha, p_new, x_own);
+        g = r_new * z_new; d = w_new * z_new;
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        double t = live ? Lj[r * 8 + c] * sV[wv][v][c] : 0.0;
+        t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t); t += dpp_move<0x141>(t);
+        if (c == 0) sP[wv][v][r] = t;
+    }
+    publish_partials(a, par ^ 1, g, d, sh);
+    if (threadIdx.x < 24) {
+        const int v = threadIdx.x >> 3, rr8 = threadIdx.x & 7;
+        co.cpart[((size_t)(par ^ 1) * 3 + v) * a.nwg * 8 + (size_t)blockIdx.x * 8 + rr8] = (sP[0][v][rr8] + sP[1][v][rr8]) + (sP[2][v][rr8] + sP[3][v][rr8]);
+    }
+    if (first) { a.alpha_hist[a.it] = alpha; a.scal[SC_PCG_ITERS] = (double)(a.it + 1); }
 }
 
 // rz_hist[it] = gamma_it, the sticky converged flag, and SC_PCG_FINAL when the solve is over (converged, broken down, or
@@ -1907,7 +2221,8 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const double *spec, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
-                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg, bool reduce_now, const PcgStart &ps)
+                     double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg, bool reduce_now, const PcgStart &ps,
+                     const CoarseArgs &co, const int *bsr_row)
 {
     FinalizeArgs f;
     f.cnp = cnp; f.mu = mu; f.spec = spec; f.fixed = fixed; f.pfix = pfix; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
@@ -1917,20 +2232,27 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, pfix, camvec, cam_a, cam_cw, cam_cv,
                        links, E, cam_part);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
-    hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps);
+    hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
     hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg);
+    if (co.ng) {   // the coarse space of this trial's system: Z'SZ, its inverse, S~Z~
+        hipLaunchKernelGGL(k_coarse_bc, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_row, f, Linv, co);
+        hipLaunchKernelGGL(k_coarse_assemble, dim3(co.ng * co.ng), dim3(256), 0, st, m, co);
+        hipLaunchKernelGGL(k_coarse_invert, dim3(1), dim3(1024), 0, st, co);
+    }
 }
 
 void launch_pcg_reinit(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_init, dim3(a.ng), dim3(64), 0, st, a); }
 
 void launch_pcg_init(hipStream_t st, const PcgArgs &a)
 {
+    if (a.co.ng) { hipLaunchKernelGGL(k_pcg2_start<4>, dim3(a.nwg), dim3(256), 0, st, a); return; }
     if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_start<1>, dim3(a.nwg), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_pcg_start<4>, dim3(a.nwg), dim3(256), 0, st, a);
 }
 
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
 {
+    if (a.co.ng) { hipLaunchKernelGGL(k_pcg2_iter, dim3(a.nwg), dim3(256), 0, st, a); return; }
     if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_iter<1>, dim3(a.nwg), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_pcg_iter<4>, dim3(a.nwg), dim3(256), 0, st, a);
 }

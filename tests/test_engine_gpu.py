@@ -122,6 +122,29 @@ def test_tight_pcg_reproduces_oracle_trajectory(oracle):
     assert abs(info[4] - o["info"][4]) < 1e-6 * o["info"][4]
 
 
+@pytest.mark.parametrize("two_level", ["1", "-1"])
+def test_two_level_preconditioner_same_trajectory_fewer_iterations(oracle, monkeypatch, two_level):
+    """MI_BA_TWO_LEVEL (opt-in): block-Jacobi + an additive coarse space on aggregates of cameras inside the one-launch CG
+    iteration.  A preconditioner changes the path of the reduced solve, not its answer: with a tight CG tolerance the LM
+    trajectory is the oracle's, in fewer CG iterations than the plain run takes.  (-1 = switch it on only once a solve ran
+    long: needs >= 400 cameras, so on this scene it stays off and the iteration counts are equal.)"""
+    sc = pkg("scene").make_scene("x", m=240, n=6000, d=6, seed=77, strides=(1,))    # a band: every row reaches <= 4 aggregates
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    its = {}
+    for tl in ("0", two_level):
+        monkeypatch.setenv("MI_BA_TWO_LEVEL", tl)
+        eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+        ret, info = eng.run()
+        # (a long weak chain of cameras: where the rounding-level tail of the run stops moves the cost in the 7th digit)
+        assert abs(info[1] - o["info"][1]) < 1e-6 * o["info"][1]
+        assert abs(oracle.cost(sc, eng.packed_params()) - info[1]) < 1e-9 * info[1]
+        its[tl] = eng.timing()["pcg_iters"]
+    if two_level == "1":
+        assert its["1"] < its["0"]
+    else:
+        assert its["-1"] == its["0"]
+
+
 def test_fixed_cameras(oracle):
     sc, z = scene_from_golden("C1")
     eng = make_engine(sc, mcon=2)
