@@ -485,7 +485,12 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
     // registers; sStage only transposes them (kStageLanes lanes at a time) into the contiguous 49-double
     // shape a global f64 atomic wants.
     constexpr int kStageLanes = 5;
-    __shared__ double sStage[(TABLE || !LDS) ? 1 : kStageLanes * BLK], sC[LDS ? kNCSlot * SC : 1];
+    // sC: the camera slots' sums; a tile with <= kCamLds cameras (one camera set: the common case) also keeps its cameras' 192-B
+    // records behind them, fetched once per tile in coalesced pieces instead of one divergent gather per observation and batch
+    constexpr int kCamLds = 12;
+    constexpr int SCN = LDS ? (kNCSlot * SC > kCamLds * (SC + kCamLin) ? kNCSlot * SC : kCamLds * (SC + kCamLin)) : 2;
+    __shared__ double sStage[(TABLE || !LDS) ? 1 : kStageLanes * BLK];
+    __shared__ __attribute__((aligned(16))) double sC[SCN];
     __shared__ double sTab[TABLE ? kNSlot * BLK : 1];
     __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
 
@@ -498,6 +503,18 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
         ncs = g.tile_cslot[tile + 1] - g.tile_cslot[tile];
         for (int i = lane; i < ncs * SC; i += kWave) sC[i] = 0.0;
         if constexpr (TABLE) for (int i = lane; i < nslots * BLK; i += kWave) sTab[i] = 0.0;
+    }
+    const bool cam_in_lds = LDS && ncs <= kCamLds;
+    double *const sCam = sC + ((kCamLds * SC + 1) & ~1);
+    static_assert(!LDS || ((kCamLds * SC + 1) & ~1) + kCamLds * kCamLin <= SCN + 1, "camera records fit behind the sums");
+    if constexpr (LDS) {
+        if (cam_in_lds) {
+            for (int i = lane; i < ncs * (kCamLin / 2); i += kWave) {
+                const int c = i / (kCamLin / 2), piece = i - c * (kCamLin / 2);
+                const int cam = g.cslot_cam[g.tile_cslot[tile] + c];
+                reinterpret_cast<double2 *>(sCam)[i] = reinterpret_cast<const double2 *>(g.cam_lin + (size_t)cam * kCamLin)[piece];
+            }
+        }
     }
     double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0, ccost = 0.0;
     // register-resident accumulator (LDS tiles): this lane's S block follows the lane for as long as its
@@ -557,8 +574,11 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
     load_batch_level1<LDS>(g, td, 0, lane, cur);
     X[0] = g.pts[3 * (size_t)cur.ip]; X[1] = g.pts[3 * (size_t)cur.ip + 1]; X[2] = g.pts[3 * (size_t)cur.ip + 2];
     nxt = cur;
+    if constexpr (LDS) wave_lds_sync();   // the camera records are in place
     STAMP(0); // prologue: LDS clear, first batch loads issued
 
+    unsigned ent_r[LDS ? kMaxRounds : 1];
+    long long ent_q0 = -1, ent_q1 = -1;
     for (int b = b_begin; b < b_end; ++b) {
         const bool have_next = b + 1 < b_end;
         const int nob = cur.nob, p0 = cur.p0, npt = cur.npt;
@@ -570,7 +590,11 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
         // ---- phase 1 (camera records are L2-resident, 192 B x m)
         {
             double cl[kCamLin];
-            load_cam_record(g, j, cl);
+            if (cam_in_lds) {
+                const double2 *src = reinterpret_cast<const double2 *>(sCam + cs * kCamLin);
+#pragma unroll
+                for (int k = 0; k < kCamLin / 2; ++k) { const double2 v = src[k]; cl[2 * k] = v.x; cl[2 * k + 1] = v.y; }
+            } else load_cam_record(g, j, cl);
             if (have_next) load_batch_level1<LDS>(g, td, b + 1 - b_begin, lane, nxt);   // streams + pair entries of the next batch
             STAMP(7);
             if (active) {
@@ -657,13 +681,15 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
         // ---- phase 4: camera-side vectors ea_j, E_j = A^T (e - B h)  (+ diag U_j on request).
         // The pair entries of this batch are requested first; phase 4 and the other wavefront of the SIMD
         // cover their latency.
-        unsigned ent_r[LDS ? kMaxRounds : 1];
         int my_rec = 0;
         if constexpr (LDS) {
+            if (cur.q0 != ent_q0 || cur.q1 != ent_q1) {   // (uniform) consecutive batches of one camera set share their entries (plan.h: pair templates)
 #pragma unroll
-            for (int t = 0; t < kMaxRounds; ++t) {
-                const long long q = cur.q0 + (long long)t * kWave + lane;
-                ent_r[t] = (q < cur.q1) ? g.pair[q] : kPairInvalid;
+                for (int t = 0; t < kMaxRounds; ++t) {
+                    const long long q = cur.q0 + (long long)t * kWave + lane;
+                    ent_r[t] = (q < cur.q1) ? g.pair[q] : kPairInvalid;
+                }
+                ent_q0 = cur.q0; ent_q1 = cur.q1;
             }
         } else if (active) my_rec = g.obs_rec[cur.o0 + lane];
         double er[2] = { 0.0, 0.0 };
