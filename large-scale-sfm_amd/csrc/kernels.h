@@ -154,6 +154,7 @@ struct PcgArgs {
     int tail;                                          // k_cam_update: do k_pcg_tail's work as well
     int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init); product kernels: nwg = m (one block row per
                                                        // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
+    int wpr;                                           // nwg = ceil(m / 4): wavefronts per block row, 1 or 2 (long rows)
     CoarseArgs co;                                     // co.ng == 0: plain block-Jacobi
 };
 

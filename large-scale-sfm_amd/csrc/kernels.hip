@@ -493,6 +493,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
     __shared__ __attribute__((aligned(16))) double sC[SCN];
     __shared__ double sTab[TABLE ? kNSlot * BLK : 1];
     __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
+    __shared__ int sFix[LDS ? kNCSlot : 1];   // per camera slot: the camera is held fixed
 
     const int lane = threadIdx.x;
     const int tile = g.tile0 + blockIdx.x;
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
     if constexpr (LDS) {
         my_gblk = lane < nslots ? g.slot_gblk[g.tile_slot[tile] + lane] : 0;
         my_cam = lane < ncs ? g.cslot_cam[g.tile_cslot[tile] + lane] : 0;
+        if (lane < ncs) sFix[lane] = g.cam_fixed[my_cam];
     }
     // wave-collective: every lane hands its register-resident block to HBM.  kStageLanes blocks at a time go
     // through sStage so that ONE global f64 atomic instruction adds ONE contiguous 7x7 block (the full-rate
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
         const bool active = lane < nob;
         double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
         const int j = cur.j, lp = cur.ip - p0, cs = cur.cs;
-        bool head = false;
+        bool head = false, cam_is_fixed = false;
         double pcw = 0.0, pcd[3] = { 0.0, 0.0, 0.0 };
         // ---- phase 1 (camera records are L2-resident, 192 B x m)
         {
@@ -598,7 +600,8 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
             if (have_next) load_batch_level1<LDS>(g, td, b + 1 - b_begin, lane, nxt);   // streams + pair entries of the next batch
             STAMP(7);
             if (active) {
-                linearize_obs<CNP, FULL>(cfg, cl, X, cur.xy, g.cam_fixed[j] != 0, e, A, B);
+                if constexpr (LDS) cam_is_fixed = sFix[cs] != 0; else cam_is_fixed = g.cam_fixed[j] != 0;
+                linearize_obs<CNP, FULL>(cfg, cl, X, cur.xy, cam_is_fixed, e, A, B);
                 cost += e[0] * e[0] + e[1] * e[1];
                 double *row = sR + lane * SR;
 #pragma unroll
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
             }
         } else if (active) my_rec = g.obs_rec[cur.o0 + lane];
         double er[2] = { 0.0, 0.0 };
-        if (active && (!LDS || !g.cam_fixed[j])) {
+        if (active && (!LDS || !cam_is_fixed)) {
             const double *sv = sV + lp * SV;
 #pragma unroll
             for (int r = 0; r < 2; ++r) er[r] = e[r] - (B[r][0] * sv[6] + B[r][1] * sv[7] + B[r][2] * sv[8]);
@@ -1522,6 +1525,7 @@ __global__ __launch_bounds__(64) void k_pcg_init(const PcgArgs a)
 }
 
 // the workgroup's two dot-product partials: four wavefronts, fixed order
+template <int NW = 4>
 __device__ __forceinline__ void publish_partials(const PcgArgs &a, int slot, double g, double d, double (*sh)[2])
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1529,92 +1533,112 @@ __device__ __forceinline__ void publish_partials(const PcgArgs &a, int slot, dou
     if (lane == 0) { sh[wv][0] = g; sh[wv][1] = d; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a.gp[(size_t)slot * a.nwg + blockIdx.x] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
-        a.dp[(size_t)slot * a.nwg + blockIdx.x] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+        double gt = 0.0, dt = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; w += 4) { gt += (sh[w][0] + sh[w + 1][0]) + (sh[w + 2][0] + sh[w + 3][0]); dt += (sh[w][1] + sh[w + 1][1]) + (sh[w + 2][1] + sh[w + 3][1]); }
+        a.gp[(size_t)slot * a.nwg + blockIdx.x] = gt;
+        a.dp[(size_t)slot * a.nwg + blockIdx.x] = dt;
     }
 }
 
-// products of a block row with NV vectors in one pass over its blocks q = qb, qb + stride, ... < qe: lane (r,c) multiplies
-// element (r,c) of each 8x8 block (a 512-B contiguous wave load) with element c of the neighbour's vectors; eight
-// independent block loads in flight (with one at a time the MALL-resident S streams at only ~3 TB/s, and a wavefront that
-// waits out a round of memory latency per four blocks spends most of a launch waiting); the sum over c by three
-// DPP moves leaves row r's value in all 8 lanes of the row
+// products of a block row with NV vectors in one pass over its blocks q = qb, qb + stride, ... < qe.  One wave load = 16 B per
+// lane = TWO 8x8 blocks (1 KB contiguous when stride = 1): the lower half-wave takes the even blocks of the row, the upper the
+// odd ones; lane (r, c2) of a half multiplies elements (r, c2) and (r, c2 + 1) with the neighbour's vector elements c2, c2 + 1
+// (one 16-B load).  Eight loads = 8 KB per wavefront in flight: a launch has only ~m wavefronts, and the bytes in flight set
+// the rate at which a matrix that lives in the Infinity Cache or HBM streams (8-B loads, 4 KB in flight: 3.2 TB/s on C4's
+// 208 MB).  The sum over the four lanes of a row by two DPP moves, the two halves by a cross-half read; the result is left
+// where the callers expect it: row r's value in all lanes 8r .. 8r + 7.
 template <int NV>
 __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, int stride, int lane, const double *const (&vec)[NV], double (&out)[NV])
 {
-    const int c = lane & 7;
+    const int half = lane >> 5, c2 = (lane & 3) * 2, el = ((lane & 31) >> 2) * 8 + c2;
     const double *__restrict__ Sv = a.S;
-    double acc[NV][4];
+    double acc[NV][2];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = acc[v][2] = acc[v][3] = 0.0;
-    int q = qb;
-    for (; q + 7 * stride < qe; q += 8 * stride) {
+    for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = 0.0;
+    int q = qb + half * stride;                       // this half's first block; then every second block of the row
+    const int st2 = 2 * stride;
+    for (; q + 7 * st2 < qe; q += 8 * st2) {          // (the halves may leave the loop one trip apart: nothing wave-wide inside)
         int k[8];
-        double sv[8];
+        double2 sv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { k[u] = a.bsr_col[q + u * stride] * 8 + c; sv[u] = Sv[(size_t)(q + u * stride) * 64 + lane]; }
+        for (int u = 0; u < 8; ++u) {
+            k[u] = a.bsr_col[q + u * st2] * 8 + c2;
+            sv[u] = *reinterpret_cast<const double2 *>(Sv + (size_t)(q + u * st2) * 64 + el);
+        }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            double x[8];
+            double2 x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = vec[v][k[u]];
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const double2 *>(vec[v] + k[u]);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[v][u & 3] = fma(sv[u], x[u], acc[v][u & 3]);
+            for (int u = 0; u < 8; ++u) acc[v][u & 1] = fma(sv[u].y, x[u].y, fma(sv[u].x, x[u].x, acc[v][u & 1]));
         }
     }
-    for (; q < qe; q += stride) {
-        const int k = a.bsr_col[q] * 8 + c;
-        const double sv = Sv[(size_t)q * 64 + lane];
+    for (; q < qe; q += st2) {
+        const int k = a.bsr_col[q] * 8 + c2;
+        const double2 sv = *reinterpret_cast<const double2 *>(Sv + (size_t)q * 64 + el);
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v][0] = fma(sv, vec[v][k], acc[v][0]);
+        for (int v = 0; v < NV; ++v) {
+            const double2 x = *reinterpret_cast<const double2 *>(vec[v] + k);
+            acc[v][0] = fma(sv.y, x.y, fma(sv.x, x.x, acc[v][0]));
+        }
     }
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        double t = (acc[v][0] + acc[v][1]) + (acc[v][2] + acc[v][3]);
-        t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t); t += dpp_move<0x141>(t);   // the 8 lanes of a row: quad permutes, half-row mirror
-        out[v] = t;
+        double t = acc[v][0] + acc[v][1];
+        t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t);          // the 4 lanes of a row (quad permutes)
+        t += __shfl_xor(t, 32);                                   // even + odd blocks
+        out[v] = __shfl(t, (lane >> 3) * 4);                      // row r: from lanes 4r .. 4r + 3 to lanes 8r .. 8r + 7
     }
 }
 
-// ROWS = 4: one wavefront per block row, four rows per workgroup.  ROWS = 1 (few cameras: fewer block rows than the chip
-// has CUs): the four wavefronts of a workgroup share one row, block q to wavefront q mod 4, and add up through LDS in a
-// fixed order -- the result is in wavefront 0.  Returns whether this wavefront holds a row's finished products.
-template <int ROWS, int NV>
+// ROWS = 4: four block rows per workgroup, WPR wavefronts each: 2 while the rows are short (C3, 37 blocks a row: the launch is
+// rounds of latency, and half a row per wavefront shortens the longest one: 0.31 -> 0.25 ms per solve; four: no better), 1 for long
+// rows (C4, 239 blocks a row: bound by the rate the 208 MB stream in; two: 2.68 -> 2.90 ms).  ROWS = 1 (few cameras: fewer block rows than the chip has CUs): the four
+// wavefronts of a workgroup share one row.  Wavefronts that share a row take its blocks in turn and add up through LDS in a
+// fixed order -- the result is in the row's first wavefront.  Returns whether this wavefront holds a row's finished products.
+template <int ROWS, int NV, int WPR = 1>
 __device__ __forceinline__ bool workgroup_row_products(const PcgArgs &a, int q0, int q1, const double *const (&vec)[NV], double (&out)[NV], double (*red)[NV][8])
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (ROWS == 4) { row_products<NV>(a, q0, q1, 1, lane, vec, out); return true; }
-    row_products<NV>(a, q0 + wv, q1, 4, lane, vec, out);
+    if (ROWS == 4 && WPR == 1) { row_products<NV>(a, q0, q1, 1, lane, vec, out); return true; }
+    constexpr int SH = ROWS == 4 ? WPR : 4;         // wavefronts per row
+    const int part = wv % SH, first = wv - part;
+    row_products<NV>(a, q0 + part, q1, SH, lane, vec, out);
     if ((lane & 7) == 0) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) red[wv][v][lane >> 3] = out[v];
     }
     __syncthreads();
 #pragma unroll
-    for (int v = 0; v < NV; ++v) out[v] = (red[0][v][lane >> 3] + red[1][v][lane >> 3]) + (red[2][v][lane >> 3] + red[3][v][lane >> 3]);
-    return wv == 0;
+    for (int v = 0; v < NV; ++v) {
+        if constexpr (SH == 2) out[v] = red[first][v][lane >> 3] + red[first + 1][v][lane >> 3];
+        else out[v] = (red[first][v][lane >> 3] + red[first + 1][v][lane >> 3]) + (red[first + 2][v][lane >> 3] + red[first + 3][v][lane >> 3]);
+    }
+    return part == 0;
 }
 
 // w_0 = S~ r_0 and the partials of gamma_0, delta_0
-template <int ROWS>
-__global__ __launch_bounds__(256) void k_pcg_start(const PcgArgs a)
+template <int ROWS, int WPR = 1>
+__global__ __launch_bounds__(256 * WPR) void k_pcg_start(const PcgArgs a)
 {
-    __shared__ double sh[4][2];
-    __shared__ double red[4][1][8];
-    const int lane = threadIdx.x & 63, j = ROWS == 4 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x, r = lane >> 3, c = lane & 7;
+    __shared__ double sh[4 * WPR][2];
+    __shared__ double red[4 * WPR][1][8];
+    const int lane = threadIdx.x & 63, j = ROWS == 4 ? blockIdx.x * 4 + (threadIdx.x >> 6) / WPR : blockIdx.x, r = lane >> 3, c = lane & 7;
     const bool live = j < a.m;
     const int jj = live ? j : 0;
     const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
     const double *const vec[1] = { a.r0 };
     double w[1];
-    const bool mine = workgroup_row_products<ROWS, 1>(a, q0, q1, vec, w, red);
+    const bool mine = workgroup_row_products<ROWS, 1, WPR>(a, q0, q1, vec, w, red);
     double g = 0.0, d = 0.0;
     if (live && mine && c == 0) {
         const double rr = a.r0[j * 8 + r];
         a.w0[j * 8 + r] = w[0];
         g = rr * rr; d = w[0] * rr;
     }
-    publish_partials(a, 0, g, d, sh);
+    publish_partials<4 * WPR>(a, 0, g, d, sh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1955,12 +1979,13 @@ __global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a) { pcg_tail(a);
 // What this launch costs is rounds of dependent memory latency (~4.2 us of it is the launch itself), so everything that
 // can be requested at once is: flags, partials, histories and row pointers together, then blocks and column indices, then
 // the neighbours' vectors.
-template <int ROWS>
-__global__ __launch_bounds__(256) void k_pcg_iter(const PcgArgs a)
+template <int ROWS, int WPR = 1>
+__global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
 {
-    __shared__ double sh[4][2];
-    __shared__ double red[4][3][8];
-    const int lane = threadIdx.x & 63, j = ROWS == 4 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x, r = lane >> 3, c = lane & 7;
+    __shared__ double sh[4 * WPR][2];
+    __shared__ double red[4 * WPR][3][8];
+    constexpr bool kOwn = ROWS == 4 && WPR == 1;     // every wavefront works for itself: no barrier, no shared totals
+    const int lane = threadIdx.x & 63, j = ROWS == 4 ? blockIdx.x * 4 + (threadIdx.x >> 6) / WPR : blockIdx.x, r = lane >> 3, c = lane & 7;
     const int par = a.it & 1, prev = a.it ? a.it - 1 : 0;
     const bool live = j < a.m;
     const int jj = live ? j : 0, idx = jj * 8 + r;
@@ -1972,7 +1997,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter(const PcgArgs a)
     // the other three through LDS -- four times fewer partial loads, which at 1 700 rows were as many bytes as a fifth of S~
     __shared__ double sgd[2];
     double gs = 0.0, ds = 0.0;
-    if (ROWS == 4 || threadIdx.x < 64)
+    if (kOwn || threadIdx.x < 64)
         for (int i = lane; i < a.nwg; i += 64) { gs += a.gp[(size_t)par * a.nwg + i]; ds += a.dp[(size_t)par * a.nwg + i]; }
     const double g_prev = a.rz_hist[prev], g_zero = a.rz_hist[0], a_prev = a.alpha_hist[prev];
     const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
@@ -1981,12 +2006,12 @@ __global__ __launch_bounds__(256) void k_pcg_iter(const PcgArgs a)
     // rounds 2 and 3
     const double *const vec[3] = { rc, wc, so };
     double S3[3];
-    if (ROWS != 4 && threadIdx.x < 64) {             // (the barrier inside workgroup_row_products<1> orders this against the reads below)
+    if (!kOwn && threadIdx.x < 64) {                 // (the barrier inside workgroup_row_products orders this against the reads below)
         const double gsum = wave_sum(gs), dsum = wave_sum(ds);
         if (lane == 0) { sgd[0] = gsum; sgd[1] = dsum; }
     }
-    const bool mine = workgroup_row_products<ROWS, 3>(a, q0, q1, vec, S3, red);
-    const double gamma = ROWS == 4 ? wave_sum(gs) : sgd[0], delta = ROWS == 4 ? wave_sum(ds) : sgd[1];
+    const bool mine = workgroup_row_products<ROWS, 3, WPR>(a, q0, q1, vec, S3, red);
+    const double gamma = kOwn ? wave_sum(gs) : sgd[0], delta = kOwn ? wave_sum(ds) : sgd[1];
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (first) a.rz_hist[a.it] = gamma;
     const bool conv = a.it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < a.tol);
@@ -2011,7 +2036,7 @@ __global__ __launch_bounds__(256) void k_pcg_iter(const PcgArgs a)
         a.x[idx] = fma(alpha, p_new, x_own);
         g = r_new * r_new; d = w_new * r_new;
     }
-    publish_partials(a, par ^ 1, g, d, sh);
+    publish_partials<4 * WPR>(a, par ^ 1, g, d, sh);
     if (first) { a.alpha_hist[a.it] = alpha; a.scal[SC_PCG_ITERS] = (double)(a.it + 1); }
 }
 
@@ -2273,6 +2298,7 @@ void launch_pcg_init(hipStream_t st, const PcgArgs &a)
 {
     if (a.co.ng) { hipLaunchKernelGGL(k_pcg2_start<4>, dim3(a.nwg), dim3(256), 0, st, a); return; }
     if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_start<1>, dim3(a.nwg), dim3(256), 0, st, a);
+    else if (a.wpr == 2) hipLaunchKernelGGL((k_pcg_start<4, 2>), dim3(a.nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL(k_pcg_start<4>, dim3(a.nwg), dim3(256), 0, st, a);
 }
 
@@ -2280,6 +2306,7 @@ void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
 {
     if (a.co.ng) { hipLaunchKernelGGL(k_pcg2_iter, dim3(a.nwg), dim3(256), 0, st, a); return; }
     if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_iter<1>, dim3(a.nwg), dim3(256), 0, st, a);
+    else if (a.wpr == 2) hipLaunchKernelGGL((k_pcg_iter<4, 2>), dim3(a.nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL(k_pcg_iter<4>, dim3(a.nwg), dim3(256), 0, st, a);
 }
 
