@@ -1653,37 +1653,73 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_start(const PcgArgs a)
 // Per trial: k_coarse_bc (per-row sums), k_coarse_assemble (fixed-order sums: the replicated solve must give the same bits on every rank), k_coarse_invert
 // (Gauss-Jordan by one workgroup, the matrix in registers), after k_coarse_bc's per-row sums.
 // ------------------------------------------------------------------------------------------
-// U_j[slot] = sum_{k in aggregate bc_agg[j][slot]} S_jk and Bc_j[slot] = L_j^-1 U_j[slot] (= (S~ Z~)_j restricted to that
-// aggregate), one wavefront per row, one pass over the row's blocks
-__global__ __launch_bounds__(256) void k_coarse_bc(int m, const int *__restrict__ bsr_row, const FinalizeArgs f, const double *__restrict__ Linv,
+// Bc_j[slot] = L_j^-1 sum_{k in aggregate bc_agg[j][slot]} S_jk (= (S~ Z~)_j restricted to that aggregate) and
+// U_j[slot] = L_j Bc_j[slot] (the plain sum of the row's blocks of S in that aggregate: what Z'SZ is made of).  Taken from the
+// SCALED matrix the CG streams anyway, L_j^-1 S_jk = S~_jk L_k', in one pass shaped like the CG product (16 B per lane, two
+// blocks per wave load, eight loads in flight; lane (r, c2) of a half holds S~[r][c2], S~[r][c2 + 1] and forms its share of
+// all eight columns): one wavefront per block row.
+__global__ __launch_bounds__(256) void k_coarse_bc(int m, const int *__restrict__ bsr_row, const int *__restrict__ bsr_col, const double *__restrict__ Sv,
                                                   const CoarseArgs co)
 {
-    __shared__ double sh[4][2][64];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7, j = blockIdx.x * 4 + wv;
-    if (j >= m) return;
+    // one workgroup per block row, its four wavefronts take the row's block pairs in turn (a wavefront alone walks a row of 240
+    // blocks in rounds of dependent latency: blocks from HBM, then the neighbours' L from L2); then wavefront s finishes slot s
+    __shared__ double sAcc[4][kBcSlots][64], sL[64], sB[kBcSlots][64];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x;
     const int cams_per_agg = co.wg_per_agg * 4;
-    sh[wv][1][lane] = Linv[(size_t)j * 64 + lane];
+    const int half = lane >> 5, c2 = (lane & 3) * 2, r = (lane & 31) >> 2, el = r * 8 + c2;
     int H[kBcSlots];
-    double u[kBcSlots];
+    double acc[kBcSlots][8];
 #pragma unroll
-    for (int s = 0; s < kBcSlots; ++s) { H[s] = co.bc_agg[j * kBcSlots + s]; u[s] = 0.0; }
-    for (int q = bsr_row[j]; q < bsr_row[j + 1]; ++q) {
-        const int g = f.col[q] / cams_per_agg;
-        const double v = finalized_element(f, q, lane);
+    for (int sl = 0; sl < kBcSlots; ++sl) {
+        H[sl] = co.bc_agg[j * kBcSlots + sl];
 #pragma unroll
-        for (int s = 0; s < kBcSlots; ++s) u[s] += g == H[s] ? v : 0.0;
+        for (int c = 0; c < 8; ++c) acc[sl][c] = 0.0;
     }
+    if (wv == 0) sL[lane] = co.Lfac[(size_t)j * 64 + lane];
+    const int qe = bsr_row[j + 1];
+    int q = bsr_row[j] + 2 * wv + half;
+    constexpr int UN = 4;
+    auto one = [&](int col, double2 sv) {
+        const int g = col / cams_per_agg;
+        const double *Lk = co.Lfac + (size_t)col * 64 + c2;
+        double t[8];
 #pragma unroll
-    for (int s = 0; s < kBcSlots; ++s) {
-        co.U[((size_t)j * kBcSlots + s) * 64 + lane] = u[s];
-        wave_lds_sync();
-        sh[wv][0][lane] = u[s];
-        wave_lds_sync();
-        double t = 0.0;
+        for (int c = 0; c < 8; ++c) { const double2 l = *reinterpret_cast<const double2 *>(Lk + c * 8); t[c] = fma(sv.y, l.y, sv.x * l.x); }
 #pragma unroll
-        for (int a = 0; a < 8; ++a) t = fma(sh[wv][1][r * 8 + a], sh[wv][0][a * 8 + c], t);
-        co.Bc[((size_t)j * kBcSlots + s) * 64 + lane] = t;
+        for (int sl = 0; sl < kBcSlots; ++sl) {
+            const double on = g == H[sl] ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[sl][c] = fma(on, t[c], acc[sl][c]);
+        }
+    };
+    for (; q + (UN - 1) * 8 < qe; q += UN * 8) {
+        int col[UN];
+        double2 sv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) { col[u] = bsr_col[q + 8 * u]; sv[u] = *reinterpret_cast<const double2 *>(Sv + (size_t)(q + 8 * u) * 64 + el); }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) one(col[u], sv[u]);
     }
+    for (; q < qe; q += 8) one(bsr_col[q], *reinterpret_cast<const double2 *>(Sv + (size_t)q * 64 + el));
+#pragma unroll
+    for (int sl = 0; sl < kBcSlots; ++sl)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            double t = acc[sl][c];
+            t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t);      // the four lanes of row r
+            t += __shfl_xor(t, 32);                               // even + odd block pairs
+            if (half == 0 && (lane & 3) == 0) sAcc[wv][sl][r * 8 + c] = t;
+        }
+    __syncthreads();
+    const int sl = wv, rr = lane >> 3, cc = lane & 7;             // (kBcSlots == 4 wavefronts)
+    const double bcv = (sAcc[0][sl][lane] + sAcc[1][sl][lane]) + (sAcc[2][sl][lane] + sAcc[3][sl][lane]);
+    sB[sl][lane] = bcv;
+    co.Bc[((size_t)j * kBcSlots + sl) * 64 + lane] = bcv;
+    wave_lds_sync();
+    double u = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u = fma(sL[rr * 8 + k], sB[sl][k * 8 + cc], u);    // U = L_j Bc
+    co.U[((size_t)j * kBcSlots + sl) * 64 + lane] = u;
 }
 
 // Ac[G][H] = sum over the rows j of aggregate G of U_j[slot of H], in a fixed order (the replicated solve must give the same
@@ -1705,76 +1741,86 @@ __global__ __launch_bounds__(256) void k_coarse_assemble(int m, const CoarseArgs
 }
 
 // Ac -> Ac^-1 (symmetric positive definite: Gauss-Jordan without pivoting), one workgroup, the matrix in registers (a 4x4
-// tile per thread), row k and column k of each step handed round through LDS; a pivot that is not positive switches the coarse
-// correction off for this trial (Acinv = 0: the iteration is then plain block-Jacobi CG)
+// tile per thread), row k and column k of each step handed round through LDS.  The matrix is first scaled to a unit diagonal
+// (pivots <= 1), which lets ONE uniform rank-1 update a_ij -= c_i r_j per step do the pivot row, the pivot column and the
+// pivot itself as well, by handing round r_k = p + 1 and c_k = 1 - 1/p in place of the pivot:
+//   (k,k): p - (1 - 1/p)(p + 1) = 1/p,   (k,j): r_j - (1 - 1/p) r_j = r_j / p,   (i,k): a_ik - (a_ik / p)(p + 1) = -a_ik / p
+// (with p <= 1 each of them keeps full relative accuracy) -- no per-element selects in the inner loop: 208 -> 40 us at 128 x 128.
+// A pivot that is not positive switches the coarse correction off for this trial (Acinv = 0: plain block-Jacobi CG).
 __global__ __launch_bounds__(1024) void k_coarse_invert(const CoarseArgs co)
 {
     static_assert(kCoarseMax * 8 == 128, "the register tiling covers 128 x 128");
-    __shared__ double sRow[2][128], sCol[2][128];
-    const int n = co.nc, tid = threadIdx.x, i0 = (tid >> 5) * 4, j0 = (tid & 31) * 4;
+    __shared__ __attribute__((aligned(16))) double sRow[2][128], sCol[2][128];
+    __shared__ double sPiv[2], sD[128];
+    // a wavefront holds 8 x 8 tiles (32 x 32 elements): row k and column k of a step live in 4 + 4 of the 16 wavefronts, the others
+    // skip the hand-over code
+    const int n = co.nc, tid = threadIdx.x, wq = tid >> 6, lq = tid & 63, i0 = ((wq >> 2) * 8 + (lq >> 3)) * 4, j0 = ((wq & 3) * 8 + (lq & 7)) * 4;
+    if (tid < 128) { const double d = tid < n ? co.Ac[(size_t)tid * n + tid] : 1.0; sD[tid] = d > 0.0 ? 1.0 / sqrt(d) : 0.0; }
+    __syncthreads();
     double a[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
             const int i = i0 + x, j = j0 + y;
-            a[x][y] = i < n && j < n ? 0.5 * (co.Ac[(size_t)i * n + j] + co.Ac[(size_t)j * n + i]) : 0.0;
+            a[x][y] = i < n && j < n ? (i == j ? 1.0 : 0.5 * (co.Ac[(size_t)i * n + j] + co.Ac[(size_t)j * n + i]) * sD[i] * sD[j]) : 0.0;
         }
     bool fail = false;
     for (int k = 0; k < n; ++k) {
         const int b = k & 1, kr = k - i0, kc = k - j0;
-        if ((unsigned)kr < 4u) {
+        if ((unsigned)kr < 4u) {              // this thread's tile holds part of row k
 #pragma unroll
             for (int x = 0; x < 4; ++x)
                 if (x == kr) {
 #pragma unroll
-                    for (int y = 0; y < 4; ++y) sRow[b][j0 + y] = a[x][y];
+                    for (int y = 0; y < 4; ++y) sRow[b][j0 + y] = y == kc ? a[x][y] + 1.0 : a[x][y];
+                    if ((unsigned)kc < 4u) {
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) if (y == kc) sPiv[b] = a[x][y];
+                    }
                 }
         }
-        if ((unsigned)kc < 4u) {
+        if ((unsigned)kc < 4u) {              // ... of column k
 #pragma unroll
             for (int y = 0; y < 4; ++y)
                 if (y == kc) {
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) sCol[b][i0 + x] = a[x][y];
+                    for (int x = 0; x < 4; ++x) sCol[b][i0 + x] = x == kr ? a[x][y] - 1.0 : a[x][y];
                 }
         }
         __syncthreads();                                                  // (one barrier a step: the buffers alternate)
-        const double piv = sRow[b][k];
+        const double piv = sPiv[b];
         if (!(piv > 0.0) || !isfinite(piv)) { fail = true; break; }       // uniform: every thread reads the same pivot
         const double ip = 1.0 / piv;
-        double rw[4], cl[4];
-#pragma unroll
-        for (int y = 0; y < 4; ++y) rw[y] = sRow[b][j0 + y];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) cl[x] = sCol[b][i0 + x] * ip;
+        const double2 r01 = *reinterpret_cast<const double2 *>(&sRow[b][j0]), r23 = *reinterpret_cast<const double2 *>(&sRow[b][j0 + 2]);
+        const double2 c01 = *reinterpret_cast<const double2 *>(&sCol[b][i0]), c23 = *reinterpret_cast<const double2 *>(&sCol[b][i0 + 2]);
+        const double rw[4] = { r01.x, r01.y, r23.x, r23.y }, cl[4] = { c01.x * ip, c01.y * ip, c23.x * ip, c23.y * ip };
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                double v = fma(-cl[x], rw[y], a[x][y]);
-                if (x == kr) v = y == kc ? ip : rw[y] * ip;
-                else if (y == kc) v = -cl[x];
-                a[x][y] = v;
-            }
+            for (int y = 0; y < 4; ++y) a[x][y] = fma(-cl[x], rw[y], a[x][y]);
     }
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y)
-            if (i0 + x < n && j0 + y < n) co.Acinv[(size_t)(i0 + x) * n + j0 + y] = fail ? 0.0 : a[x][y];
+            if (i0 + x < n && j0 + y < n) co.Acinv[(size_t)(i0 + x) * n + j0 + y] = fail ? 0.0 : a[x][y] * sD[i0 + x] * sD[j0 + y];
 }
 
-// The coarse part of one launch, by the whole workgroup: coarse projections of up to three vectors from the per-workgroup
-// partial sums (cpart[par]), combined as cr - alpha (cw + beta cs); y = Ac^-1 c for the aggregates this workgroup's rows reach
-// (its own and the band's: a handful of the ng), left in sY[aggregate * 8 + r].
-__device__ __forceinline__ void coarse_solve(const PcgArgs &a, int par, int nvec, double alpha, double beta, const double *E0,
+// The coarse part of one launch, by NT threads (tid = 0 .. NT - 1: the whole workgroup of k_pcg2_start, or the one wavefront
+// k_pcg2_iter sets aside for it while the other four stream the matrix): coarse projections of up to three vectors from the
+// per-workgroup partial sums (cpart[par]), combined as cr - alpha (cw + beta cs); y = Ac^-1 c for the aggregates this
+// workgroup's rows reach (its own and the band's: a handful of the ng), left in sY[aggregate * 8 + r].  The caller puts a
+// barrier between this and the readers of sY.
+template <int NT>
+__device__ __forceinline__ void coarse_solve(const PcgArgs &a, int tid, int par, int nvec, double alpha, double beta, const double *E0,
                                              double *sC /* [3][128] */, double *sY /* [128] */, int *sList /* [kCoarseMax + 1] */)
 {
     const CoarseArgs &co = a.co;
-    const int tid = threadIdx.x, nc = co.nc;
+    const int nc = co.nc;
+    auto sync = [] { if constexpr (NT == 64) wave_lds_sync(); else __syncthreads(); };
     if (E0) {   // the first residual: c_0 = aggregate sums of the unscaled right-hand side
-        for (int o = tid; o < nc; o += 256) {
+        for (int o = tid; o < nc; o += NT) {
             const int G = o >> 3, rr = o & 7, j0 = G * co.wg_per_agg * 4, j1 = min(a.m, j0 + co.wg_per_agg * 4);
             double s0 = 0.0, s1 = 0.0;
             int k = j0;
@@ -1784,7 +1830,7 @@ __device__ __forceinline__ void coarse_solve(const PcgArgs &a, int par, int nvec
         }
     } else {
         const double *cp = co.cpart + (size_t)par * 3 * a.nwg * 8;
-        for (int o = tid; o < nvec * nc; o += 256) {
+        for (int o = tid; o < nvec * nc; o += NT) {
             const int v = o / nc, idx = o - v * nc, G = idx >> 3, rr = idx & 7;
             const int w0 = G * co.wg_per_agg, w1 = min(a.nwg, w0 + co.wg_per_agg);
             double s0 = 0.0, s1 = 0.0;
@@ -1807,15 +1853,13 @@ __device__ __forceinline__ void coarse_solve(const PcgArgs &a, int par, int nvec
         }
         sList[0] = n;
     }
-    __syncthreads();
-    if (!E0 && tid < nc) {
-        const double cn = nvec == 3 ? sC[tid] - alpha * (sC[128 + tid] + beta * sC[256 + tid]) : sC[tid];
-        sC[tid] = cn;                                        // (only thread tid reads sC[.][tid] here)
-    }
-    __syncthreads();
-    // y_o = sum_k Acinv[o][k] c_k for the listed aggregates: 8 lanes per output (k = part, part + 8, ...: independent loads), 32 outputs a pass
+    sync();
+    if (!E0 && nvec == 3)
+        for (int o = tid; o < nc; o += NT) sC[o] = sC[o] - alpha * (sC[128 + o] + beta * sC[256 + o]);   // (only this thread reads sC[.][o] here)
+    sync();
+    // y_o = sum_k Acinv[o][k] c_k for the listed aggregates: 8 lanes per output (k = part, part + 8, ...: independent loads), NT / 8 outputs a pass
     const int nout = sList[0] * 8, part = tid & 7;
-    for (int oi = tid >> 3; oi < ((nout + 31) & ~31); oi += 32) {    // (uniform trip count: the DPP sums below need whole rows of lanes)
+    for (int oi = tid >> 3; oi < ((nout + NT / 8 - 1) & ~(NT / 8 - 1)); oi += NT / 8) {    // (uniform trip count: the DPP sums below need whole rows of lanes)
         const bool on = oi < nout;
         const int o = on ? sList[1 + (oi >> 3)] * 8 + (oi & 7) : 0;
         double acc = 0.0;
@@ -1824,7 +1868,6 @@ __device__ __forceinline__ void coarse_solve(const PcgArgs &a, int par, int nvec
         acc += dpp_move<0xB1>(acc); acc += dpp_move<0x4E>(acc); acc += dpp_move<0x141>(acc);
         if (on && part == 0) sY[o] = acc;
     }
-    __syncthreads();
 }
 
 // per block row: z_j = r_j + L_j' y_G, the band term (S~ Z~)_j y, and the coarse projections L_j (r | w | s)_j of the new vectors;
@@ -1840,10 +1883,11 @@ __global__ __launch_bounds__(256) void k_pcg2_start(const PcgArgs a)
     const int jj = live ? j : 0;
     const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
     // c_0 = Z~' r_0 = aggregate sums of the unscaled right-hand side E (r_0 = L^-1 E): straight from E, every workgroup for itself
-    coarse_solve(a, 0, 1, 0.0, 0.0, a.E, sC, sY, sList);
+    coarse_solve<256>(a, threadIdx.x, 0, 1, 0.0, 0.0, a.E, sC, sY, sList);
     const double *const vec[1] = { a.r0 };
     double w[1];
     (void)workgroup_row_products<4, 1>(a, q0, q1, vec, w, red);      // (S~ r_0)_j[r] in every lane of row r
+    __syncthreads();                                                  // sY
     const int G = blockIdx.x / co.wg_per_agg;
     const double *Lj = co.Lfac + (size_t)jj * 64;
     // z = r + L' y_G ; band term
@@ -1879,14 +1923,19 @@ __global__ __launch_bounds__(256) void k_pcg2_start(const PcgArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_pcg2_iter(const PcgArgs a)
+// iteration a.it with the coarse correction: FIVE wavefronts -- four stream their block rows of S~ as in k_pcg_iter, the fifth
+// meanwhile sums the partials, forms alpha and beta and does the coarse solve (rounds of dependent loads that, done by the same
+// wavefronts before or after the pass over the matrix, cost an iteration a third more: C4 63.6 against 46 us)
+__global__ __launch_bounds__(320) void k_pcg2_iter(const PcgArgs a)
 {
-    __shared__ double sh[4][2], red[4][3][8], sC[3 * 128], sY[128], sV[4][3][8], sP[4][3][8];
+    __shared__ double sh[5][2], red[4][3][8], sC[3 * 128], sY[128], sV[4][3][8], sP[4][3][8];
     __shared__ int sList[kCoarseMax + 1];
     const CoarseArgs &co = a.co;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv, r = lane >> 3, c = lane & 7;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
+    const bool cw = wv == 4;                                            // the coarse wavefront
+    const int j = blockIdx.x * 4 + (cw ? 0 : wv);
     const int par = a.it & 1, prev = a.it ? a.it - 1 : 0;
-    const bool live = j < a.m;
+    const bool live = !cw && j < a.m;
     const int jj = live ? j : 0, idx = jj * 8 + r;
     const double *__restrict__ rc = par ? a.r1 : a.r0, *__restrict__ wc = par ? a.w1 : a.w0, *__restrict__ so = par ? a.s1 : a.s0;
     const double st = a.scal[SC_PCG_STATUS], dn = a.scal[SC_PCG_DONE];
@@ -1897,8 +1946,9 @@ __global__ __launch_bounds__(256) void k_pcg2_iter(const PcgArgs a)
     const double r_own = rc[idx], w_own = wc[idx], s_own = so[idx], p_own = a.p[idx], x_own = a.x[idx], z_own = co.z[idx];
     if (st != 0.0 || dn != 0.0) return;
     const double *const vec[3] = { rc, wc, so };
-    double S3[3];
-    (void)workgroup_row_products<4, 3>(a, q0, q1, vec, S3, red);
+    double S3[3] = { 0.0, 0.0, 0.0 };
+    if (!cw) (void)workgroup_row_products<4, 3>(a, q0, q1, vec, S3, red);
+    // every wavefront takes the same decisions from the same sums (the coarse one before its solve, the others after their rows)
     const double gamma = wave_sum(gs), delta = wave_sum(ds);           // gamma = r.z, delta = w.z (w = S~ z)
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (first) a.rz_hist[a.it] = gamma;
@@ -1915,7 +1965,8 @@ __global__ __launch_bounds__(256) void k_pcg2_iter(const PcgArgs a)
     }
     const double alpha = gamma / den;
     // the coarse state of the NEXT residual, from what the last launch left: y = Ac^-1 (cr - alpha (cw + beta cs))
-    coarse_solve(a, par, 3, alpha, beta, nullptr, sC, sY, sList);
+    if (cw) coarse_solve<64>(a, lane, par, 3, alpha, beta, nullptr, sC, sY, sList);
+    __syncthreads();
     const int G = blockIdx.x / co.wg_per_agg;
     const double *Lj = co.Lfac + (size_t)jj * 64;
     double zt = Lj[c * 8 + r] * sY[G * 8 + c];
@@ -1932,7 +1983,7 @@ __global__ __launch_bounds__(256) void k_pcg2_iter(const PcgArgs a)
     const double z_new = r_new + zt;
     const double w_new = fma(-alpha, fma(beta, S3[2], S3[1]), S3[0]) + bt;
     double g = 0.0, d = 0.0;
-    if (c == 0) { sV[wv][0][r] = live ? r_new : 0.0; sV[wv][1][r] = live ? w_new : 0.0; sV[wv][2][r] = live ? s_new : 0.0; }
+    if (!cw && c == 0) { sV[wv][0][r] = live ? r_new : 0.0; sV[wv][1][r] = live ? w_new : 0.0; sV[wv][2][r] = live ? s_new : 0.0; }
     if (live && c == 0) {
         sn[idx] = s_new; rn[idx] = r_new; wn[idx] = w_new; co.z[idx] = z_new;
         a.p[idx] = p_new;
@@ -1940,13 +1991,15 @@ __global__ __launch_bounds__(256) void k_pcg2_iter(const PcgArgs a)
         g = r_new * z_new; d = w_new * z_new;
     }
     wave_lds_sync();
+    if (!cw) {
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-        double t = live ? Lj[r * 8 + c] * sV[wv][v][c] : 0.0;
-        t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t); t += dpp_move<0x141>(t);
-        if (c == 0) sP[wv][v][r] = t;
+        for (int v = 0; v < 3; ++v) {
+            double t = live ? Lj[r * 8 + c] * sV[wv][v][c] : 0.0;
+            t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t); t += dpp_move<0x141>(t);
+            if (c == 0) sP[wv][v][r] = t;
+        }
     }
-    publish_partials(a, par ^ 1, g, d, sh);
+    publish_partials(a, par ^ 1, g, d, sh);                            // (the fifth wavefront adds zeros to a row nobody sums)
     if (threadIdx.x < 24) {
         const int v = threadIdx.x >> 3, rr8 = threadIdx.x & 7;
         co.cpart[((size_t)(par ^ 1) * 3 + v) * a.nwg * 8 + (size_t)blockIdx.x * 8 + rr8] = (sP[0][v][rr8] + sP[1][v][rr8]) + (sP[2][v][rr8] + sP[3][v][rr8]);
@@ -2286,7 +2339,8 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
     hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg);
     if (co.ng) {   // the coarse space of this trial's system: Z'SZ, its inverse, S~Z~
-        hipLaunchKernelGGL(k_coarse_bc, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_row, f, Linv, co);
+        static_assert(kBcSlots == 4, "k_coarse_bc: one wavefront per slot");
+        hipLaunchKernelGGL(k_coarse_bc, dim3(m), dim3(256), 0, st, m, bsr_row, bsr_col, (const double *)S_pcg, co);
         hipLaunchKernelGGL(k_coarse_assemble, dim3(co.ng * co.ng), dim3(256), 0, st, m, co);
         hipLaunchKernelGGL(k_coarse_invert, dim3(1), dim3(1024), 0, st, co);
     }
@@ -2304,7 +2358,7 @@ void launch_pcg_init(hipStream_t st, const PcgArgs &a)
 
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
 {
-    if (a.co.ng) { hipLaunchKernelGGL(k_pcg2_iter, dim3(a.nwg), dim3(256), 0, st, a); return; }
+    if (a.co.ng) { hipLaunchKernelGGL(k_pcg2_iter, dim3(a.nwg), dim3(320), 0, st, a); return; }
     if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_iter<1>, dim3(a.nwg), dim3(256), 0, st, a);
     else if (a.wpr == 2) hipLaunchKernelGGL((k_pcg_iter<4, 2>), dim3(a.nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL(k_pcg_iter<4>, dim3(a.nwg), dim3(256), 0, st, a);
