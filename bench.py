@@ -202,7 +202,7 @@ def main():
         # HBM traffic of one k_build launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
         # inside this process); only quoted for the configuration it was measured on
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_build_traffic_%s.json" % args.config)
+        tpath = os.path.join(ROOT, "profiles", "r02b_build_traffic_%s.json" % args.config)
         if world == 1 and not args.deterministic and os.path.exists(tpath):
             traffic = json.load(open(tpath))["hbm_bytes_gfx950_corrected"]
         achieved = tm["build_bytes"] / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
