@@ -75,7 +75,19 @@ typedef struct {
      * model (sfm.c:360-373, 648-649).  With the focal length that is NINE camera parameters (cnp 9): the engine then keeps camera j
      * as two rows of its 8-wide camera-side arrays (parameters 0-7, parameter 8) and every point takes the row path. */
     int nk;
-    int reserved[4];
+    /* Levenberg-Marquardt variant.  0 (default): sba's (sba_levmar.c:1085-1617) -- additive damping mu I started at tau max diag,
+     * the stop rules of opts[1..5].  1: PBA's (SparseBundleCPU.cpp:3797-3983, what ParallelBA::RunBundleAdjustment runs) --
+     * multiplicative damping, U* = U + mu diag(U), V* = V + mu diag(V) (:1813-1814), started at opts[0] itself
+     * (__lm_initial_damp); a trial is accepted when the cost goes down; the gain ratio is the cost change over
+     * d'(mu D d + g), D = diag(J'J) (the exact-solve form of :3740-3745); mu <- mu max(1/3, 1 - (2 rho - 1)^3) kept within
+     * [opts[3], opts[4]] after a success (__lm_minimum_damp, __lm_maximum_damp), mu <- mu nu, nu <- 2 nu after a failure;
+     * stops: sqrt(d'D d) <= opts[2] (__lm_delta_threshold; stop code 2), gradient |g|_inf <= opts[1] when opts[1] > 0
+     * (__lm_check_gradient; stop code 1), itmax TRIALS (stop code 3).  The mean-squared-error and time-budget rules are the
+     * caller's (pba_shim.cpp).  opts[5] is not used.  2: the same controller with PBA's identity damping (mu I; its
+     * __lm_use_diagonal_damp off). */
+    int lm_variant;
+    int pcg_minit;          /* the reduced solve's tolerance test counts from this iteration on (PBA: __cg_min_iteration = 10) */
+    int reserved[2];
 } mi_ba_config;
 
 /* fills the defaults above (Bundler's run_sfm settings, cnp 7, explicit centres) */

@@ -4,9 +4,10 @@
  * Same class name, method names, argument meaning and order of virtuals as the reference's
  * Optimizer/pba/src/pba/pba.h:52-133 (class ParallelBA, NewParallelBA, ParallelBA_GetVersion), so a
  * caller of that interface recompiles against this header and links libmi_ba.so instead of libpba
- * (INTEGRATION.md).  What runs underneath is NOT PBA's algorithm but the engine of mi_ba.h: the
- * reference sba-1.5 Levenberg-Marquardt (additive damping, gain-ratio update) with the reduced
- * camera system solved by block-Jacobi PCG on the GPU.
+ * (INTEGRATION.md).  What runs underneath is the engine of mi_ba.h under PBA's own Levenberg-Marquardt
+ * rules (lm_variant 1: damping on the diagonals, PBA's accept / gain-ratio / damping schedule and
+ * stop rules), the reduced camera system formed explicitly and solved by block-Jacobi PCG on the GPU
+ * where PBA applies it implicitly.
  *
  * Ownership and error behaviour follow the reference (SparseBundleCPU.cpp:2541-2590, 2660-2674):
  * the caller owns every array, SetCameraData / SetPointData keep the raw pointers and
@@ -48,6 +49,15 @@ public:
     float __data_normalize_median, __depth_check_epsilon;
     float __focal_scaling, __depth_scaling;      /* what the last run used (1 = none) */
     int __num_point_behind, __num_camera_modified;
+    /* PBA's Levenberg-Marquardt (NonlinearOptimizeLM, SparseBundleCPU.cpp:3797-3983; defaults ConfigBA.cpp:44-63): damping on the
+     * diagonals ("-id": on the identity) started at __lm_initial_damp ("-damp") and kept within [__lm_minimum_damp ("-dmin"),
+     * __lm_maximum_damp ("-dmax")]; stop 'S' once the step's norm (in the metric of diag J'J) is at or below __lm_delta_threshold
+     * ("-lmd"), 'G' on the gradient when __lm_check_gradient ("-chkg", "-lmg"); the CG looks at its tolerance from iteration
+     * __cg_min_iteration ("-cgim") on.  Run as mi_ba.h's lm_variant 1 / 2; MI_PBA_SBA_LM=1 in the environment runs sba's
+     * controller instead (round 1's behaviour: same minima, two to three times the iterations on the golden cases). */
+    float __lm_initial_damp, __lm_minimum_damp, __lm_maximum_damp, __lm_delta_threshold, __lm_gradient_threshold, __lm_damping_auto_switch;
+    bool __lm_use_diagonal_damp, __lm_check_gradient;
+    int __cg_min_iteration;
     ConfigBA();
     char GetBundleReturnCode() const { return __bundle_return_code; }
     const char *GetOutputParam() const { return __output_param; }

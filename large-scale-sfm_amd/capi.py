@@ -29,7 +29,7 @@ class Config(C.Structure):
                 ("itmax", C.c_int), ("opts", C.c_double * 6), ("disable_stops", C.c_int),
                 ("pcg_maxit", C.c_int), ("pcg_tol", C.c_double),
                 ("device", C.c_int), ("rank", C.c_int), ("world", C.c_int), ("verbose", C.c_int),
-                ("tile_max_batches", C.c_int), ("mode", C.c_int), ("deterministic", C.c_int), ("nk", C.c_int), ("reserved", C.c_int * 4)]
+                ("tile_max_batches", C.c_int), ("mode", C.c_int), ("deterministic", C.c_int), ("nk", C.c_int), ("lm_variant", C.c_int), ("pcg_minit", C.c_int), ("reserved", C.c_int * 2)]
 
 
 class Timing(C.Structure):

@@ -58,6 +58,7 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
 {
     if (cfg.undistort < 0 || cfg.undistort > 2) { err = "undistort must be 0, 1 (projection distortion) or 2 (measurement distortion)"; return; }
     if (cfg.nk != 0 && cfg.nk != 1 && cfg.nk != 2) { err = "nk must be 1 (k1) or 2 (k1 and k2)"; return; }
+    if (cfg.lm_variant < 0 || cfg.lm_variant > 2) { err = "lm_variant must be 0 (sba), 1 (PBA) or 2 (PBA, identity damping)"; return; }
     if (cfg.nk == 0) cfg.nk = 1;
     cnp = 6 + (cfg.est_focal ? 1 : 0) + (cfg.undistort == 1 ? cfg.nk : cfg.undistort == 2 ? 1 : 0);
     split_ = cnp == 9;       // Bundler's full camera (sfm.c:648-649): blocks wider than the 8 x 8 the camera-side kernels are shaped for
@@ -103,6 +104,7 @@ ModelCfg Engine::model() const
     mc.explicit_centers = cfg.explicit_centers; mc.est_focal = cfg.est_focal; mc.undistort = cfg.undistort;
     mc.mcon = cfg.mcon; mc.points_fixed = cfg.mode == 1; mc.proj_sign = cfg.proj_sign; mc.f_scale = cfg.f_scale; mc.k_scale = cfg.k_scale;
     mc.nk = cfg.undistort == 1 ? cfg.nk : 1; mc.split = split_ ? 1 : 0;
+    mc.damp_diag = cfg.lm_variant == 1;         // (2: PBA's controller with identity damping, __lm_use_diagonal_damp off)
     return mc;
 }
 
@@ -528,7 +530,8 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     a.pair = d_pair_.p; a.obs_rec = d_obs_rec_.p; a.rec = d_rec_.p;
     a.m = mv_; a.cam_lin = d_cam_lin_[cur_].p; a.pts = d_pts_[cur_].p; a.mu = mu;
     a.S_up = S_up_(); a.camvec = camvec_(); a.ptout = d_ptout_.p; a.part = d_part_.p; a.cfg = mc; a.spec = spec;
-    a.dbg = d_dbg_.p; a.want_diag = want_diag ? 1 : 0;
+    const bool pba = cfg.lm_variant == 1;       // PBA's diagonal damping needs diag U of every linearisation
+    a.dbg = d_dbg_.p; a.want_diag = (want_diag || pba) ? 1 : 0;
     a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
     lin_pair_ = (lin_count_++ & 1) ? 6 : 0;
     if (timing_detail >= 1) (void)hipEventRecord(ev_[lin_pair_], st_);
@@ -544,7 +547,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
         SchurArgs sa{};
         sa.rec = d_rec_.p; sa.wk_blk = d_wk_blk_.p; sa.wk_q = d_wk_q_.p; sa.rpair = d_rpair_.p;
         sa.diag_cam = d_wk_diag_cam_.p; sa.diag_blk = d_wk_diag_blk_.p; sa.rec_cam = d_rec_cam_.p;
-        sa.nwork = (int)pl.wk_blk.size(); sa.ndiag = (int)pl.wk_diag_cam.size(); sa.m = m_; sa.mv = mv_; sa.want_diag = want_diag ? 1 : 0;
+        sa.nwork = (int)pl.wk_blk.size(); sa.ndiag = (int)pl.wk_diag_cam.size(); sa.m = m_; sa.mv = mv_; sa.want_diag = (want_diag || pba) ? 1 : 0;
         sa.wk_vblk = d_wk_vblk_.p; sa.diag_vblk = d_wk_diag_vblk_.p;
         sa.S_up = S_up_(); sa.camvec = camvec_(); sa.spec = spec;
         launch_schur_blocks(st_, cnp, sa);
@@ -559,7 +562,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     launch_finalize(st_, cnp_cam_(), mv_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
                     d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag /* a linear phase on its own (begin, parity hooks) */, pcg_start(),
-                    co_active_ ? co_ : CoarseArgs{}, d_bsr_row_.p);
+                    co_active_ ? co_ : CoarseArgs{}, d_bsr_row_.p, pba);
     cg_start_fresh_ = true;
     return hipok(hipGetLastError(), "launch (linear phase)");
 }
@@ -596,7 +599,7 @@ PcgArgs Engine::pcg_args()
     static const int force_wpr = std::getenv("MI_BA_PCG_WPR") ? std::atoi(std::getenv("MI_BA_PCG_WPR")) : 0;
     p.wpr = force_wpr == 1 || force_wpr == 2 ? force_wpr : ((size_t)plan_.nb_full() < (size_t)kPcgTwoWavesPerRowBelow * mv_ ? 2 : 1);
     p.rz_hist = d_rzpq_.p; p.alpha_hist = p.rz_hist + (cfg.pcg_maxit + 4); p.gp = p.alpha_hist + (cfg.pcg_maxit + 4); p.dp = p.gp + 2 * (size_t)p.nwg;
-    p.scal = scal_(); p.tol = cfg.pcg_tol; p.m = mv_; p.it = 0;
+    p.scal = scal_(); p.tol = cfg.pcg_tol; p.minit = cfg.pcg_minit; p.m = mv_; p.it = 0;
     if (co_active_) p.co = co_;
     return p;
 }
@@ -725,7 +728,8 @@ int Engine::begin()
     p_eL2_ = init_p_eL2_ = h_scal_[SC_COST] + c_lag_ + h_scal_[SC_LINK];
     maxdiag_ = measured_maxdiag();
     eab_inf_ = std::max(h_scal_[SC_EA_INF], h_scal_[SC_EB_INF]);
-    mu_ = std::fabs(cfg.opts[0]) * maxdiag_;
+    mu_ = cfg.lm_variant >= 1 ? std::fabs(cfg.opts[0]) : std::fabs(cfg.opts[0]) * maxdiag_;   // PBA: __lm_initial_damp multiplies the diagonals itself
+    trials_ = 0;
     if (cfg.verbose && cfg.rank == 0)   // sba's own line, sba_levmar.c:844
         std::printf("initial motstr-SBA error %g [%g]\n", p_eL2_ / (double)nobs_, p_eL2_);
     if (!std::isfinite(p_eL2_)) stop_ = 7;
@@ -747,7 +751,7 @@ int Engine::step()
 {
     DeviceGuard on_device(cfg.device);
     if (!begun_) { err = "step: begin first"; return MI_BA_ERROR; }
-    if (stop_ || itno_ >= cfg.itmax) { if (!stop_) stop_ = 3; return 2; }
+    if (stop_ || (cfg.lm_variant >= 1 ? trials_ : itno_) >= cfg.itmax) { if (!stop_) stop_ = 3; return 2; }
     const double t0 = now_ms();
     const double eps1 = std::fabs(cfg.opts[1]), eps2 = std::fabs(cfg.opts[2]), eps2_sq = cfg.opts[2] * cfg.opts[2],
                  eps3_sq = cfg.opts[3] * cfg.opts[3], eps4_sq = cfg.opts[4] * cfg.opts[4], eps5 = cfg.opts[5];
@@ -788,6 +792,57 @@ int Engine::step()
         const double row[6] = { (double)itno_, mu, p_eL2_, cost_trial, (double)accepted, s[SC_PCG_ITERS] };
         trace.insert(trace.end(), row, row + 6);
     };
+    if (cfg.lm_variant >= 1) {
+        // PBA's controller, SparseBundleCPU.cpp:3843-3976 (one pass of its for-loop).  SC_DL_* and SC_DP2_* are in the metric of
+        // D = diag(J'J) here (k_cam_update, k_backsub): dL = d'(mu D d + g), |d|_D^2 = d'D d -- PBA's step norm, which it takes on
+        // its column-normalised Jacobian (:3872, :3779-3793).
+        const double g_thr = cfg.opts[1], d_thr = cfg.opts[2], mu_min = cfg.opts[3], mu_max = cfg.opts[4];
+        do {
+            if (s[SC_SINGULAR] != 0.0 || s[SC_PCG_STATUS] != 0.0 || s[SC_NOT_PD] != 0.0) {   // :3858-3868 ('I': more damping, the pass does not count)
+                push_trace(NAN, 0);
+                mu_ *= nu_;
+                const int nu2 = (int)((unsigned)nu_ << 1);
+                if (nu2 <= nu_ || !std::isfinite(mu_)) { stop_ = 6; ret = 2; } else nu_ = nu2;
+                break;
+            }
+            ++trials_; ++nlss_;
+            dp_L2_ = s[SC_DP2_CAMS] + s[SC_DP2_PTS];
+            if (std::sqrt(dp_L2_) <= d_thr && stops) { stop_ = 2; ret = 2; break; }          // :3875-3884 "quit on too small change"
+            ++nfev_;
+            const double pdp_eL2 = s[SC_COST_NEW] + c_cur + s[SC_LINK_NEW];
+            const double dF = p_eL2_ - pdp_eL2;
+            if (std::isfinite(pdp_eL2) && dF > 0.0) {                                        // :3892
+                double dL = s[SC_DL_CAMS] + s[SC_DL_PTS];
+                if (!(dL > 0.0)) dL = 0.001 * dF;                                            // :3748
+                push_trace(pdp_eL2, 1);
+                if (cfg.verbose > 1 && cfg.rank == 0)
+                    std::printf("[mi_ba] it %3d  mu %.3e  cost %.9g -> %.9g  pcg %3d  gain %.3f\n", itno_, mu, p_eL2_, pdp_eL2, (int)s[SC_PCG_ITERS], dF / dL);
+                accept_trial(); p_eL2_ = pdp_eL2; c_lag_ = c_cur;
+                ++itno_; new_outer_ = true;
+                if (g_thr > 0.0 && eab_inf_ < g_thr && stops) { stop_ = 1; ret = 2; break; }  // :3927 (the gradient of the point just left)
+                double tmp = 2.0 * dF / dL - 1.0;
+                tmp = 1.0 - tmp * tmp * tmp;
+                mu_ *= (tmp >= kOneThird) ? tmp : kOneThird;                                  // :3940-3946
+                nu_ = 2;
+                if (mu_ < mu_min) mu_ = mu_min; else if (mu_max > 0.0 && mu_ > mu_max) mu_ = mu_max;
+                if (trials_ >= cfg.itmax) stop_ = 3;
+                ret = stop_ ? 2 : 1;
+                spec_ready_ = ret == 1 && spec_enqueued_ && s[SC_SPEC_GO] == 1.0 && s[SC_SPEC_MU] == mu_;
+                break;
+            }
+            push_trace(pdp_eL2, 0);
+            mu_ *= nu_;                                                                       // :3969-3974
+            {
+                const int nu2 = (int)((unsigned)nu_ << 1);
+                if (nu2 <= nu_ || !std::isfinite(mu_)) { stop_ = 6; ret = 2; break; }
+                nu_ = nu2;
+            }
+            if (trials_ >= cfg.itmax) { stop_ = 3; ret = 2; break; }
+            ret = 0;
+        } while (false);
+        timing.step_ms += now_ms() - t0; timing.steps += 1;
+        return ret;
+    }
     do {
         if (eab_inf_ <= eps1 && stops) { dp_L2_ = 0.0; stop_ = 1; ret = 2; break; }          // :1117-1121
         if (s[SC_SINGULAR] != 0.0) { push_trace(NAN, 0); goto moredamping; }                 // :1156-1158

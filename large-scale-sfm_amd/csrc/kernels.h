@@ -28,6 +28,7 @@ struct ModelCfg {
     int nk;             // radial coefficients that are parameters with undistort == 1: 1 (k1) or 2 (k1, k2: Bundler, sfm.c:648-649)
     int split;          // 9 camera parameters: camera j is rows 2j (parameters 0-7) and 2j + 1 (parameter 8) of every camera-side array
     int points_fixed;   // motion-only bundle: B_ij := 0 (sba_mot_levmar_x has no structure block)
+    int damp_diag;      // PBA's damping: U* = U + mu diag(U), V* = V + mu diag(V) (SparseBundleCPU.cpp:1813-1814) instead of sba's + mu I
     double proj_sign, f_scale, k_scale;
 };
 
@@ -155,6 +156,7 @@ struct PcgArgs {
     int m, ng, nwg, it;                                // ng = ceil(m / 8) (k_pcg_init); product kernels: nwg = m (one block row per
                                                        // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
     int wpr;                                           // nwg = ceil(m / 4): wavefronts per block row, 1 or 2 (long rows)
+    int minit;                                         // the tolerance test counts from this iteration on (PBA: __cg_min_iteration)
     CoarseArgs co;                                     // co.ng == 0: plain block-Jacobi
 };
 
@@ -166,7 +168,8 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg,
                      bool reduce_now /* false: the camera-side sums are taken by launch_reduce_final at the end of the trial */,
-                     const PcgStart &ps, const CoarseArgs &co /* co.ng != 0: also Z'SZ, its inverse, S~Z~ */, const int *bsr_row);
+                     const PcgStart &ps, const CoarseArgs &co /* co.ng != 0: also Z'SZ, its inverse, S~Z~ */, const int *bsr_row,
+                     bool damp_diag /* PBA's damping: + mu diag(U) */);
 void launch_pcg_init(hipStream_t st, const PcgArgs &a);  // w_0 = S~ r_0 and the first partials (r_0: k_block_inv)
 void launch_pcg_reinit(hipStream_t st, const PcgArgs &a); // r_0, x~_0 again, for a second solve on the same linearisation
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a); // iteration a.it: one launch

@@ -226,7 +226,7 @@ __device__ __forceinline__ CamDelta cam_delta(const ModelCfg &cfg, const double 
 
 template <int CNP, bool FULL>
 __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *__restrict__ cl, const CamDelta &cd, const double X[3], double2 xy,
-                                            double e[2], double t[3])
+                                            double e[2], double t[3], double bd[3])
 {
     double q[3], qr[3];
     const bool md = FULL && cfg.undistort == 2;
@@ -269,12 +269,13 @@ __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *_
             if (FULL) w[r] = fma(s * f * mr * r2 * r2 / cfg.k_scale, cd.dk2, w[r]);   // zero update unless k2 is a parameter
         }
     }
-    if (cfg.points_fixed) { t[0] = t[1] = t[2] = 0.0; return; }      // a motion-only bundle has no structure block
+    if (cfg.points_fixed) { t[0] = t[1] = t[2] = bd[0] = bd[1] = bd[2] = 0.0; return; }      // a motion-only bundle has no structure block
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const double B0 = Pq[0][0] * cl[c] + Pq[0][1] * cl[3 + c] + Pq[0][2] * cl[6 + c];
         const double B1 = Pq[1][0] * cl[c] + Pq[1][1] * cl[3 + c] + Pq[1][2] * cl[6 + c];
         t[c] = B0 * w[0] + B1 * w[1];
+        bd[c] = fma(B1, B1, B0 * B0);                                  // this observation's share of diag V_i (PBA's damping metric)
     }
 }
 
@@ -661,11 +662,12 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
             }
             maxdv = fmax(maxdv, fmax(v00, fmax(v11, v22)));
             ebinf = fmax(ebinf, fmax(fabs(eb0), fmax(fabs(eb1), fabs(eb2))));
-            v00 += mu_lin; v11 += mu_lin; v22 += mu_lin;
+            if (cfg.damp_diag) { v00 = fma(mu_lin, v00, v00); v11 = fma(mu_lin, v11, v11); v22 = fma(mu_lin, v22, v22); }
+            else { v00 += mu_lin; v11 += mu_lin; v22 += mu_lin; }
             const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
             const double det = v00 * c00 + v01 * c01 + v02 * c02;
             double i00 = 0, i01 = 0, i02 = 0, i11 = 0, i12 = 0, i22 = 0;
-            if (det == 0.0 || !isfinite(det)) sing = 1.0; // "singular matrix V*_i, increasing damping", :1156-1158
+            if (det == 0.0 || !isfinite(det)) { if (!(cfg.points_fixed && cfg.damp_diag)) sing = 1.0; } // "singular matrix V*_i, increasing damping", :1156-1158 (motion only with PBA's damping: V = 0 on purpose)
             else {
                 const double id = 1.0 / det;
                 i00 = c00 * id; i01 = c01 * id; i02 = c02 * id;
@@ -860,11 +862,12 @@ __global__ __launch_bounds__(256) void k_long_reduce(const LongArgs g)
         }
         double v00 = v[0], v01 = v[1], v02 = v[2], v11 = v[3], v12 = v[4], v22 = v[5];
         const double maxdv = fmax(v00, fmax(v11, v22)), ebinf = fmax(fabs(v[6]), fmax(fabs(v[7]), fabs(v[8])));
-        v00 += mu_lin; v11 += mu_lin; v22 += mu_lin;
+        if (g.cfg.damp_diag) { v00 = fma(mu_lin, v00, v00); v11 = fma(mu_lin, v11, v11); v22 = fma(mu_lin, v22, v22); }
+        else { v00 += mu_lin; v11 += mu_lin; v22 += mu_lin; }
         const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
         const double det = v00 * c00 + v01 * c01 + v02 * c02;
         double inv[6] = { 0, 0, 0, 0, 0, 0 }, sing = 0.0;
-        if (det == 0.0 || !isfinite(det)) sing = 1.0;
+        if (det == 0.0 || !isfinite(det)) { if (!(g.cfg.points_fixed && g.cfg.damp_diag)) sing = 1.0; }
         else {
             const double id = 1.0 / det;
             inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
@@ -1142,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
     const int l = blockIdx.x, ip = g.long_pts[l], tid = threadIdx.x;
     const int os = g.pt_obs[ip], oe = g.pt_obs[ip + 1];
     const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
-    double t3[3] = { 0, 0, 0 };
+    double t3[3] = { 0, 0, 0 }, dv[3] = { 0, 0, 0 };
     using L = RecL<CNP>;
     for (int o = os + tid; o < oe; o += 256) {
         const int j = g.obs_cam[o];
@@ -1153,10 +1156,17 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
 #pragma unroll
         for (int t = 0; t < CNP; ++t) { w0 += row[L::A0 + t] * da[t]; w1 += row[L::A1 + t] * da[t]; }
 #pragma unroll
-        for (int t = 0; t < 3; ++t) t3[t] += row[L::B + t] * w0 + row[L::B + 3 + t] * w1;
+        for (int t = 0; t < 3; ++t) {
+            t3[t] += row[L::B + t] * w0 + row[L::B + 3 + t] * w1;
+            if (g.cfg.damp_diag) dv[t] += row[L::B + t] * row[L::B + t] + row[L::B + 3 + t] * row[L::B + 3 + t];
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) t3[c] = block_sum_256(t3[c], sh);
+    if (g.cfg.damp_diag) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dv[c] = block_sum_256(dv[c], sh);
+    } else dv[0] = dv[1] = dv[2] = 1.0;
     double dl = 0.0, dp2 = 0.0;
     if (tid == 0) {
         const double *po = g.ptout + (size_t)ip * kPtOut;
@@ -1166,8 +1176,8 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
         sX[0] = X[0] + d0; sX[1] = X[1] + d1; sX[2] = X[2] + d2;
         g.pts_new[3 * (size_t)ip] = sX[0]; g.pts_new[3 * (size_t)ip + 1] = sX[1]; g.pts_new[3 * (size_t)ip + 2] = sX[2];
         if (g.dB) { g.dB[3 * (size_t)ip] = d0; g.dB[3 * (size_t)ip + 1] = d1; g.dB[3 * (size_t)ip + 2] = d2; }
-        dl = d0 * (g.mu * d0 + po[9]) + d1 * (g.mu * d1 + po[10]) + d2 * (g.mu * d2 + po[11]);
-        dp2 = d0 * d0 + d1 * d1 + d2 * d2;
+        dl = d0 * (g.mu * dv[0] * d0 + po[9]) + d1 * (g.mu * dv[1] * d1 + po[10]) + d2 * (g.mu * dv[2] * d2 + po[11]);
+        dp2 = dv[0] * d0 * d0 + dv[1] * d1 * d1 + dv[2] * d2 * d2;
     }
     __syncthreads();
     const double Xn[3] = { sX[0], sX[1], sX[2] };
@@ -1323,6 +1333,7 @@ struct FinalizeArgs {
     const int *rowidx, *col, *src;
     const double *S_up, *cam_cw;
     const double *spec;                             // speculative launch: the damping is spec[1]
+    const double *diagU;                            // PBA's damping: mu diag(U_j) on the diagonal (camvec section 2), nullptr: mu
     CamLinks lk;
 };
 
@@ -1335,7 +1346,7 @@ __device__ __forceinline__ double finalized_element(const FinalizeArgs &f, int b
         v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
         if (r == c && r < f.cnp && f.lk.row)                           // shared-intrinsics links: U_jj += sum w
             for (int q = f.lk.row[j]; q < f.lk.row[j + 1]; ++q) v += f.lk.w[(size_t)q * kCP + r];
-        if (r == c) v = (r < f.cnp) ? v + (f.spec ? f.spec[1] : f.mu) + f.cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
+        if (r == c) v = (r < f.cnp) ? v + (f.spec ? f.spec[1] : f.mu) * (f.diagU ? f.diagU[j * 8 + r] : 1.0) + f.cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
         if (f.fixed[j]) v = (r == c) ? 1.0 : 0.0;
     } else {
         v = f.trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
@@ -1385,6 +1396,7 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
             if (live && (add != 0.0 || dadd != 0.0)) {
                 ea += add; Ev += add; du += dadd;
                 camvec[gid] = ea;                             // k_cam_update reads ea for dL
+                camvec[2 * (size_t)m * kCP + gid] = du;       // ... and diag U for PBA's damping (finalized_element) and its dL
             }
         }
         E[gid] = live ? Ev : 0.0;
@@ -1503,11 +1515,14 @@ __device__ __forceinline__ double wave_total(const double *__restrict__ v, int n
     return wave_sum(s);
 }
 
+// before iteration minit (PBA's __cg_min_iteration) only a residual at rounding level ends the solve (a block-diagonal system is
+// solved exactly by the first step: going on would divide by p'S~p = 0)
+constexpr double kPcgFloor = 1e-10;
 __device__ __forceinline__ bool pcg_converged(const PcgArgs &a, double rz_it)
 {
     const double rz0 = a.rz_hist[0];
     if (!(rz0 > 0.0)) return true;
-    return sqrt(fabs(rz_it) / rz0) < a.tol;
+    return sqrt(fabs(rz_it) / rz0) < (a.it >= a.minit ? a.tol : fmin(a.tol, kPcgFloor));
 }
 
 // r_0 = E~ = Linv E, x~_0 = 0 on its own (k_block_inv does this as part of a linear phase; a second solve on the same
@@ -1952,7 +1967,7 @@ __global__ __launch_bounds__(320) void k_pcg2_iter(const PcgArgs a)
     const double gamma = wave_sum(gs), delta = wave_sum(ds);           // gamma = r.z, delta = w.z (w = S~ z)
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (first) a.rz_hist[a.it] = gamma;
-    const bool conv = a.it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < a.tol);
+    const bool conv = a.it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < (a.it >= a.minit ? a.tol : fmin(a.tol, kPcgFloor)));
     if (conv) {
         if (first) a.scal[SC_PCG_DONE] = 1.0;
         return;
@@ -2067,7 +2082,7 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
     const double gamma = kOwn ? wave_sum(gs) : sgd[0], delta = kOwn ? wave_sum(ds) : sgd[1];
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (first) a.rz_hist[a.it] = gamma;
-    const bool conv = a.it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < a.tol);
+    const bool conv = a.it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < (a.it >= a.minit ? a.tol : fmin(a.tol, kPcgFloor)));
     if (conv) {
         if (first) a.scal[SC_PCG_DONE] = 1.0;
         return;
@@ -2135,8 +2150,9 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
                 const double d = live ? dj : 0.0;
                 const double a_new = cam_a[v * kCP + r] + d;
                 cam_a_new[v * kCP + r] = a_new;
-                dl += d * (mu * d + camvec[v * kCP + r]);
-                dp2 += d * d;
+                const double D = cfg.damp_diag ? camvec[(2 * (size_t)(cfg.split ? 2 * m : m) + v) * kCP + r] : 1.0;   // PBA: dL = d'(mu D d + g), |d|^2 in D's metric
+                dl += d * (mu * D * d + camvec[v * kCP + r]);
+                dp2 += D * d * d;
                 if (row == 0) an[r] = a_new; else if (r == 0) an[8] = a_new;
             }
         }
@@ -2165,7 +2181,7 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
 template <int CNP, bool FULL>
 __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
 {
-    __shared__ double sT[kWave * 3], sX[kMaxPtsBatch * 3];
+    __shared__ double sT[kWave * 3], sX[kMaxPtsBatch * 3], sD[kWave * 3];
     __shared__ int sStart[kMaxPtsBatch + 1];
     if (g.scal[SC_PCG_FINAL] == 0.0) return;   // launched ahead of the host's look at the reduced solve (engine.cpp solve_phase)
     const int lane = threadIdx.x;
@@ -2229,10 +2245,14 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
                 cd = cam_delta(cfg, cl, da, g.cam_fixed[j] != 0, FULL);
                 jc = j;
             }
-            double t[3];
-            backsub_obs<CNP, FULL>(cfg, cl, cd, X, xy, e, t);
+            double t[3], bd[3];
+            backsub_obs<CNP, FULL>(cfg, cl, cd, X, xy, e, t, bd);
 #pragma unroll
             for (int c = 0; c < 3; ++c) sT[lane * 3 + c] = t[c];
+            if (cfg.damp_diag) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sD[lane * 3 + c] = bd[c];
+            }
         }
         wave_lds_sync();
         if (head) { // the head lane of a point owns the point: it already holds X and the ptout row
@@ -2247,8 +2267,13 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
             g.pts_new[3 * (size_t)ip] = X0; g.pts_new[3 * (size_t)ip + 1] = X1; g.pts_new[3 * (size_t)ip + 2] = X2;
             if (g.dB) { g.dB[3 * (size_t)ip] = d0; g.dB[3 * (size_t)ip + 1] = d1; g.dB[3 * (size_t)ip + 2] = d2; }
             sX[lp * 3] = X0; sX[lp * 3 + 1] = X1; sX[lp * 3 + 2] = X2;
-            dl += d0 * (g.mu * d0 + h2e0.y) + d1 * (g.mu * d1 + e12.x) + d2 * (g.mu * d2 + e12.y);
-            dp2 += d0 * d0 + d1 * d1 + d2 * d2;
+            double D0 = 1.0, D1 = 1.0, D2 = 1.0;
+            if (cfg.damp_diag) {                                            // PBA: dL and |d|^2 in the metric of diag V_i
+                D0 = D1 = D2 = 0.0;
+                for (int o = lane; o < oe; ++o) { D0 += sD[o * 3]; D1 += sD[o * 3 + 1]; D2 += sD[o * 3 + 2]; }
+            }
+            dl += d0 * (g.mu * D0 * d0 + h2e0.y) + d1 * (g.mu * D1 * d1 + e12.x) + d2 * (g.mu * D2 * d2 + e12.y);
+            dp2 += D0 * d0 * d0 + D1 * d1 * d1 + D2 * d2 * d2;
         }
         wave_lds_sync();
         if (active) {
@@ -2326,15 +2351,16 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
                      double *E, double *cam_part, double *stage, double *scal, double *Linv, double *S_pcg, bool reduce_now, const PcgStart &ps,
-                     const CoarseArgs &co, const int *bsr_row)
+                     const CoarseArgs &co, const int *bsr_row, bool damp_diag)
 {
     FinalizeArgs f;
     f.cnp = cnp; f.mu = mu; f.spec = spec; f.fixed = fixed; f.pfix = pfix; f.trans = bsr_trans; f.rowidx = bsr_rowidx; f.col = bsr_col; f.src = bsr_src;
     f.S_up = S_up; f.cam_cw = cam_cw; f.lk = links;
+    f.diagU = damp_diag ? camvec + 2 * (size_t)m * kCP : nullptr;
     const long long total = (long long)nb * 64;
-    if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, pfix, camvec, cam_a, cam_cw, cam_cv,
                        links, E, cam_part);
+    if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
     hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
     hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg);

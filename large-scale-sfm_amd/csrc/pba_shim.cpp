@@ -20,7 +20,9 @@ ConfigBA::ConfigBA()
       __use_radial_distortion(0), __verbose_level(0), __selected_device(0), __bundle_return_code(0), __num_lm_success(0),
       __num_lm_iteration(0), __initial_mse(0), __final_mse(0), __focal_normalize(true), __depth_normalize(true), __depth_degeneracy_fix(true),
       __honour_data_normalize(false), __data_normalize_median(0.5f), __depth_check_epsilon(0.01f), __focal_scaling(1.0f), __depth_scaling(1.0f),
-      __num_point_behind(0), __num_camera_modified(0)
+      __num_point_behind(0), __num_camera_modified(0), __lm_initial_damp(1e-3f), __lm_minimum_damp(1e-10f), __lm_maximum_damp(1e+5f),
+      __lm_delta_threshold(1e-6f), __lm_gradient_threshold(1e-10f), __lm_damping_auto_switch(0), __lm_use_diagonal_damp(true),
+      __lm_check_gradient(false), __cg_min_iteration(10)
 {
     __output_param[0] = 0;
 }
@@ -41,6 +43,14 @@ void ConfigBA::ParseParam(int argc, char **argv)
         else if (!std::strcmp(a, "-moti")) __bundle_mode_next = 1;
         else if (!std::strcmp(a, "-stru")) __bundle_mode_next = 2;
         else if (!std::strcmp(a, "-cgi") && v) { __cg_max_iteration = std::atoi(v); ++i; }
+        else if (!std::strcmp(a, "-cgim") && v) { if (std::atoi(v) > 0) __cg_min_iteration = std::atoi(v); ++i; }        // ConfigBA.cpp:376-413
+        else if (!std::strcmp(a, "-lmd") && v) { if (std::atof(v) >= 0) __lm_delta_threshold = (float)std::atof(v); ++i; }
+        else if (!std::strcmp(a, "-lmg") && v) { if (std::atof(v) > 0) __lm_gradient_threshold = (float)std::atof(v); ++i; }
+        else if (!std::strcmp(a, "-damp") && v) { if (std::atof(v) > 0) __lm_initial_damp = (float)std::atof(v); ++i; }
+        else if (!std::strcmp(a, "-dmin") && v) { if (std::atof(v) > 0) __lm_minimum_damp = (float)std::atof(v); ++i; }
+        else if (!std::strcmp(a, "-dmax") && v) { if (std::atof(v) > 0) __lm_maximum_damp = (float)std::atof(v); ++i; }
+        else if (!std::strcmp(a, "-id")) __lm_use_diagonal_damp = false;                                              // :473-482
+        else if (!std::strcmp(a, "-chkg")) __lm_check_gradient = true;
         else if (!std::strcmp(a, "-cgn") && v) { __cg_norm_threshold = (float)std::atof(v); ++i; }
         else if (!std::strcmp(a, "-dev") && v) { __selected_device = std::atoi(v); ++i; }
         else if (!std::strcmp(a, "-out") && v) { std::snprintf(__output_param, sizeof(__output_param), "%s", v); ++i; }
@@ -125,6 +135,19 @@ int ParallelBA::RunBundleAdjustment()
     cfg.itmax = c.__lm_max_iteration;
     cfg.opts[5] = 0.0;                     // Bundler's "residuals changed by < 4 %" exit (stop 8) is not a PBA rule
     cfg.pcg_maxit = c.__cg_max_iteration; cfg.pcg_tol = c.__cg_norm_threshold;
+    // PBA's own Levenberg-Marquardt (NonlinearOptimizeLM, SparseBundleCPU.cpp:3797-3983) unless MI_PBA_SBA_LM=1 asks for sba's:
+    // damping on the diagonals started at __lm_initial_damp, its accept rule, gain ratio, damping bounds, step and gradient
+    // stops, the iteration cap counting trials, the CG's minimum iteration count (mi_ba.h lm_variant)
+    const char *sba_lm = std::getenv("MI_PBA_SBA_LM");
+    if (!(sba_lm && sba_lm[0] == '1')) {
+        cfg.lm_variant = c.__lm_use_diagonal_damp ? 1 : 2;
+        cfg.opts[0] = c.__lm_initial_damp;
+        cfg.opts[1] = c.__lm_check_gradient ? c.__lm_gradient_threshold : 0.0;
+        cfg.opts[2] = c.__lm_delta_threshold;
+        cfg.opts[3] = c.__lm_minimum_damp;
+        cfg.opts[4] = (c.__lm_damping_auto_switch == 0 && c.__lm_use_diagonal_damp) ? c.__lm_maximum_damp : 0.0;   // :3950
+        cfg.pcg_minit = c.__cg_min_iteration;
+    }
     cfg.device = o.device; cfg.verbose = c.__verbose_level >= 3 ? 2 : 0;   // level 2 prints the reference-style lines below, 3 the engine's too
     cfg.mode = c.__bundle_mode_next == 1 ? 1 : c.__bundle_mode_next == 2 ? 2 : 0;        // SetNextBundleMode, pba.h:103
     c.__bundle_mode_next = 0;                                                             // ResetTemporarySetting, ConfigBA.cpp:149-157
@@ -282,6 +305,8 @@ int ParallelBA::RunBundleAdjustment()
         }
         if (st == 2) break;
     }
+    if (c.__verbose_level >= 3)
+        std::printf("[mi_pba] engine stop %d after %d trials, %d successful; |dp|^2 %g, cost %g -> %g\n", (int)info[6], (int)info[9], c.__num_lm_success, info[3], info[0], info[1]);
     c.__bundle_time_budget = 0;          // ResetTemporarySetting, ConfigBA.cpp:149-157
     if (st == MI_BA_ERROR) { std::fprintf(stderr, "[mi_pba] %s\n", mi_ba_last_error(e)); c.__bundle_return_code = 'E'; }
     else if (early) c.__bundle_return_code = early;

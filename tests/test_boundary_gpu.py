@@ -311,6 +311,10 @@ def test_parallelba_against_the_references_own_parallelba(name, pba_mi_client):
         assert np.abs(r["f"] / ref["f"] - 1).max() < 5e-3   # no camera is held and the reference has not converged: loose
         return
     assert abs(rm - rw) <= 1e-4 * rw                   # measured: 7 digits of the MSE agree
+    # PBA's own Levenberg-Marquardt rules behind the plugin (mi_ba.h lm_variant 1): the count of successful iterations that
+    # RunBundleAdjustment() returns stays within two of the reference's (float arithmetic and a CG stopped at 0.1 there; measured:
+    # 7/9, 6/5, 7/6, 5/7, 6/4, 6/4, 3/2 -- under sba's rules the same cases took 12, 14, 15, 10, 10, 9, 2)
+    assert abs(int(r["iters"]) - int(ref["iters"])) <= 2
     nc = kw["nconst"]
     if nc:                                             # constant cameras are untouched
         assert np.array_equal(r["f"][:nc], ref["f"][:nc]) and np.array_equal(r["t"][:nc], ref["t"][:nc])

@@ -12,10 +12,12 @@ def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def reduced_system(lin, sc, mu, mcon=0):
-    """S(mu), E(mu), Vinv from the oracle's undamped blocks (numpy, dense)."""
+def reduced_system(lin, sc, mu, mcon=0, damp_diag=False):
+    """S(mu), E(mu), Vinv from the oracle's undamped blocks (numpy, dense).  damp_diag: PBA's damping, mu diag(U), mu diag(V),
+    instead of sba's mu I"""
     m, n, cnp = sc.m, sc.n, sc.cnp
-    Vinv = np.linalg.inv(lin["V"] + mu * np.eye(3))
+    dV = np.einsum("iaa->ia", lin["V"])[:, :, None] * np.eye(3) if damp_diag else np.eye(3)
+    Vinv = np.linalg.inv(lin["V"] + mu * dV)
     N = m * cnp
     S = np.zeros((N, N)); E = lin["ea"].copy().reshape(-1)
     pt = sc.obs_pt()
@@ -29,7 +31,7 @@ def reduced_system(lin, sc, mu, mcon=0):
                 jb = sc.obs_cam[b]
                 S[ja * cnp:(ja + 1) * cnp, jb * cnp:(jb + 1) * cnp] -= Y[a] @ lin["W"][b].T
     for j in range(m):
-        S[j * cnp:(j + 1) * cnp, j * cnp:(j + 1) * cnp] += lin["U"][j] + mu * np.eye(cnp)
+        S[j * cnp:(j + 1) * cnp, j * cnp:(j + 1) * cnp] += lin["U"][j] + mu * (np.diag(np.diag(lin["U"][j])) if damp_diag else np.eye(cnp))
     return S, E, Vinv
 
 
@@ -83,6 +85,73 @@ def test_solve_and_backsubstitution(oracle, name):
     p_new = sc.p0 + np.concatenate([da.reshape(-1), db.reshape(-1)])
     want = oracle.cost(sc, p_new)
     assert abs(g["cost_new"] - want) < 1e-7 * want
+
+
+PBA_OPTS = (1e-3, 0.0, 1e-6, 1e-10, 1e5, 0.0)    # __lm_initial_damp, (no gradient test), __lm_delta_threshold, damping bounds (ConfigBA.cpp:44-53)
+
+
+@pytest.mark.parametrize("name", ["micro", "C1", "C1t"])
+def test_pba_damping_reduced_system_and_step(oracle, name):
+    """mi_ba_config.lm_variant = 1: PBA's damping on the diagonals (SparseBundleCPU.cpp:1813-1814).  The reduced system, its
+    solution, the back-substituted points and the predicted decrease d'(mu D d + g) against dense numpy on the oracle's blocks"""
+    sc, z = scene_from_golden(name)
+    eng = make_engine(sc, pcg_tol=1e-13, pcg_maxit=400, lm_variant=1, opts=PBA_OPTS)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 0.05
+    g1 = eng.debug_linearize(mu)
+    S, E, Vinv = reduced_system(lin, sc, mu, damp_diag=True)
+    assert rel(g1["S"], S) < 1e-10 and rel(g1["E"].reshape(-1), E) < 1e-9
+    g = eng.debug_solve(mu)
+    da = np.linalg.solve(S, E).reshape(sc.m, sc.cnp)
+    assert rel(g["da"], da) < 1e-7
+    t = np.zeros((sc.n, 3))
+    np.add.at(t, sc.obs_pt(), np.einsum("oab,oa->ob", lin["W"], da[sc.obs_cam]))
+    db = np.einsum("iab,ib->ia", Vinv, lin["eb"] - t)
+    assert rel(g["db"], db) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["C1", "C1t"])
+def test_pba_controller_trajectory(oracle, name):
+    """lm_variant = 1 end to end: PBA's loop (SparseBundleCPU.cpp:3843-3976) replayed in numpy on dense solves of the oracle's
+    blocks -- damping from __lm_initial_damp, accept on any decrease, gain ratio over d'(mu D d + g), mu max(1/3, 1-(2 rho-1)^3),
+    the step stop in D's metric -- against the engine's trace trial by trial"""
+    sc, z = scene_from_golden(name)
+    eng = make_engine(sc, pcg_tol=1e-13, pcg_maxit=400, pcg_minit=10, lm_variant=1, opts=PBA_OPTS, itmax=30)
+    ret, info = eng.run()
+    tr = eng.trace()
+    p = sc.p0.copy(); m, n, cnp = sc.m, sc.n, sc.cnp
+    mu, nu = PBA_OPTS[0], 2.0
+    cost = oracle.cost(sc, p)
+    rows = []
+    for trial in range(30):
+        lin = oracle.linearize(sc, fd_jacobian=0, p=p)
+        S, E, Vinv = reduced_system(lin, sc, mu, damp_diag=True)
+        da = np.linalg.solve(S, E).reshape(m, cnp)
+        t = np.zeros((n, 3)); np.add.at(t, sc.obs_pt(), np.einsum("oab,oa->ob", lin["W"], da[sc.obs_cam]))
+        db = np.einsum("iab,ib->ia", Vinv, lin["eb"] - t)
+        DU = np.einsum("jaa->ja", lin["U"]); DV = np.einsum("iaa->ia", lin["V"])
+        dn2 = (DU * da * da).sum() + (DV * db * db).sum()
+        if np.sqrt(dn2) <= PBA_OPTS[2]:
+            break
+        dL = (da * (mu * DU * da + lin["ea"])).sum() + (db * (mu * DV * db + lin["eb"])).sum()
+        p_new = p + np.concatenate([da.reshape(-1), db.reshape(-1)])
+        c_new = oracle.cost(sc, p_new)
+        ok = c_new < cost
+        rows.append((mu, cost, c_new, ok))
+        if ok:
+            rho = (cost - c_new) / dL
+            p, cost = p_new, c_new
+            mu = max(mu * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), PBA_OPTS[3]); nu = 2.0
+        else:
+            mu *= nu; nu *= 2.0
+    rows = np.array(rows, dtype=float)
+    k = min(len(rows), len(tr))
+    decided = np.abs(rows[:k, 2] - rows[:k, 1]) > 1e-10 * rows[:k, 1]      # (at the minimum the sign of a rounding-level change decides,
+    kk = k if decided.all() else int(np.argmin(decided)) + 1               #  and the two runs part ways after such a trial)
+    assert kk >= 4
+    assert np.allclose(tr[:kk, 1], rows[:kk, 0], rtol=1e-6) and np.allclose(tr[:kk, 3], rows[:kk, 2], rtol=1e-8)
+    assert np.array_equal(tr[:kk, 4][decided[:kk]], rows[:kk, 3][decided[:kk]])
+    assert info[6] == 2 or not decided.all()                   # "quit on too small change"
 
 
 @pytest.mark.parametrize("name", ["micro", "C1", "C1t"])
