@@ -13,9 +13,11 @@
 #include <iomanip>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -769,6 +771,39 @@ int mi_optimizer_all_main(int argc, char **argv)
             kids.push_back(pid);
         }
         RankCtx ctx{ sh, rank };
+        // Watchdog, one thread per rank (started after the forks): a rank that dies inside the solve -- GPU fault, out of memory --
+        // would leave the others in ncclAllReduce / the host arena's barrier and the stage program that ran optimizer_all hanging.
+        // Rank 0 polls its children, the children their parent and the shared failure word; a failure seen, the normal error path
+        // gets two seconds to report, then the rank leaves with a non-zero status (rank 0 after ending its children).
+        std::atomic<int> solve_over{ 0 };
+        std::vector<int> kid_status(kids.size(), -1);           // -1 running, else the exit status the watchdog reaped
+        const pid_t parent = getppid();
+        std::thread watchdog([&, rank]() {
+            int failed_for = 0;
+            while (!solve_over.load()) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                if (rank == 0) {
+                    for (size_t k = 0; k < kids.size(); ++k) {
+                        int st = 0;
+                        if (kid_status[k] >= 0 || waitpid(kids[k], &st, WNOHANG) != kids[k]) continue;
+                        kid_status[k] = (WIFEXITED(st) && WEXITSTATUS(st) == 0) ? 0 : 1;
+                        if (kid_status[k] && !solve_over.load()) sh->failed.store(1);
+                    }
+                } else if (getppid() != parent) sh->failed.store(1);
+                if (!sh->failed.load()) continue;
+                if (++failed_for < 40) continue;                // 2 s for the rank's own error path
+                if (solve_over.load()) break;
+                std::fprintf(stderr, "optimizer_all: rank %d: another rank failed, leaving\n", rank);
+                std::fflush(stderr);
+                if (rank == 0) for (size_t k = 0; k < kids.size(); ++k) if (kid_status[k] < 0) kill(kids[k], SIGKILL);
+                std::_Exit(1);
+            }
+        });
+        if (const char *die = std::getenv("MI_BA_TEST_RANK_DIES")) {   // test hook "rank:milliseconds": that rank ends abruptly
+            int r = -1, ms = 0;
+            if (std::sscanf(die, "%d:%d", &r, &ms) == 2 && r == rank)
+                std::thread([ms]() { std::this_thread::sleep_for(std::chrono::milliseconds(ms)); std::_Exit(3); }).detach();
+        }
         cfg.rank = rank; cfg.world = world;
         if (!host_transport) cfg.device += rank;
         if (rank != 0) cfg.verbose = 0;
@@ -785,14 +820,17 @@ int mi_optimizer_all_main(int argc, char **argv)
         }
         if (ok) it = mi_model_optimize_shard(m, &cfg, info, &shard);
         if (it == MI_BA_ERROR) sh->failed.store(1);
+        solve_over.store(1);
+        watchdog.join();
         if (rank != 0) {
             if (it == MI_BA_ERROR) std::fprintf(stderr, "optimizer_all: rank %d: %s\n", rank, g_err.empty() ? "another rank failed" : g_err.c_str());
             std::fflush(stderr);
             std::_Exit(it == MI_BA_ERROR ? 1 : 0); // the answer is rank 0's to write
         }
-        for (pid_t pid : kids) {
+        for (size_t k = 0; k < kids.size(); ++k) {
             int st = 0;
-            if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { if (it != MI_BA_ERROR) g_err = "a rank ended abnormally"; it = MI_BA_ERROR; }
+            const bool bad = kid_status[k] >= 0 ? kid_status[k] != 0 : (waitpid(kids[k], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0);
+            if (bad) { if (it != MI_BA_ERROR) g_err = "a rank ended abnormally"; it = MI_BA_ERROR; }
         }
         munmap(mem, bytes);
         if (it != MI_BA_ERROR) std::printf("optimizer_all: %d ranks, %s\n", world, host_transport ? "host all-reduce on one GPU" : "RCCL all-reduce, one GPU each");

@@ -474,6 +474,25 @@ def test_config_c5_merged_clusters_global_refine(tmp_path, oracle):
     assert np.abs(mdl3["xyz"] - mdl["xyz"]).max() < 1e-5 and np.abs(mdl3["t"] - mdl["t"]).max() < 1e-5 and np.abs(mdl3["f"] - mdl["f"]).max() < 1e-3
 
 
+def test_a_rank_that_dies_takes_the_whole_run_down_quickly(tmp_path):
+    """a rank ending abruptly in the middle of a sharded solve (GPU fault, out of memory) must not leave the other ranks waiting in
+    the exchange and the stage program that ran optimizer_all hanging: every rank's watchdog sees it, rank 0 ends the children
+    and exits non-zero, the model file is left alone.  (MI_BA_TEST_RANK_DIES = "rank:milliseconds" is the test hook.)"""
+    import time
+    sc = vsfm_scene(m=40, n=20000, d=6, seed=9)
+    d = tmp_path / "c"; d.mkdir()
+    nvm = str(d / "outputVSFM_GB.nvm")
+    write_nvm(nvm, sc)
+    before = open(nvm).read()
+    exe = os.path.join(ROOT, "large-scale-sfm_amd", "bin", "optimizer_all")
+    t0 = time.time()
+    out = subprocess.run([exe, str(d) + "/", "0", "300", "16", "32", "0.5", "0"], capture_output=True, text=True, timeout=120,
+                         env={**os.environ, "MI_BA_GPUS": "3", "MI_BA_TRANSPORT": "host", "MI_BA_TEST_RANK_DIES": "2:1"})
+    assert out.returncode != 0 and time.time() - t0 < 60
+    assert "optimizer_all:" in out.stderr
+    assert open(nvm).read() == before
+
+
 def test_two_clusters_aligned_merged_and_refined(tmp_path):
     """the cluster-merge flow end to end on the GPU (Merge3D3D.cpp:564-904): two sub-reconstructions of one scene, the second
     in its own similarity frame; their common points give scale, R, t (mi_sim3_align); the second cluster's cameras and
