@@ -115,3 +115,56 @@ def test_tiny_problems(oracle, m, n, d):
     # so compare where the cost ends up, not how many trials it took
     assert abs(info[1] - o["info"][1]) < 1e-6 * max(o["info"][1], 1e-12) or abs(np.sqrt(info[1] / sc.nobs) - np.sqrt(o["info"][1] / sc.nobs)) < 1e-6
     assert abs(oracle.cost(sc, eng.packed_params()) - info[1]) < 1e-9 * max(info[1], 1e-12)
+
+
+@pytest.mark.parametrize("case", [0, 3, 5])
+def test_pba_damping_on_ragged_scenes(oracle, case, monkeypatch):
+    """mi_ba_config.lm_variant = 1 (PBA's damping on the diagonals, its gain ratio in the metric of diag J'J) where every kind of
+    tile, the row path and tracks longer than a wavefront take part: reduced system, solution, back-substitution and the first
+    trials of the controller against dense numpy on the oracle's blocks"""
+    from test_engine_gpu import PBA_OPTS, reduced_system, rel
+    monkeypatch.setenv("MI_BA_MIN_RUN_PTS", "2")
+    est_focal, undistort, explicit_centers, proj_sign, mode, mcon, cons = CASES[case]
+    rng = np.random.default_rng(5000 + case)
+    sc = ragged_scene(rng, m=90, n=1200, est_focal=est_focal, undistort=undistort, explicit_centers=explicit_centers,
+                      proj_sign=proj_sign, dmax=80)
+    capi = pkg("capi")
+    eng = capi.Engine(capi.default_config(est_focal=est_focal, undistort=undistort, explicit_centers=explicit_centers,
+                                          proj_sign=proj_sign, pcg_tol=1e-13, pcg_maxit=490, pcg_minit=10, lm_variant=1, opts=PBA_OPTS, itmax=6))
+    eng.load_scene(sc)
+    eng.prepare()
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 0.02
+    g1 = eng.debug_linearize(mu)
+    S, E, Vinv = reduced_system(lin, sc, mu, damp_diag=True)
+    assert rel(g1["S"], S) < 1e-10 and rel(g1["E"].reshape(-1), E) < 1e-9
+    g = eng.debug_solve(mu)
+    da = np.linalg.solve(S, E).reshape(sc.m, sc.cnp)
+    assert rel(g["da"], da) < 1e-6
+    t = np.zeros((sc.n, 3))
+    np.add.at(t, sc.obs_pt(), np.einsum("oab,oa->ob", lin["W"], da[sc.obs_cam]))
+    db = np.einsum("iab,ib->ia", Vinv, lin["eb"] - t)
+    assert rel(g["db"], db) < 1e-6
+    # the controller's first trials: damping schedule and trial costs (the gain ratio's denominator is d'(mu D d + g))
+    ret, info = eng.run()
+    tr = eng.trace()
+    p = sc.p0.copy(); mu, nu = PBA_OPTS[0], 2.0
+    cost = oracle.cost(sc, p)
+    for k in range(min(4, len(tr))):
+        lin = oracle.linearize(sc, fd_jacobian=0, p=p)
+        S, E, Vinv = reduced_system(lin, sc, mu, damp_diag=True)
+        da = np.linalg.solve(S, E).reshape(sc.m, sc.cnp)
+        t = np.zeros((sc.n, 3)); np.add.at(t, sc.obs_pt(), np.einsum("oab,oa->ob", lin["W"], da[sc.obs_cam]))
+        db = np.einsum("iab,ib->ia", Vinv, lin["eb"] - t)
+        DU = np.einsum("jaa->ja", lin["U"]); DV = np.einsum("iaa->ia", lin["V"])
+        dL = (da * (mu * DU * da + lin["ea"])).sum() + (db * (mu * DV * db + lin["eb"])).sum()
+        p_new = p + np.concatenate([da.reshape(-1), db.reshape(-1)])
+        c_new = oracle.cost(sc, p_new)
+        assert abs(tr[k, 1] - mu) < 1e-6 * mu and abs(tr[k, 3] - c_new) < 1e-7 * c_new
+        assert bool(tr[k, 4]) == (c_new < cost)
+        if c_new < cost:
+            rho = (cost - c_new) / dL
+            p, cost = p_new, c_new
+            mu = max(mu * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), PBA_OPTS[3]); nu = 2.0
+        else:
+            mu *= nu; nu *= 2.0
