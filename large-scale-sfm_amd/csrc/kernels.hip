@@ -464,7 +464,7 @@ __device__ __forceinline__ void pair_block(const double *sR, const double *sv, i
 // the end of the tile, for tiles whose points keep changing camera set (plan.h kTableRuns); the register scheme would
 // flush to HBM almost every round there and the L2's f64 atomic rate (~120 G elements/s) would be the bound
 template <int CNP, bool LDS, bool FULL, bool TABLE>
-__global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_build(const BuildArgs g) // 8x8 blocks: 128 accumulator VGPRs, one wave per SIMD
+__global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_build(const BuildArgs g) // two wavefronts per SIMD (98 accumulator VGPRs, <= 20 KB of LDS) up to 7 parameters; 8x8 blocks: 128 accumulator VGPRs, one
 {
     if constexpr (LDS) { if (g.tile_mode[g.tile0 + blockIdx.x] != (TABLE ? 2 : 1)) return; }
     if (g.spec && g.spec[0] == 0.0) return;   // enqueued ahead of the host's decision, and the trial was not accepted
