@@ -66,10 +66,12 @@ typedef struct {
      * ParallelBA::BUNDLE_ONLY_MOTION), 2: points only, cameras fixed (sba_str_levmar, sba.h:118-123;
      * BUNDLE_ONLY_STRUCTURE) */
     int mode;
-    /* 1: no floating-point atomics in the linear phase -- every point takes the block-major row path (csrc/plan.h), every sum
-     * has a fixed order, two runs give the same bits (the reference is deterministic: sba_levmar.c:1182-1339).  0 (default):
-     * points whose camera set repeats accumulate their blocks in registers and hand them over with f64 atomics (faster on
-     * such scenes; results differ from run to run at rounding level). */
+    /* 0 (default): points whose camera set repeats accumulate their blocks of S in registers and hand them over with f64 atomics;
+     * results differ from run to run at rounding level.  1: the same tiles leave per-tile copies of their blocks and camera
+     * vectors instead, and a second kernel sums the copies in tile order (csrc/kernels.hip k_tile_reduce_*): no floating-point
+     * atomics anywhere, every sum has a fixed order, two runs give the same bits (the reference is deterministic:
+     * sba_levmar.c:1182-1339) -- at about the speed of 0.  2: every point takes the block-major row path (csrc/plan.h),
+     * round 2's first deterministic mode (4x slower on scenes whose camera sets repeat; what nine-parameter cameras always use). */
     int deterministic;
     /* radial coefficients that are parameters with undistort == 1: 1 (default; 0 means 1) = k1, 2 = k1 and k2, Bundler's full
      * model (sfm.c:360-373, 648-649).  With the focal length that is NINE camera parameters (cnp 9): the engine then keeps camera j

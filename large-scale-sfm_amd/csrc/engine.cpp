@@ -238,7 +238,7 @@ int Engine::prepare()
     }
     if (!h_link_cam_.empty() && cfg.mode == 2) { err = "prepare: camera links make no sense in a structure-only bundle"; return MI_BA_ERROR; }
     std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches,
-                                  h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic != 0, split_);
+                                  h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic == 2, split_);
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
     const Plan &pl = plan_;
 #define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
@@ -264,6 +264,23 @@ int Engine::prepare()
         std::vector<double2> xy(nol);
         for (int64_t o = 0; o < nol; ++o) { xy[o].x = h_xy_[2 * pl.obs_src[o]]; xy[o].y = h_xy_[2 * pl.obs_src[o] + 1]; }
         UP(d_obs_xy_, xy);
+    }
+    if (cfg.deterministic == 1 && pl.ntile_lds > 0) {   // ordered hand-over: who contributes to every block of S and to every camera, in tile order
+        std::vector<int> bp((size_t)pl.nb_up() + 1, 0), cp((size_t)mv_ + 1, 0);
+        for (int t = 0; t < pl.ntile_lds; ++t) {
+            for (int q = pl.tile_slot[t]; q < pl.tile_slot[t + 1]; ++q) bp[(size_t)pl.slot_gblk[q] + 1]++;
+            for (int q = pl.tile_cslot[t]; q < pl.tile_cslot[t + 1]; ++q) cp[(size_t)pl.cslot_cam[q] + 1]++;
+        }
+        for (size_t i = 0; i + 1 < bp.size(); ++i) bp[i + 1] += bp[i];
+        for (size_t i = 0; i + 1 < cp.size(); ++i) cp[i + 1] += cp[i];
+        std::vector<int> bl((size_t)bp.back()), cl((size_t)cp.back()), bf(bp.begin(), bp.end() - 1), cf(cp.begin(), cp.end() - 1);
+        for (int t = 0; t < pl.ntile_lds; ++t) {
+            for (int q = pl.tile_slot[t]; q < pl.tile_slot[t + 1]; ++q) bl[(size_t)bf[pl.slot_gblk[q]]++] = t * kNSlot + (q - pl.tile_slot[t]);
+            for (int q = pl.tile_cslot[t]; q < pl.tile_cslot[t + 1]; ++q) cl[(size_t)cf[pl.cslot_cam[q]]++] = t * kNCSlot + (q - pl.tile_cslot[t]);
+        }
+        UP(d_tb_ptr_, bp); UP(d_tb_list_, bl); UP(d_tc_ptr_, cp); UP(d_tc_list_, cl);
+        if (!hipok(d_tile_blk_.alloc((size_t)pl.ntile_lds * kNSlot * cnp_cam_() * cnp_cam_()), "alloc per-tile blocks") ||
+            !hipok(d_tile_cam_.alloc((size_t)pl.ntile_lds * kNCSlot * 3 * kCP), "alloc per-tile camera vectors")) return MI_BA_ERROR;
     }
     {   // two-level preconditioner: aggregates of consecutive block rows (whole workgroups of four), their coarse blocks, the band slots
         co_ = CoarseArgs{};
@@ -535,8 +552,11 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
     lin_pair_ = (lin_count_++ & 1) ? 6 : 0;
     if (timing_detail >= 1) (void)hipEventRecord(ev_[lin_pair_], st_);
+    const bool ordered = cfg.deterministic == 1 && pl.ntile_lds > 0;   // per-tile copies + sums in tile order instead of f64 atomics
+    if (ordered) { a.tile_blk = d_tile_blk_.p; a.tile_cam = d_tile_cam_.p; }
     a.tile0 = 0;
     launch_build(st_, cnp, true, pl.ntile_lds, a);
+    if (ordered) launch_tile_reduce(st_, cnp, pl.nb_up(), mv_, d_tb_ptr_.p, d_tb_list_.p, d_tc_ptr_.p, d_tc_list_.p, d_tile_blk_.p, d_tile_cam_.p, S_up_(), camvec_());
     a.tile0 = pl.ntile_lds;
     launch_build(st_, cnp, false, pl.ntile() - pl.ntile_lds, a);
     {

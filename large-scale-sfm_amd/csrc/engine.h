@@ -105,6 +105,8 @@ private:
     bool co_active_ = false;        // the last linear phase built the coarse space: the next solve uses it
     int co_force_ = 0;              // MI_BA_TWO_LEVEL: 0 off (default), 1 from the first trial, -1 once a solve ran long (>= kTwoLevelMinCams cameras)
     DevBuf<int> d_bc_agg_;
+    DevBuf<int> d_tb_ptr_, d_tb_list_, d_tc_ptr_, d_tc_list_;   // ordered hand-over (deterministic = 1): contributors per block of S / per camera
+    DevBuf<double> d_tile_blk_, d_tile_cam_;
     DevBuf<double> d_Ac_, d_Acinv_, d_Bc_, d_U_, d_Lfac_, d_z_, d_cpart_;
     bool cg_start_fresh_ = false;   // the last linear phase's k_block_inv has set up the CG start and no solve has used it yet
     void *comm_ = nullptr; // ncclComm_t

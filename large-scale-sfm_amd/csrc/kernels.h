@@ -85,6 +85,7 @@ struct BuildArgs {
     const double *spec;                     // speculative launch (engine.cpp solve_phase): spec[0] == 0 -> do nothing, else mu = spec[1]; nullptr: mu above
     unsigned long long *dbg;                // diagnostic stamp sums (MIBA_STAMPS build), else NULL
     double *S_up, *camvec, *ptout, *part;   // part: [ntile][kPartW] cost, |X|^2, -, -, |eb|inf, max diag V, singular
+    double *tile_blk, *tile_cam;            // ordered hand-over (deterministic = 1): per-tile copies [ntile][kNSlot][cnp^2], [ntile][kNCSlot][24]; nullptr: f64 atomics into S_up, camvec
     ModelCfg cfg;
 };
 
@@ -163,6 +164,9 @@ struct PcgArgs {
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
                      const double *f_fixed, double *cam_lin);
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);
+// sums of the per-tile copies in tile order (ordered hand-over): S_up blocks and camera vectors
+void launch_tile_reduce(hipStream_t st, int cnp, int nb_up, int m, const int *blk_ptr, const int *blk_list, const int *cam_ptr, const int *cam_list,
+                        const double *tile_blk, const double *tile_cam, double *S_up, double *camvec);
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const double *spec, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full /* or nullptr */,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,

@@ -538,6 +538,7 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
     // wave-collective: every lane hands its register-resident block to HBM.  kStageLanes blocks at a time go
     // through sStage so that ONE global f64 atomic instruction adds ONE contiguous 7x7 block (the full-rate
     // atomic shape); then the accumulators restart from zero.
+    unsigned long long slot_written = 0;      // ordered hand-over: the slots of this tile that hold a block already
     auto flush_blocks = [&]() {
         if constexpr (LDS && !TABLE) {
             const int rr = lane / CNP, cc = lane - rr * CNP;
@@ -552,8 +553,16 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
                 for (int q2 = 0; q2 < kStageLanes && base + q2 < kWave; ++q2) {
                     const int cL = rl(cur_slot, base + q2);
                     if (cL >= 0) {
-                        const int gb = rl(my_gblk, cL);
-                        if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + rr * kCP + cc], sStage[q2 * BLK + lane]);
+                        if (g.tile_blk) {   // ordered hand-over: this tile's own copy of the block, summed over the tiles by k_tile_reduce_blocks
+                            double *dst = g.tile_blk + ((size_t)tile * kNSlot + cL) * BLK;
+                            if (!((slot_written >> cL) & 1ull)) {                        // (uniform) the slot's first block: a plain store
+                                if (lane < BLK) dst[lane] = sStage[q2 * BLK + lane];
+                            } else if (lane < BLK) dst[lane] += sStage[q2 * BLK + lane];    // several lanes of a round held it, or a later flush
+                            slot_written |= 1ull << cL;
+                        } else {
+                            const int gb = rl(my_gblk, cL);
+                            if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + rr * kCP + cc], sStage[q2 * BLK + lane]);
+                        }
                     }
                 }
                 wave_lds_sync();
@@ -781,14 +790,20 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
         if constexpr (TABLE) { // the table goes to HBM once, one contiguous atomic instruction per block
             const int rr = lane / CNP, cc = lane - rr * CNP;
             for (int sl = 0; sl < nslots; ++sl) {
-                const int gb = rl(my_gblk, sl);
-                if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + rr * kCP + cc], sTab[sl * BLK + lane]);
+                if (g.tile_blk) { if (lane < BLK) g.tile_blk[((size_t)tile * kNSlot + sl) * BLK + lane] = sTab[sl * BLK + lane]; }
+                else {
+                    const int gb = rl(my_gblk, sl);
+                    if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + rr * kCP + cc], sTab[sl * BLK + lane]);
+                }
             }
         }
         const int which = lane / CNP, t = lane - which * CNP;
         for (int k = 0; k < ncs; ++k) {
-            const int cam = rl(my_cam, k);
-            if (lane < 3 * CNP) gadd(&g.camvec[((size_t)which * g.m + cam) * kCP + t], sC[k * SC + lane]);
+            if (g.tile_blk) { if (lane < 3 * CNP) g.tile_cam[((size_t)tile * kNCSlot + k) * (3 * kCP) + lane] = sC[k * SC + lane]; }
+            else {
+                const int cam = rl(my_cam, k);
+                if (lane < 3 * CNP) gadd(&g.camvec[((size_t)which * g.m + cam) * kCP + t], sC[k * SC + lane]);
+            }
         }
     }
     STAMP(6); // flush
@@ -801,6 +816,56 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
     if (lane == 0) { // one partial row per tile; k_reduce_partials folds them (no same-address atomics)
         double *pr = g.part + (size_t)tile * kPartW;
         pr[0] = cost; pr[1] = pl2; pr[2] = ccost; pr[3] = 0.0; pr[4] = ebinf; pr[5] = maxdv; pr[6] = sing; pr[7] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Ordered hand-over (mi_ba_config.deterministic = 1): the register and table tiles leave their blocks and camera vectors in
+// per-tile copies (k_build above) instead of adding them to S with f64 atomics; these two kernels sum the copies in tile order --
+// one wavefront per block of S / per camera, the plan's list of (tile, slot) contributors -- so two runs give the same bits.
+// They run before the row path's kernels, which add theirs on top in stream order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_reduce_blocks(int nb_up, int cnp, const int *__restrict__ ptr, const int *__restrict__ list,
+                                                           const double *__restrict__ tile_blk, double *__restrict__ S_up)
+{
+    const int gb = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (gb >= nb_up || lane >= cnp * cnp) return;
+    const int q0 = ptr[gb], q1 = ptr[gb + 1], blk = cnp * cnp;
+    if (q0 == q1) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int q = q0;
+    for (; q + 3 < q1; q += 4) {      // four copies in flight; the order of the sum is fixed all the same
+        const int e0 = list[q], e1 = list[q + 1], e2 = list[q + 2], e3 = list[q + 3];
+        const double v0 = tile_blk[(size_t)e0 * blk + lane], v1 = tile_blk[(size_t)e1 * blk + lane], v2 = tile_blk[(size_t)e2 * blk + lane],
+                     v3 = tile_blk[(size_t)e3 * blk + lane];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; q < q1; ++q) s0 += tile_blk[(size_t)list[q] * blk + lane];
+    const int rr = lane / cnp, cc = lane - rr * cnp;
+    S_up[(size_t)gb * (kCP * kCP) + rr * kCP + cc] = (s0 + s1) + (s2 + s3);
+}
+
+// (cameras: a camera sits in ~60 tiles of C3; the groups of 3 cnp lanes a wavefront holds -- three, two with 8 parameters -- take the
+// copies in turn, two in flight each, and are added up in group order)
+__global__ __launch_bounds__(256) void k_tile_reduce_cams(int m, int cnp, const int *__restrict__ ptr, const int *__restrict__ list,
+                                                         const double *__restrict__ tile_cam, double *__restrict__ camvec)
+{
+    const int cam = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, w = 3 * cnp;
+    if (cam >= m) return;
+    const int q0 = ptr[cam], q1 = ptr[cam + 1];
+    if (q0 == q1) return;
+    const int ngrp = kWave / w, grp = lane / w, el = lane - grp * w;        // 3 groups up to 7 parameters, 2 with 8
+    double s0 = 0.0, s1 = 0.0;
+    if (grp < ngrp) {
+        int q = q0 + grp;
+        for (; q + ngrp < q1; q += 2 * ngrp) { s0 += tile_cam[(size_t)list[q] * (3 * kCP) + el]; s1 += tile_cam[(size_t)list[q + ngrp] * (3 * kCP) + el]; }
+        if (q < q1) s0 += tile_cam[(size_t)list[q] * (3 * kCP) + el];
+    }
+    const double t = s0 + s1;
+    const double t1 = __shfl(t, (lane + w) & 63), t2 = ngrp > 2 ? __shfl(t, (lane + 2 * w) & 63) : 0.0;
+    if (lane < w) {
+        const int which = lane / cnp, k = lane - which * cnp;
+        camvec[((size_t)which * m + cam) * kCP + k] = (t + t1) + t2;
     }
 }
 
@@ -2332,6 +2397,13 @@ static void launch_build_t(hipStream_t st, bool lds_mode, int ntiles, const Buil
         hipLaunchKernelGGL((k_build<CNP, true, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
         if (a.has_table) hipLaunchKernelGGL((k_build<CNP, true, FULL, true>), dim3(ntiles), dim3(64), 0, st, a);
     } else hipLaunchKernelGGL((k_build<CNP, false, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
+}
+
+void launch_tile_reduce(hipStream_t st, int cnp, int nb_up, int m, const int *blk_ptr, const int *blk_list, const int *cam_ptr, const int *cam_list,
+                        const double *tile_blk, const double *tile_cam, double *S_up, double *camvec)
+{
+    if (nb_up > 0) hipLaunchKernelGGL(k_tile_reduce_blocks, dim3((nb_up + 3) / 4), dim3(256), 0, st, nb_up, cnp, blk_ptr, blk_list, tile_blk, S_up);
+    if (m > 0) hipLaunchKernelGGL(k_tile_reduce_cams, dim3((m + 3) / 4), dim3(256), 0, st, m, cnp, cam_ptr, cam_list, tile_cam, camvec);
 }
 
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a)

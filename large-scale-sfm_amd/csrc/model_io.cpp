@@ -740,7 +740,7 @@ int mi_optimizer_all_main(int argc, char **argv)
     cfg.est_focal = A >= 0 ? 1 : 0;
     cfg.itmax = B > 0 ? B : 1;
     if (const char *dev = std::getenv("MI_BA_DEVICE")) cfg.device = std::atoi(dev);
-    if (const char *det = std::getenv("MI_BA_DETERMINISTIC")) cfg.deterministic = std::atoi(det) != 0;
+    if (const char *det = std::getenv("MI_BA_DETERMINISTIC")) { const int v = std::atoi(det); cfg.deterministic = v == 2 ? 2 : v != 0; }   // mi_ba.h: 1 ordered hand-over, 2 all rows
     const char *gpus = std::getenv("MI_BA_GPUS"), *transport = std::getenv("MI_BA_TRANSPORT");
     const int world = gpus ? std::atoi(gpus) : 1;
     const bool host_transport = transport && std::strcmp(transport, "host") == 0;

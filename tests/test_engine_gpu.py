@@ -479,13 +479,19 @@ def test_tracks_longer_than_a_wavefront(oracle):
     assert ret2 == o2["ret"] and abs(np.sqrt(info2[1] / sub.nobs) - np.sqrt(o2["info"][1] / sub.nobs)) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["C1", "ragged"])
-def test_deterministic_mode_gives_the_same_bits_twice(oracle, name):
-    """mi_ba_config.deterministic: every point on the block-major row path, no floating-point atomics in the linear phase --
-    the reduced system, the trial trace and the answer are bit-identical from run to run (the reference is deterministic,
-    sba_levmar.c:1182-1339), and still the oracle's to the usual tolerances"""
+@pytest.mark.parametrize("det", [1, 2])
+@pytest.mark.parametrize("name", ["C1", "ragged", "mixed"])
+def test_deterministic_mode_gives_the_same_bits_twice(oracle, name, det, monkeypatch):
+    """mi_ba_config.deterministic -- 1: the register / table tiles hand over per-tile copies that are summed in tile order, 2: every
+    point on the block-major row path; no floating-point atomics in the linear phase either way -- the reduced system, the trial
+    trace and the answer are bit-identical from run to run (the reference is deterministic, sba_levmar.c:1182-1339), and still
+    the oracle's to the usual tolerances"""
     if name == "C1":
         sc, _ = scene_from_golden("C1")
+    elif name == "mixed":       # camera sets shared by few points (several lanes of a round hold the same block), table tiles, rows, long tracks
+        monkeypatch.setenv("MI_BA_MIN_RUN_PTS", "2")
+        from test_fuzz_gpu import ragged_scene
+        sc = ragged_scene(np.random.default_rng(77), m=90, n=1500, est_focal=1, undistort=0, explicit_centers=1, proj_sign=-1.0, dmax=80)
     else:
         from helpers import ladybug_like_scene
         sc = ladybug_like_scene(m=100, n=1500, dmax=80, seed=9)
@@ -494,7 +500,7 @@ def test_deterministic_mode_gives_the_same_bits_twice(oracle, name):
     S, E, _ = reduced_system(lin, sc, mu)
     runs = []
     for rep in range(2):
-        eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, deterministic=1)
+        eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, deterministic=det)
         g = eng.debug_linearize(mu)
         ret, info = eng.run()
         runs.append((g["S"].copy(), g["E"].copy(), g["ea"].copy(), np.array(info), eng.packed_params().copy(), eng.trace().copy(), ret))

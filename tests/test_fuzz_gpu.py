@@ -44,10 +44,10 @@ CASES = [  # est_focal, undistort, explicit_centers, proj_sign, mode, mcon, cons
 ]
 
 
-@pytest.mark.parametrize("det", [0, 1])
+@pytest.mark.parametrize("det", [0, 1, 2])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_random_ragged_scenes_match_the_oracle(oracle, case, det, monkeypatch):
-    """det = 1: mi_ba_config.deterministic -- no f64 atomics, so the run is reproducible and the comparisons with the oracle take
+    """det = 1 (per-tile copies summed in tile order), 2 (every point on the row path): mi_ba_config.deterministic -- no f64 atomics, so the run is reproducible and the comparisons with the oracle take
     their strict form (every trial of the truncated drivers, every accept / reject decision, the tight parameter bound): what
     the atomics' run-to-run noise had forced to loosen (commits 0cd8ded, 0eba4de, 583573b)"""
     monkeypatch.setenv("MI_BA_MIN_RUN_PTS", "2")              # camera sets shared by two points already earn an LDS tile: all paths in one problem

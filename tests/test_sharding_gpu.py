@@ -23,7 +23,7 @@ def _case(kind):
     if kind == "long":
         from helpers import ladybug_like_scene
         return ladybug_like_scene(m=120, n=3000, dmax=90, seed=9 + off), {}, lambda eng: None
-    if kind == "det":      # deterministic mode: every point on the block-major row path, on both ranks
+    if kind == "det":      # deterministic mode (ordered hand-over of the register tiles; the ragged tracks take the row path), on both ranks
         from helpers import ladybug_like_scene
         return ladybug_like_scene(m=100, n=2500, dmax=80, seed=12 + off), dict(deterministic=1), lambda eng: None
     if kind == "resume":   # every trial's first run of CG iterations falls short (engine.cpp solve_phase): the update phase -- and with
