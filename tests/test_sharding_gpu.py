@@ -26,6 +26,8 @@ def _case(kind):
     if kind == "det":      # deterministic mode (ordered hand-over of the register tiles; the ragged tracks take the row path), on both ranks
         from helpers import ladybug_like_scene
         return ladybug_like_scene(m=100, n=2500, dmax=80, seed=12 + off), dict(deterministic=1), lambda eng: None
+    if kind == "pba":      # PBA's Levenberg-Marquardt rules (lm_variant 1): damping on the diagonals, dL and the step norm in the metric of diag J'J
+        return scene.make_scene("x", m=40, n=6000, d=6, seed=79 + off), dict(lm_variant=1, pcg_minit=10, opts=(1e-3, 0.0, 1e-6, 1e-10, 1e5, 0.0), itmax=40), lambda eng: None
     if kind == "resume":   # every trial's first run of CG iterations falls short (engine.cpp solve_phase): the update phase -- and with
         os.environ["MI_BA_PCG_FIRST_RUN"] = "2"   # it the second exchange and its per-rank maxima slots -- runs twice per trial
         return scene.make_scene("x", m=40, n=6000, d=6, seed=77 + off), {}, lambda eng: None
@@ -72,7 +74,7 @@ def _worker(rank, world, port, outdir, kind):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "plain"), (3, "long"), (2, "extras"), (2, "resume"), (2, "det")])
+@pytest.mark.parametrize("world,kind", [(2, "plain"), (3, "long"), (2, "extras"), (2, "resume"), (2, "det"), (2, "pba")])
 def test_ranks_sharing_one_gpu_reproduce_the_single_rank_solve(tmp_path, world, kind):
     import torch.multiprocessing as mp
     from conftest import pkg
