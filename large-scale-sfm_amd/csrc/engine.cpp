@@ -406,7 +406,7 @@ int Engine::prepare()
         !hipok(d_E_.alloc((size_t)mv_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)mv_ * kCP), "alloc dA") ||
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)mv_ * kCP * 8), "alloc pcg") ||
         !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)mv_), "alloc rz/pq") ||
-        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGrid) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
+        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), 16384) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
         !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage") ||
         !hipok(d_cam_part_.alloc((size_t)((mv_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
         !hipok(d_cam_part2_.alloc((size_t)((m_ + 63) / 64 + 1) * kPartW), "alloc camera partials"))
@@ -705,6 +705,14 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
 }
 
 // camera update, back-substitution, cost at the trial point
+// workgroups of k_backsub: whole rounds of what the chip holds at once (3 wavefronts per SIMD at 168 VGPRs: 3 072), so that no
+// SIMD idles through a part-filled last round; MI_BA_BACKSUB_GRID overrides (probe)
+static int backsub_grid()
+{
+    static const int v = std::getenv("MI_BA_BACKSUB_GRID") ? std::atoi(std::getenv("MI_BA_BACKSUB_GRID")) : 0;
+    return v > 0 ? v : kBacksubGrid;
+}
+
 bool Engine::update_phase(double mu, double *dB_dev, bool peek)
 {
     const Plan &pl = plan_;
@@ -715,7 +723,7 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_real_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
-    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, kBacksubGrid); b.cfg = mc; b.scal = scal_();
+    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, backsub_grid()); b.cfg = mc; b.scal = scal_();
     if (timing_detail >= 2) (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, dB_dev, b.ngrid));

@@ -20,7 +20,7 @@ namespace miba {
 constexpr int kCamLin = 24;
 constexpr int kPtOut = 12;
 constexpr int kPartW = 8;      // per-workgroup partial row: [0,4) sums, [4,8) maxima
-constexpr int kBacksubGrid = 8192;    // workgroups of k_backsub (each walks a contiguous chunk of batches)
+constexpr int kBacksubGrid = 6144;    // workgroups of k_backsub (each walks a contiguous chunk of batches): two rounds of the 3 072 the chip holds at 3 wavefronts per SIMD
 constexpr int kReduceStage = 64;      // first-stage workgroups of k_reduce_partials
 
 struct ModelCfg {
