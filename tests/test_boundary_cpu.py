@@ -436,3 +436,21 @@ def test_plan_rejects_bad_input():
         capi.Plan(2, 2, [0, 0, 1], [1, 1, 0])
     with pytest.raises(ValueError, match="out of range"):
         capi.Plan(2, 2, [0, 1], [0, 5])
+
+
+def test_plan_with_more_long_tracks_than_a_grid_dimension():
+    """66 000 tracks of 65 views: more points beyond a wavefront than the 65 535 a grid's y dimension can index.  Round 1 launched a
+    kernel with the long points on blockIdx.y; since round 2 they take one workgroup each on blockIdx.x (k_long_reduce,
+    k_long_backsub) and their pairs are k_schur_*'s block-major work lists, whatever their number.  The planner's side: all of
+    them long, every pair of every track in the row path's lists exactly once."""
+    m, n, d = 70, 66000, 65
+    start = (np.arange(n) * 7) % m
+    cams = np.sort((start[:, None] + np.arange(d)[None, :]) % m, axis=1).astype(np.int32).reshape(-1)
+    pts = np.repeat(np.arange(n, dtype=np.int32), d)
+    capi = pkg("capi")
+    pl = capi.Plan(n, m, pts, cams)
+    st = pl.stats()
+    assert st["nlong"] == n > 65535 and st["ntile"] == 0
+    assert st["nrec"] == n * d and st["npair_rows"] == n * (d * (d + 1) // 2 - d)      # off-diagonal pairs; the diagonal ones are k_schur_blocks<DIAG>'s
+    long_pts = pl.get("long_pts")
+    assert len(long_pts) == n and len(set(long_pts.tolist())) == n
