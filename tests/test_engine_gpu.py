@@ -479,6 +479,18 @@ def test_tracks_longer_than_a_wavefront(oracle):
     assert ret2 == o2["ret"] and abs(np.sqrt(info2[1] / sub.nobs) - np.sqrt(o2["info"][1] / sub.nobs)) < 1e-6
 
 
+def test_more_long_tracks_than_a_grid_dimension(oracle):
+    """66 000 tracks of 65 views (4.3 M observations, 137 M pairs on the row path): more points beyond a wavefront than a grid's y
+    dimension can index -- the launch shape round 1's k_long_pairs had.  The solve runs, converges, and the cost it reports at
+    its answer is the CPU cost function's"""
+    sc = pkg("scene").make_scene("x", m=70, n=66000, d=65, seed=5, strides=(1,))
+    eng = make_engine(sc, itmax=6)
+    ret, info = eng.run()
+    assert ret == 6 and info[1] < 0.01 * info[0]
+    c = oracle.cost(sc, eng.packed_params())
+    assert abs(c - info[1]) < 1e-9 * c
+
+
 @pytest.mark.parametrize("det", [1, 2])
 @pytest.mark.parametrize("name", ["C1", "ragged", "mixed"])
 def test_deterministic_mode_gives_the_same_bits_twice(oracle, name, det, monkeypatch):
