@@ -36,6 +36,30 @@ inline double point_weight(int d) { return (double)d + 0.5 * (double)d * (d + 1)
 
 } // namespace
 
+// std::sort on a few host threads: the ranges sorted on their own, then merged pairwise (the result is std::sort's: the keys
+// are distinct -- every element carries its index)
+template <class T>
+static void parallel_sort(std::vector<T> &v)
+{
+    const size_t n = v.size();
+    unsigned nt = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    while (nt & (nt - 1)) nt &= nt - 1;                     // a power of two
+    if (nt <= 1 || n < (1u << 16)) { std::sort(v.begin(), v.end()); return; }
+    std::vector<size_t> cut(nt + 1);
+    for (unsigned k = 0; k <= nt; ++k) cut[k] = n * k / nt;
+    {
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; ++k) th.emplace_back([&, k]() { std::sort(v.begin() + cut[k], v.begin() + cut[k + 1]); });
+        for (auto &t : th) t.join();
+    }
+    for (unsigned w = 1; w < nt; w *= 2) {
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k + w < nt + 1 && k < nt; k += 2 * w)
+            th.emplace_back([&, k, w]() { std::inplace_merge(v.begin() + cut[k], v.begin() + cut[k + w], v.begin() + cut[std::min(k + 2 * w, nt)]); });
+        for (auto &t : th) t.join();
+    }
+}
+
 // fn(begin, end) over [0, n) on a few host threads (the loops below touch every observation once and are independent per point)
 template <class F>
 static void parallel_ranges(int n, F fn)
@@ -132,15 +156,17 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     // in one group) falls back to the plain sort.
     {
         std::vector<std::pair<uint64_t, int>> hashed(n);
-        for (int i = 0; i < n; ++i) {
-            uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(cls[i] + 1);
-            if (cls[i] == 0 || cls[i] == 1) {
-                const int *p = cam.data() + pt_ptr[i];
-                for (int t = 0, d = deg(i); t < d; ++t) { h ^= (uint64_t)(p[t] + 1); h *= 0x100000001B3ull; h ^= h >> 29; }
+        parallel_ranges(n, [&](int b, int e) {
+            for (int i = b; i < e; ++i) {
+                uint64_t h = 0x9E3779B97F4A7C15ull * (uint64_t)(cls[i] + 1);
+                if (cls[i] == 0 || cls[i] == 1) {
+                    const int *p = cam.data() + pt_ptr[i];
+                    for (int t = 0, d = deg(i); t < d; ++t) { h ^= (uint64_t)(p[t] + 1); h *= 0x100000001B3ull; h ^= h >> 29; }
+                }
+                hashed[i] = { h, i };
             }
-            hashed[i] = { h, i };
-        }
-        std::sort(hashed.begin(), hashed.end());
+        });
+        parallel_sort(hashed);
         std::vector<int> rep, first;                   // per group: representative point, start in hashed[]
         bool collision = false;
         for (int q = 0; q < n && !collision; ++q) {
