@@ -1831,7 +1831,7 @@ __global__ __launch_bounds__(1024) void k_coarse_invert(const CoarseArgs co)
 {
     static_assert(kCoarseMax * 8 == 128, "the register tiling covers 128 x 128");
     __shared__ __attribute__((aligned(16))) double sRow[2][128], sCol[2][128];
-    __shared__ double sPiv[2], sD[128];
+    __shared__ double sPiv[2], sD[128];                                  // sPiv: 1 / pivot, by the thread that holds it (NaN: not positive)
     // a wavefront holds 8 x 8 tiles (32 x 32 elements): row k and column k of a step live in 4 + 4 of the 16 wavefronts, the others
     // skip the hand-over code
     const int n = co.nc, tid = threadIdx.x, wq = tid >> 6, lq = tid & 63, i0 = ((wq >> 2) * 8 + (lq >> 3)) * 4, j0 = ((wq & 3) * 8 + (lq & 7)) * 4;
@@ -1856,7 +1856,7 @@ __global__ __launch_bounds__(1024) void k_coarse_invert(const CoarseArgs co)
                     for (int y = 0; y < 4; ++y) sRow[b][j0 + y] = y == kc ? a[x][y] + 1.0 : a[x][y];
                     if ((unsigned)kc < 4u) {
 #pragma unroll
-                        for (int y = 0; y < 4; ++y) if (y == kc) sPiv[b] = a[x][y];
+                        for (int y = 0; y < 4; ++y) if (y == kc) sPiv[b] = (a[x][y] > 0.0 && isfinite(a[x][y])) ? 1.0 / a[x][y] : __builtin_nan("");
                     }
                 }
         }
@@ -1869,9 +1869,8 @@ __global__ __launch_bounds__(1024) void k_coarse_invert(const CoarseArgs co)
                 }
         }
         __syncthreads();                                                  // (one barrier a step: the buffers alternate)
-        const double piv = sPiv[b];
-        if (!(piv > 0.0) || !isfinite(piv)) { fail = true; break; }       // uniform: every thread reads the same pivot
-        const double ip = 1.0 / piv;
+        const double ip = sPiv[b];
+        if (!(ip == ip)) { fail = true; break; }                          // uniform: every thread reads the same value
         const double2 r01 = *reinterpret_cast<const double2 *>(&sRow[b][j0]), r23 = *reinterpret_cast<const double2 *>(&sRow[b][j0 + 2]);
         const double2 c01 = *reinterpret_cast<const double2 *>(&sCol[b][i0]), c23 = *reinterpret_cast<const double2 *>(&sCol[b][i0 + 2]);
         const double rw[4] = { r01.x, r01.y, r23.x, r23.y }, cl[4] = { c01.x * ip, c01.y * ip, c23.x * ip, c23.y * ip };
