@@ -237,6 +237,15 @@ int Engine::prepare()
         return MI_BA_ERROR;
     }
     if (!h_link_cam_.empty() && cfg.mode == 2) { err = "prepare: camera links make no sense in a structure-only bundle"; return MI_BA_ERROR; }
+    const bool plan_timing = std::getenv("MI_BA_PLAN_TIMING") != nullptr;
+    double t_stage = now_ms();
+    auto stage = [&](const char *what) {
+        if (!plan_timing) return;
+        (void)hipDeviceSynchronize();
+        const double t = now_ms();
+        std::fprintf(stderr, "[mi_ba prepare] %-26s %8.1f ms\n", what, t - t_stage);
+        t_stage = t;
+    };
     std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches,
                                   h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic == 2, split_);
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
@@ -265,6 +274,7 @@ int Engine::prepare()
         for (int64_t o = 0; o < nol; ++o) { xy[o].x = h_xy_[2 * pl.obs_src[o]]; xy[o].y = h_xy_[2 * pl.obs_src[o] + 1]; }
         UP(d_obs_xy_, xy);
     }
+    stage("plan + index uploads");
     if (cfg.deterministic == 1 && pl.ntile_lds > 0) {   // ordered hand-over: who contributes to every block of S and to every camera, in tile order
         std::vector<int> bp((size_t)pl.nb_up() + 1, 0), cp((size_t)mv_ + 1, 0);
         for (int t = 0; t < pl.ntile_lds; ++t) {
@@ -418,6 +428,7 @@ int Engine::prepare()
     if (std::getenv("MI_BA_STAMPS")) {
         if (!hipok(d_dbg_.alloc(8), "alloc dbg") || !hipok(hipMemset(d_dbg_.p, 0, 64), "memset dbg")) return MI_BA_ERROR;
     }
+    stage("parameters, buffers");
     prepared_ = true;
     if (set_params(h_a0_.data(), h_xyz_.data()) != 0) return MI_BA_ERROR;
     // algorithmic HBM bytes of one linearisation + Schur build, SURVEY.md 8(d) "Pass A" with the f64 state the engine really
