@@ -19,7 +19,9 @@ constexpr double kEpsilonSq = 1E-12 * 1E-12; // SBA_EPSILON_SQ, sba_levmar.c:37-
 constexpr double kOneThird = 0.3333333334;   // SBA_ONE_THIRD, sba_levmar.c:40
 constexpr int kPcgChunk = 8;                 // PCG iterations launched between two host checks
 constexpr int kPcgRowPerWorkgroupMax = 512; // up to this many cameras a block row of S~ gets a whole workgroup (4 wavefronts), above: a wavefront
-constexpr int kPcgTwoWavesPerRowBelow = 128; // blocks per block row of S~ on average below which two wavefronts share a row in the CG product (kernels.hip)
+constexpr int kPcgTotalsFrom = 1024;          // workgroups of the CG product from which the dot products are summed by a launch of their own (k_pcg_totals)
+constexpr int kPcgTwoWavesPerRowBelow = 128; // blocks per block row of S~ on average below which two wavefronts share a row in the CG product (kernels.hip) ...
+constexpr int kPcgTwoWavesPerRowUpTo = 512;  // ... while the launch is a single round of workgroups (5 000 cameras, 1 250 workgroups: 3.06 ms per solve with two, 2.34 with one)
 constexpr int kTwoLevelMinCams = 400;       // the coarse space is considered from this many cameras on (fewer: the CG needs few iterations anyway)
 constexpr int kTwoLevelFrom = 12;           // ... and built from the first trial after a solve that took this many iterations (per trial it
                                             // costs ~35 us: coarse matrix, its inverse, the band S~Z~)
@@ -628,9 +630,12 @@ PcgArgs Engine::pcg_args()
     const bool row_wg = co_.ng ? false : force_row_wg >= 0 ? force_row_wg != 0 : mv_ <= kPcgRowPerWorkgroupMax;   // (the coarse space is laid out for four rows per workgroup)
     p.ng = (mv_ + 7) / 8; p.nwg = row_wg ? mv_ : (mv_ + 3) / 4;
     static const int force_wpr = std::getenv("MI_BA_PCG_WPR") ? std::atoi(std::getenv("MI_BA_PCG_WPR")) : 0;
-    p.wpr = force_wpr == 1 || force_wpr == 2 ? force_wpr : ((size_t)plan_.nb_full() < (size_t)kPcgTwoWavesPerRowBelow * mv_ ? 2 : 1);
+    p.wpr = force_wpr == 1 || force_wpr == 2 ? force_wpr
+                                                : ((size_t)plan_.nb_full() < (size_t)kPcgTwoWavesPerRowBelow * mv_ && p.nwg <= kPcgTwoWavesPerRowUpTo ? 2 : 1);
     p.rz_hist = d_rzpq_.p; p.alpha_hist = p.rz_hist + (cfg.pcg_maxit + 4); p.gp = p.alpha_hist + (cfg.pcg_maxit + 4); p.dp = p.gp + 2 * (size_t)p.nwg;
     p.scal = scal_(); p.tol = cfg.pcg_tol; p.minit = cfg.pcg_minit; p.m = mv_; p.it = 0;
+    static const int force_tot = std::getenv("MI_BA_PCG_TOTALS") ? std::atoi(std::getenv("MI_BA_PCG_TOTALS")) : -1;
+    if (!row_wg && !co_active_ && (force_tot >= 0 ? force_tot != 0 : p.nwg >= kPcgTotalsFrom)) p.tot = p.dp + 2 * (size_t)p.nwg;   // (room: 4 mv doubles are allocated for the partials)
     if (co_active_) p.co = co_;
     return p;
 }

@@ -158,6 +158,8 @@ struct PcgArgs {
                                                        // workgroup, few cameras) or ceil(m / 4) (one per wavefront)
     int wpr;                                           // nwg = ceil(m / 4): wavefronts per block row, 1 or 2 (long rows)
     int minit;                                         // the tolerance test counts from this iteration on (PBA: __cg_min_iteration)
+    double *tot;                                       // [2][2] or nullptr: the two dot products summed once per launch by k_pcg_totals (many workgroups:
+                                                       // every workgroup adding up all nwg partials itself is O(nwg^2) loads per iteration)
     CoarseArgs co;                                     // co.ng == 0: plain block-Jacobi
 };
 

@@ -2111,6 +2111,23 @@ __global__ __launch_bounds__(64) void k_pcg_tail(const PcgArgs a) { pcg_tail(a);
 // What this launch costs is rounds of dependent memory latency (~4.2 us of it is the launch itself), so everything that
 // can be requested at once is: flags, partials, histories and row pointers together, then blocks and column indices, then
 // the neighbours' vectors.
+// the two dot products of the launch before, summed ONCE (fixed order) for everybody: with thousands of workgroups each adding up
+// all nwg partials itself, an iteration spent more time on 2 nwg^2 partial loads than on the matrix (10 000 cameras: 122 us, 42 of
+// them the matrix).  One small launch between two iterations; used from kPcgTotalsFrom workgroups on (engine.cpp).
+__global__ __launch_bounds__(256) void k_pcg_totals(const PcgArgs a, int slot)
+{
+    __shared__ double sg[256], sd[256];
+    double g = 0.0, d = 0.0;
+    for (int i = threadIdx.x; i < a.nwg; i += 256) { g += a.gp[(size_t)slot * a.nwg + i]; d += a.dp[(size_t)slot * a.nwg + i]; }
+    sg[threadIdx.x] = g; sd[threadIdx.x] = d;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { sg[threadIdx.x] += sg[threadIdx.x + w]; sd[threadIdx.x] += sd[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { a.tot[slot * 2] = sg[0]; a.tot[slot * 2 + 1] = sd[0]; }
+}
+
 template <int ROWS, int WPR = 1>
 __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
 {
@@ -2129,7 +2146,8 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
     // the other three through LDS -- four times fewer partial loads, which at 1 700 rows were as many bytes as a fifth of S~
     __shared__ double sgd[2];
     double gs = 0.0, ds = 0.0;
-    if (kOwn || threadIdx.x < 64)
+    if (a.tot) { if (lane == 0) { gs = a.tot[par * 2]; ds = a.tot[par * 2 + 1]; } }      // (the wave sums below add zeros to it)
+    else if (kOwn || threadIdx.x < 64)
         for (int i = lane; i < a.nwg; i += 64) { gs += a.gp[(size_t)par * a.nwg + i]; ds += a.dp[(size_t)par * a.nwg + i]; }
     const double g_prev = a.rz_hist[prev], g_zero = a.rz_hist[0], a_prev = a.alpha_hist[prev];
     const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
@@ -2451,6 +2469,7 @@ void launch_pcg_init(hipStream_t st, const PcgArgs &a)
     if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_start<1>, dim3(a.nwg), dim3(256), 0, st, a);
     else if (a.wpr == 2) hipLaunchKernelGGL((k_pcg_start<4, 2>), dim3(a.nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL(k_pcg_start<4>, dim3(a.nwg), dim3(256), 0, st, a);
+    if (a.tot) hipLaunchKernelGGL(k_pcg_totals, dim3(1), dim3(256), 0, st, a, 0);
 }
 
 void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
@@ -2459,6 +2478,7 @@ void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
     if (a.nwg == a.m) hipLaunchKernelGGL(k_pcg_iter<1>, dim3(a.nwg), dim3(256), 0, st, a);
     else if (a.wpr == 2) hipLaunchKernelGGL((k_pcg_iter<4, 2>), dim3(a.nwg), dim3(512), 0, st, a);
     else hipLaunchKernelGGL(k_pcg_iter<4>, dim3(a.nwg), dim3(256), 0, st, a);
+    if (a.tot) hipLaunchKernelGGL(k_pcg_totals, dim3(1), dim3(256), 0, st, a, (a.it & 1) ^ 1);
 }
 
 
