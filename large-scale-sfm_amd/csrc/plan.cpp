@@ -154,6 +154,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     // camera list), sort one representative per group with the comparator, and emit the groups' members in index order --
     // the same permutation as sorting every point, at a fraction of the comparisons.  A hash collision (two different lists
     // in one group) falls back to the plain sort.
+    std::vector<int> sig_rep;      // one point per distinct (class, camera list) of class 0 / 1, when the hash grouping held (else empty)
     {
         std::vector<std::pair<uint64_t, int>> hashed(n);
         parallel_ranges(n, [&](int b, int e) {
@@ -166,16 +167,31 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                 hashed[i] = { h, i };
             }
         });
+        stage("  sig: hash");
         parallel_sort(hashed);
+        stage("  sig: sort");
+        // groups: a new one starts where the hash changes; inside a group every member must have its predecessor's class and camera list
+        // (equality is transitive) -- one random access per point, spread over the threads
+        std::vector<uint8_t> starts(n, 0);
+        std::atomic<int> collided{ 0 };
+        parallel_ranges(n, [&](int b, int e) {
+            for (int q = b; q < e; ++q) {
+                if (q == 0 || hashed[q].first != hashed[q - 1].first) { starts[q] = 1; continue; }
+                const int a = hashed[q - 1].second, c = hashed[q].second;
+                bool bad = cls[a] != cls[c];
+                if (!bad && (cls[a] == 0 || cls[a] == 1))
+                    bad = deg(a) != deg(c) || std::memcmp(cam.data() + pt_ptr[a], cam.data() + pt_ptr[c], sizeof(int) * (size_t)deg(a)) != 0;
+                if (bad) collided.store(1, std::memory_order_relaxed);
+            }
+        });
+        const bool collision = collided.load() != 0;
         std::vector<int> rep, first;                   // per group: representative point, start in hashed[]
-        bool collision = false;
-        for (int q = 0; q < n && !collision; ++q) {
-            if (q == 0 || hashed[q].first != hashed[q - 1].first) { rep.push_back(hashed[q].second); first.push_back(q); continue; }
-            const int a = rep.back(), b = hashed[q].second;
-            if (cls[a] != cls[b]) collision = true;
-            else if (cls[a] == 0 || cls[a] == 1)
-                collision = deg(a) != deg(b) || std::memcmp(cam.data() + pt_ptr[a], cam.data() + pt_ptr[b], sizeof(int) * (size_t)deg(a)) != 0;
+        if (!collision) {
+            for (int q = 0; q < n; ++q) if (starts[q]) { rep.push_back(hashed[q].second); first.push_back(q); }
+            for (int i : rep) if (cls[i] == 0 || cls[i] == 1) sig_rep.push_back(i);
         }
+        stage("  sig: group scan");
+        std::vector<int> run_end;                      // ends (in perm) of the runs of one camera set, in order
         if (collision) std::sort(pl.perm.begin(), pl.perm.end(), by_class_then_signature);
         else {
             first.push_back(n);
@@ -183,24 +199,37 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             std::iota(order.begin(), order.end(), 0);
             std::sort(order.begin(), order.end(), [&](int x, int y) { return by_class_then_signature(rep[x], rep[y]); });
             int w = 0;
-            for (int g : order)
+            run_end.reserve(order.size());
+            for (int g : order) {
                 for (int q = first[g]; q < first[g + 1]; ++q) pl.perm[w++] = hashed[q].second;   // index order inside a group
+                run_end.push_back(w);
+            }
         }
-    }
-    {   // a camera set has to repeat to earn a register-accumulated tile: short runs take the row path (plan.h kMinRunPts).
-        // perm is sorted by (class, signature); moving a subset of class 0 to class 1 keeps both parts in signature order,
-        // so the new order is a stable partition plus one merge of the two class-1 pieces
+        stage("  sig: emit");
+    // a camera set has to repeat to earn a register-accumulated tile: short runs take the row path (plan.h kMinRunPts).
+    // perm is sorted by (class, signature); moving a subset of class 0 to class 1 keeps both parts in signature order,
+    // so the new order is a stable partition plus one merge of the two class-1 pieces
         int min_run = kMinRunPts;
         if (const char *ev = std::getenv("MI_BA_MIN_RUN_PTS")) min_run = std::atoi(ev);
         bool changed = false;
-        int t0 = 0, n0 = 0;
+        int n0 = 0;
         while (n0 < n && cls[pl.perm[n0]] == 0) ++n0;
-        while (t0 < n0) {
-            const int i0 = pl.perm[t0], d = deg(i0);
-            int t1 = t0 + 1;
-            while (t1 < n0 && deg(pl.perm[t1]) == d && std::memcmp(cam.data() + pt_ptr[i0], cam.data() + pt_ptr[pl.perm[t1]], sizeof(int) * d) == 0) ++t1;
-            if (t1 - t0 < min_run) { for (int t = t0; t < t1; ++t) cls[pl.perm[t]] = 1; changed = true; }
-            t0 = t1;
+        if (!collision) {          // the runs are the groups just emitted (class 0 comes first)
+            int t0 = 0;
+            for (int t1 : run_end) {
+                if (t0 >= n0) break;
+                if (t1 - t0 < min_run) { for (int t = t0; t < t1; ++t) cls[pl.perm[t]] = 1; changed = true; }
+                t0 = t1;
+            }
+        } else {
+            int t0 = 0;
+            while (t0 < n0) {
+                const int i0 = pl.perm[t0], d = deg(i0);
+                int t1 = t0 + 1;
+                while (t1 < n0 && deg(pl.perm[t1]) == d && std::memcmp(cam.data() + pt_ptr[i0], cam.data() + pt_ptr[pl.perm[t1]], sizeof(int) * d) == 0) ++t1;
+                if (t1 - t0 < min_run) { for (int t = t0; t < t1; ++t) cls[pl.perm[t]] = 1; changed = true; }
+                t0 = t1;
+            }
         }
         if (changed) {
             int n1 = n0;
@@ -214,7 +243,8 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
 
     stage("signature sort");
     // ---- shard cut (contiguous internal ranges, balanced by observations + pairs)
-    {
+    if (world == 1) { pl.pt_begin = 0; pl.pt_end = pl.n_active; }
+    else {
         double total = 0;
         for (int t = 0; t < pl.n_active; ++t) total += point_weight(deg(pl.perm[t]));
         double lo = total * rank / world, hi = total * (rank + 1) / world, acc = 0;
@@ -237,15 +267,25 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         const size_t words = ((size_t)m + 63) / 64;
         std::vector<uint64_t> bits(words * (size_t)m, 0);
         for (int j = 0; j < m; ++j) bits[(size_t)j * words + (j >> 6)] |= 1ull << (j & 63);
-        const int *prev = nullptr; int prevd = -1;
-        for (int t = 0; t < pl.n_active; ++t) {
-            int i = pl.perm[t], d = deg(i);
+        auto mark = [&](int i) {
+            const int d = deg(i);
             const int *c = cam.data() + pt_ptr[i];
-            if (d == prevd && prev && std::memcmp(prev, c, sizeof(int) * d) == 0) continue; // same signature
-            prev = c; prevd = d;
             for (int a = 0; a < d; ++a) {
                 uint64_t *row = bits.data() + (size_t)c[a] * words;
                 for (int b = a + 1; b < d; ++b) row[c[b] >> 6] |= 1ull << (c[b] & 63);
+            }
+        };
+        if (!sig_rep.empty() || pl.n_active == 0) {        // one point per camera set, and the long points one by one (they were grouped by class only)
+            for (int i : sig_rep) mark(i);
+            for (int t = pl.n_active - 1; t >= 0 && cls[pl.perm[t]] == 2; --t) mark(pl.perm[t]);
+        } else {
+            const int *prev = nullptr; int prevd = -1;
+            for (int t = 0; t < pl.n_active; ++t) {
+                int i = pl.perm[t], d = deg(i);
+                const int *c = cam.data() + pt_ptr[i];
+                if (d == prevd && prev && std::memcmp(prev, c, sizeof(int) * d) == 0) continue; // same signature
+                prev = c; prevd = d;
+                mark(i);
             }
         }
         if (extra_pairs)
