@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <unordered_map>
 
 namespace miba {
@@ -273,7 +274,15 @@ int Engine::prepare()
         UP(d_bsr_rowidx_, rowidx); UP(d_bsr_diag_, diag);
         const int64_t nol = pl.nobs_local();
         std::vector<double2> xy(nol);
-        for (int64_t o = 0; o < nol; ++o) { xy[o].x = h_xy_[2 * pl.obs_src[o]]; xy[o].y = h_xy_[2 * pl.obs_src[o] + 1]; }
+        {   // the measurements in the plan's order: a random gather over the caller's array, spread over a few host threads
+            const int nt = nol < (1 << 18) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> th;
+            for (int k = 0; k < nt; ++k)
+                th.emplace_back([&, k]() {
+                    for (int64_t o = nol * k / nt, e = nol * (k + 1) / nt; o < e; ++o) { xy[o].x = h_xy_[2 * pl.obs_src[o]]; xy[o].y = h_xy_[2 * pl.obs_src[o] + 1]; }
+                });
+            for (auto &t : th) t.join();
+        }
         UP(d_obs_xy_, xy);
     }
     stage("plan + index uploads");
