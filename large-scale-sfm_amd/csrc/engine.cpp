@@ -249,8 +249,31 @@ int Engine::prepare()
         std::fprintf(stderr, "[mi_ba prepare] %-26s %8.1f ms\n", what, t - t_stage);
         t_stage = t;
     };
+    // the observation streams are final long before the planner is done (plan.h shard_arrays_ready): a second host thread gathers
+    // the measurements into the plan's order and uploads them with the two index streams while the tiling runs
+    std::thread early_upload;
+    hipError_t early_err = hipSuccess;
+    auto start_early_upload = [&]() {
+        early_upload = std::thread([&]() {
+            if ((early_err = hipSetDevice(cfg.device)) != hipSuccess) return;
+            const Plan &q = plan_;
+            if ((early_err = d_obs_cam_.upload(q.obs_cam)) != hipSuccess || (early_err = d_obs_pt_.upload(q.obs_pt)) != hipSuccess) return;
+            const int64_t nol = q.nobs_local();
+            std::vector<double2> xy(nol);
+            const int nt = nol < (1 << 18) ? 1 : (int)std::min<unsigned>(4u, std::max(1u, std::thread::hardware_concurrency() / 2));
+            std::vector<std::thread> th;
+            for (int k = 0; k < nt; ++k)
+                th.emplace_back([&, k]() {
+                    for (int64_t o = nol * k / nt, e = nol * (k + 1) / nt; o < e; ++o) { xy[o].x = h_xy_[2 * q.obs_src[o]]; xy[o].y = h_xy_[2 * q.obs_src[o] + 1]; }
+                });
+            for (auto &t : th) t.join();
+            early_err = d_obs_xy_.upload(xy);
+        });
+    };
     std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches,
-                                  h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic == 2, split_);
+                                  h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic == 2, split_, start_early_upload);
+    if (early_upload.joinable()) early_upload.join();
+    if (perr.empty() && !hipok(early_err, "upload of the observation streams")) return MI_BA_ERROR;
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
     const Plan &pl = plan_;
 #define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
@@ -258,7 +281,7 @@ int Engine::prepare()
     UP(d_slot_gblk_, pl.slot_gblk); UP(d_cslot_cam_, pl.cslot_cam);
     UP(d_batch_obs_, pl.batch_obs); UP(d_batch_pt_, pl.batch_pt); UP(d_pt_obs_, pl.pt_obs);
     UP(d_bs_batch_obs_, pl.bs_batch_obs); UP(d_bs_batch_pt_, pl.bs_batch_pt);
-    UP(d_obs_cam_, pl.obs_cam); UP(d_obs_pt_, pl.obs_pt); UP(d_obs_cslot_, pl.obs_cslot);
+    UP(d_obs_cslot_, pl.obs_cslot);                              // (obs_cam, obs_pt, obs_xy: the early upload above)
     UP(d_pair_, pl.pair);
     UP(d_obs_rec_, pl.obs_rec); UP(d_rec_cam_, pl.rec_cam); UP(d_wk_blk_, pl.wk_blk); UP(d_rpair_, pl.rpair);
     UP(d_wk_diag_cam_, pl.wk_diag_cam); UP(d_wk_diag_blk_, pl.wk_diag_blk);
@@ -272,18 +295,6 @@ int Engine::prepare()
         for (int j = 0; j < mv_; ++j)
             for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) { rowidx[q] = j; if (pl.bsr_col[q] == j) diag[j] = q; }
         UP(d_bsr_rowidx_, rowidx); UP(d_bsr_diag_, diag);
-        const int64_t nol = pl.nobs_local();
-        std::vector<double2> xy(nol);
-        {   // the measurements in the plan's order: a random gather over the caller's array, spread over a few host threads
-            const int nt = nol < (1 << 18) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-            std::vector<std::thread> th;
-            for (int k = 0; k < nt; ++k)
-                th.emplace_back([&, k]() {
-                    for (int64_t o = nol * k / nt, e = nol * (k + 1) / nt; o < e; ++o) { xy[o].x = h_xy_[2 * pl.obs_src[o]]; xy[o].y = h_xy_[2 * pl.obs_src[o] + 1]; }
-                });
-            for (auto &t : th) t.join();
-        }
-        UP(d_obs_xy_, xy);
     }
     stage("plan + index uploads");
     if (cfg.deterministic == 1 && pl.ntile_lds > 0) {   // ordered hand-over: who contributes to every block of S and to every camera, in tile order

@@ -75,7 +75,8 @@ static void parallel_ranges(int n, F fn)
 }
 
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
-                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs, bool all_rows, bool cam_split)
+                       int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs, bool all_rows, bool cam_split,
+                       const std::function<void()> &shard_arrays_ready)
 {
     if (cam_split) all_rows = true;    // nine-parameter blocks exist on the row path only
     if (n <= 0 || m <= 0 || nobs < 0) return "empty problem";
@@ -353,6 +354,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         }
     });
 
+    if (shard_arrays_ready) shard_arrays_ready();
     // ---- batches and tiles (as a lambda: the automatic tile length needs a first pass to see where the
     // slot / camera budgets force tiles to end)
     std::vector<std::pair<int, bool>> tile_log; // per LDS tile: batches, closed only because of the length cap

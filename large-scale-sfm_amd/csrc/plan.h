@@ -22,6 +22,7 @@
 //   * S = U* - W V*^-1 W^T is block sparse by co-visibility: upper pattern + full BSR pattern.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -102,6 +103,8 @@ struct Plan {
 // all_rows: every point takes the row path (the deterministic mode: no floating-point atomics anywhere)
 std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, const int *cam_idx,
                        int rank, int world, int tile_max_batches, const std::vector<int> *extra_pairs = nullptr, bool all_rows = false,
-                       bool cam_split = false);
+                       bool cam_split = false, const std::function<void()> &shard_arrays_ready = nullptr);
+// shard_arrays_ready: called once obs_cam, obs_pt, obs_src and pt_obs hold their final values (the tiling that follows does not touch
+// them): the engine starts their upload on another thread while the planner goes on
 
 } // namespace miba
