@@ -383,11 +383,20 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     bool rounds_mode = true;
     int pts_in_batch = 0;
     int rounds_in_batch = 0;
-    auto flush_round = [&]() {
+    auto flush_round = [&]() {          // (counts only: the entries of a batch are written when it closes, if they are needed at all)
         if (round_fill == 0) return;
         rounds_in_batch++;
         round_fill = 0;
-        if (dry) return;
+    };
+    // The points of the batch being filled: the version of the slot list they use (one per signature run of the tile), views, first
+    // lane, local index.  Two consecutive batches of a tile with the same sequence have the same pair entries -- the usual case inside
+    // a run of one camera set --, so the entries (d (d + 1) / 2 per point: 55 M pushes on C3) are only generated for a batch whose
+    // sequence is new.
+    struct BatchPoint { int ver, d, obs0, lp; };
+    std::vector<BatchPoint> bpts, prev_bpts;
+    std::vector<std::vector<int>> ver_slots;     // slot lists of this tile's signature runs
+    auto emit_round = [&]() {
+        if (round_buf.empty()) return;
         round_buf.resize(kWave, kPairInvalid);
         pl.pair.insert(pl.pair.end(), round_buf.begin(), round_buf.end());
         round_buf.clear();
@@ -400,13 +409,36 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         // Pair TEMPLATES: points of one camera set produce the same entries batch after batch (lane-local indices, slots, local
         // points), so a batch whose rounds equal the previous batch's of its tile points at those instead of storing its own --
         // C3: 64 M entries (256 MB streamed per linearisation) -> one or two templates per tile, read from L2
-        int64_t off = batch_q0;
-        const int64_t n_ent = (int64_t)pl.pair.size() - batch_q0;
-        if (!dry && n_ent > 0 && prev_q0 >= 0 && n_ent == prev_n &&
-            std::memcmp(pl.pair.data() + prev_q0, pl.pair.data() + batch_q0, sizeof(uint32_t) * (size_t)n_ent) == 0) {
-            pl.pair.resize((size_t)batch_q0);
-            off = prev_q0;
-        } else { prev_q0 = batch_q0; prev_n = n_ent; }
+        int64_t off = batch_q0, n_ent = 0;
+        if (!dry && rounds_mode) {
+            bool same = prev_q0 >= 0 && bpts.size() == prev_bpts.size();
+            for (size_t k = 0; same && k < bpts.size(); ++k)
+                same = bpts[k].ver == prev_bpts[k].ver && bpts[k].d == prev_bpts[k].d && bpts[k].obs0 == prev_bpts[k].obs0 && bpts[k].lp == prev_bpts[k].lp;
+            if (same) { off = prev_q0; n_ent = prev_n; }
+            else {
+                size_t fill = 0;
+                for (const BatchPoint &bp : bpts) {       // the rounds as the point loop counted them
+                    const size_t np = (size_t)bp.d * (bp.d + 1) / 2;
+                    if (fill + np > (size_t)kWave) { emit_round(); fill = 0; }
+                    fill += np;
+                    const std::vector<int> &slots = ver_slots[bp.ver];
+                    int q = 0;
+                    for (int a = 0; a < bp.d; ++a)
+                        for (int b = a; b < bp.d; ++b)
+                            round_buf.push_back((uint32_t)(bp.obs0 + a) | ((uint32_t)(bp.obs0 + b) << 6) | ((uint32_t)slots[q++] << 12) | ((uint32_t)bp.lp << 18));
+                }
+                emit_round();
+                n_ent = (int64_t)pl.pair.size() - batch_q0;
+                // (a run that comes back to an earlier camera set of the tile gets a new version with the old slots: equal entries)
+                if (n_ent > 0 && prev_q0 >= 0 && n_ent == prev_n &&
+                    std::memcmp(pl.pair.data() + prev_q0, pl.pair.data() + batch_q0, sizeof(uint32_t) * (size_t)n_ent) == 0) {
+                    pl.pair.resize((size_t)batch_q0);
+                    off = prev_q0;
+                } else { prev_q0 = batch_q0; prev_n = n_ent; }
+                prev_bpts = bpts;
+            }
+            bpts.clear();
+        }
         pl.batch_pair.push_back(off | ((n_ent / kWave) << 48));
         batch_q0 = (int64_t)pl.pair.size();
         cur_obs = 0; pts_in_batch = 0; rounds_in_batch = 0;
@@ -427,6 +459,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         pl.max_slots = std::max(pl.max_slots, (int)smap.size());
         smap.clear(); cmap.clear(); sig_cams = nullptr; sig_d = -1;
         batches_in_tile = 0; prev_q0 = -1; prev_n = 0;
+        ver_slots.clear(); prev_bpts.clear();
     };
 
     // class 0: LDS-accumulated tiles
@@ -476,17 +509,13 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                 }
             }
             sig_cams = c; sig_d = d;
+            if (!dry) ver_slots.push_back(sig_slots);
         }
         if ((int)round_fill + d * (d + 1) / 2 > kWave) flush_round();
         round_fill += (size_t)d * (d + 1) / 2;
         if (!dry) {
-            int q = 0;
-            for (int a = 0; a < d; ++a) {
-                pl.obs_cslot[pl.pt_obs[t] + a] = sig_cslots[a];
-                for (int b = a; b < d; ++b)
-                    round_buf.push_back((uint32_t)(cur_obs + a) | ((uint32_t)(cur_obs + b) << 6) | ((uint32_t)sig_slots[q++] << 12) |
-                                        ((uint32_t)pts_in_batch << 18));
-            }
+            for (int a = 0; a < d; ++a) pl.obs_cslot[pl.pt_obs[t] + a] = sig_cslots[a];
+            bpts.push_back({ (int)ver_slots.size() - 1, d, cur_obs, pts_in_batch });
         }
         cur_obs += d; pts_in_batch++;
     }
