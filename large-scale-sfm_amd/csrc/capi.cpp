@@ -15,8 +15,8 @@ struct mi_ba_plan { Plan pl; };
 
 static thread_local std::string g_create_error;
 
-template <class T, class U>
-static int64_t copy_out(const std::vector<T> &v, U *out, int64_t cap)
+template <class T, class A, class U>
+static int64_t copy_out(const std::vector<T, A> &v, U *out, int64_t cap)
 {
     const int64_t n = (int64_t)v.size();
     if (out) for (int64_t i = 0; i < n && i < cap; ++i) out[i] = (U)v[i];

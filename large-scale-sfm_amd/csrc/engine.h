@@ -24,7 +24,8 @@ struct DevBuf {
         n = count;
         return hipMalloc((void **)&p, (count ? count : 1) * sizeof(T));
     }
-    hipError_t upload(const std::vector<T> &v)
+    template <class A>
+    hipError_t upload(const std::vector<T, A> &v)
     {
         hipError_t e = alloc(v.size());
         if (e != hipSuccess || v.empty()) return e;

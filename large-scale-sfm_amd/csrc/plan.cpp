@@ -107,8 +107,8 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         pt_ptr[i + 1]++;
     }
     for (int i = 0; i < n; ++i) pt_ptr[i + 1] += pt_ptr[i];
-    std::vector<int> cam(nobs);
-    std::vector<int64_t> src(nobs);
+    uvector<int> cam(nobs);            // (every element is written by the threads below)
+    uvector<int64_t> src(nobs);
     {
         std::atomic<bool> twice(false);
         parallel_ranges(n, [&](int i0, int i1) {
@@ -341,7 +341,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     pl.pt_obs.assign(npl + 1, 0);
     for (int t = 0; t < npl; ++t) pl.pt_obs[t + 1] = pl.pt_obs[t] + deg(pl.perm[pl.pt_begin + t]);
     const int nol = pl.pt_obs[npl];
-    pl.obs_cam.resize(nol); pl.obs_pt.resize(nol); pl.obs_src.resize(nol); pl.obs_cslot.assign(nol, 0);
+    pl.obs_cam.resize(nol); pl.obs_pt.resize(nol); pl.obs_src.resize(nol); pl.obs_cslot.resize(nol);   // (obs_cslot: zeroed by every tiling pass)
     parallel_ranges(npl, [&](int t0, int t1) {
         for (int t = t0; t < t1; ++t) {
             int i = pl.perm[pl.pt_begin + t], d = deg(i);

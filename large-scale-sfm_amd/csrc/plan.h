@@ -23,10 +23,27 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
+#include <utility>
 #include <string>
 #include <vector>
 
 namespace miba {
+
+// std::vector whose resize() leaves new elements uninitialised: the per-observation arrays are hundreds of megabytes, filled
+// right away by several host threads -- a serial zero fill (and its page faults) first was a quarter of the stage
+template <class T>
+struct noinit_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = noinit_allocator<U>; };
+    template <class U, class... A>
+    void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using uvector = std::vector<T, noinit_allocator<T>>;
+
 
 constexpr int kWave = 64;        // observations per batch
 constexpr int kNSlot = 55;       // S-block accumulators per LDS tile (55 = pairs of a 10-view point)
@@ -63,9 +80,9 @@ struct Plan {
 
     // local shard, internal order
     std::vector<int> pt_obs;                         // npl+1 local observation offsets
-    std::vector<int> obs_cam, obs_pt;                // per local observation
-    std::vector<int64_t> obs_src;                    // original observation index
-    std::vector<uint8_t> obs_cslot;                  // tile-local camera slot (LDS tiles)
+    uvector<int> obs_cam, obs_pt;                    // per local observation (uvector: sized without a serial zero fill, first touched by the threads that write them)
+    uvector<int64_t> obs_src;                        // original observation index
+    uvector<uint8_t> obs_cslot;                      // tile-local camera slot (LDS tiles)
     std::vector<int> batch_obs, batch_pt;            // nbatch+1
     std::vector<int> bs_batch_obs, bs_batch_pt;      // batches of k_backsub (same points, packed regardless of tiles)
     std::vector<int64_t> batch_pair;                 // nbatch+1: first pair entry of the batch | rounds << 48 (batches of one camera set share entries)
