@@ -454,3 +454,44 @@ def test_plan_with_more_long_tracks_than_a_grid_dimension():
     assert st["nrec"] == n * d and st["npair_rows"] == n * (d * (d + 1) // 2 - d)      # off-diagonal pairs; the diagonal ones are k_schur_blocks<DIAG>'s
     long_pts = pl.get("long_pts")
     assert len(long_pts) == n and len(set(long_pts.tolist())) == n
+
+
+def test_large_nvm_files_read_and_written_by_threads_equal_the_serial_path(tmp_path, monkeypatch):
+    """models beyond 32 768 points: the point records are parsed / formatted by several host threads (model_io.cpp).  Same arrays,
+    same bytes as the serial reader and writer (MI_MODEL_IO_THREADS=1); a file whose records do not end with their lines goes
+    through the token-by-token reader and still loads"""
+    L = model_lib()
+    sc = vsfm_scene(m=12, n=40000, d=4, seed=21)
+    src = str(tmp_path / "in.nvm")
+    write_nvm(src, sc)
+    assert os.path.getsize(src) > (1 << 20)
+    out = {}
+    for mode in ("threads", "serial"):
+        if mode == "serial":
+            monkeypatch.setenv("MI_MODEL_IO_THREADS", "1")
+        h = L.mi_model_load_nvm(src.encode())
+        assert h, L.mi_model_last_error()
+        mdl = read_model(L, h)
+        dst = str(tmp_path / (mode + ".nvm"))
+        assert L.mi_model_save_nvm(h, dst.encode()) == 0
+        L.mi_model_free(h)
+        out[mode] = (mdl, open(dst, "rb").read())
+    a, b = out["threads"], out["serial"]
+    for k in a[0]:
+        assert np.array_equal(np.asarray(a[0][k]), np.asarray(b[0][k])), k
+    assert a[1] == b[1]
+    monkeypatch.delenv("MI_MODEL_IO_THREADS")
+    # records broken over two lines: the threaded reader declines, the stream reader takes over
+    text = open(src).read().split("\n")
+    head, pts = text[:2 + 12 + 1], text[2 + 12 + 1:]
+    broken = []
+    for k, line in enumerate(pts):
+        toks = line.split(" ")
+        broken.append(" ".join(toks[:5]) + "\n" + " ".join(toks[5:]) if (k % 3 == 0 and len(toks) > 8) else line)
+    src2 = str(tmp_path / "broken.nvm")
+    open(src2, "w").write("\n".join(head + broken))
+    h = L.mi_model_load_nvm(src2.encode())
+    assert h, L.mi_model_last_error()
+    mdl2 = read_model(L, h); L.mi_model_free(h)
+    for k in a[0]:
+        assert np.array_equal(np.asarray(a[0][k]), np.asarray(mdl2[k])), k
