@@ -181,7 +181,7 @@ static bool load_points_in_parallel(Scanner &in, int ncam, int npt, mi_model *m)
 {
     const char *b = in.pos(), *e = in.end();
     const unsigned nt = io_threads();
-    if (npt < (1 << 15) || nt < 2 || e - b < (1 << 20)) return false;
+    if ((npt >= 0 && npt < (1 << 15)) || nt < 2 || e - b < (1 << 20)) return false;   // npt < 0: as many records as the text holds (ours_new.txt)
     std::vector<const char *> cut(nt + 1, e);
     cut[0] = b;
     for (unsigned k = 1; k < nt; ++k) {
@@ -214,7 +214,8 @@ static bool load_points_in_parallel(Scanner &in, int ncam, int npt, mi_model *m)
     for (auto &t : th) t.join();
     size_t total = 0, nproj = 0;
     for (const Piece &q : pc) { if (!q.ok) return false; total += q.npj.size(); nproj += q.cam.size(); }
-    if (total != (size_t)npt) return false;
+    if (npt >= 0 ? total != (size_t)npt : total == 0) return false;
+    m->xyz.resize(3 * total); m->rgb.resize(3 * total);
     m->cam_idx.resize(nproj); m->pt_idx.resize(nproj); m->feat_id.resize(nproj); m->xy.resize(2 * nproj);
     std::vector<size_t> p0(nt + 1, 0), j0(nt + 1, 0);
     for (unsigned k = 0; k < nt; ++k) { p0[k + 1] = p0[k] + pc[k].npj.size(); j0[k + 1] = j0[k] + pc[k].cam.size(); }
@@ -324,6 +325,8 @@ mi_model *mi_model_load_side_files(const char *dir_c)
     }
     if (dist.open((dir + "Distortion.txt").c_str()))
         for (int j = 0; j < ncam && dist.peek() != '\0'; ++j) dist.get(m->d[2 * (size_t)j]);
+    if (load_points_in_parallel(pts, ncam, -1, m)) return m;      // (the same record as an NVM point line; large files only)
+    m->xyz.clear(); m->rgb.clear(); m->cam_idx.clear(); m->pt_idx.clear(); m->feat_id.clear(); m->xy.clear();
     while (pts.peek() != '\0') {
         double X[3]; int rgb[3], nview = 0;
         pts.get(X[0]); pts.get(X[1]); pts.get(X[2]); pts.get_int(rgb[0]); pts.get_int(rgb[1]); pts.get_int(rgb[2]); pts.get_int(nview);

@@ -495,3 +495,23 @@ def test_large_nvm_files_read_and_written_by_threads_equal_the_serial_path(tmp_p
     mdl2 = read_model(L, h); L.mi_model_free(h)
     for k in a[0]:
         assert np.array_equal(np.asarray(a[0][k]), np.asarray(mdl2[k])), k
+
+
+def test_large_side_files_read_by_threads_equal_the_serial_path(tmp_path, monkeypatch):
+    """ours_new.txt of a large cluster (the same point records as an NVM, no count in front): threaded and serial readers agree"""
+    from helpers import write_side_files
+    L = model_lib()
+    sc = vsfm_scene(m=12, n=40000, d=4, seed=22)
+    d = tmp_path / "c"; d.mkdir()
+    write_side_files(str(d), sc)
+    assert os.path.getsize(str(d / "ours_new.txt")) > (1 << 20)
+    out = []
+    for mode in ("threads", "serial"):
+        if mode == "serial":
+            monkeypatch.setenv("MI_MODEL_IO_THREADS", "1")
+        h = L.mi_model_load_side_files((str(d) + "/").encode())
+        assert h, L.mi_model_last_error()
+        out.append(read_model(L, h)); L.mi_model_free(h)
+    for k in out[0]:
+        assert np.array_equal(np.asarray(out[0][k]), np.asarray(out[1][k])), k
+    assert len(out[0]["xyz"]) == sc.n
