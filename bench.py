@@ -132,7 +132,7 @@ def main():
     sc = scene_mod.make_scene(args.config)
     t_gen = time.time() - t0
     cfg = capi.default_config(device=device, rank=rank, world=world, pcg_tol=args.pcg_tol, pcg_maxit=args.pcg_maxit,
-                              deterministic=args.deterministic)
+                              deterministic=args.deterministic, tile_max_batches=int(os.environ.get("MI_BENCH_TILE_MAX_BATCHES", "0")))   # (probe: 0 = the planner's choice)
     eng = capi.Engine(cfg)
     if rehearsal:
         def host_allreduce(buf, op):
