@@ -22,6 +22,8 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <hip/hip_runtime_api.h>
+
 #include "focal_links.h"
 #include "model.h"
 
@@ -828,6 +830,17 @@ int mi_optimizer_all_main(int argc, char **argv)
     auto seconds = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
     auto exists = [&](const char *name) { return access((dir + name).c_str(), R_OK) == 0; };
     const bool have_side = exists("RTglobalmapped_for_optimisation.txt") && exists("focal_for_optimisation.txt") && exists("ours_new.txt");
+    // one rank: the HIP context (a few tenths of a second in a fresh process) comes up on another thread while this one reads the
+    // model.  (Several ranks fork first and must not have touched HIP before: they open their devices after the fork.)
+    std::thread hip_warm_up;
+    {
+        const char *gpus_env = std::getenv("MI_BA_GPUS"), *dev_env = std::getenv("MI_BA_DEVICE");
+        if (!gpus_env || std::atoi(gpus_env) == 1) {
+            const int dev = dev_env ? std::atoi(dev_env) : 0;
+            hip_warm_up = std::thread([dev]() { if (hipSetDevice(dev) == hipSuccess) (void)hipFree(nullptr); });
+        }
+    }
+    struct JoinWarmUp { std::thread &t; ~JoinWarmUp() { if (t.joinable()) t.join(); } } join_warm_up{ hip_warm_up };
     mi_model *m = nullptr;
     if (have_side) {
         m = mi_model_load_side_files(dir.c_str());
@@ -864,6 +877,7 @@ int mi_optimizer_all_main(int argc, char **argv)
     std::printf("%zu cameras; %zu 3D points; %zu projections\n", m->ncam(), m->npt(), m->nproj());
     int it = MI_BA_ERROR;
     if (world == 1) {
+        if (hip_warm_up.joinable()) hip_warm_up.join();
         it = mi_model_optimize(m, &cfg, info);
     } else {
         const size_t bytes = RankShared::bytes(world, host_transport);
