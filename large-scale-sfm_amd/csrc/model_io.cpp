@@ -623,16 +623,31 @@ int mi_model_get(const mi_model *m, double *f, double *R, double *t, double *d, 
 double mi_model_rmse(const mi_model *m)
 {
     if (!m || !m->nproj()) return 0.0;
-    double s = 0.0;
-    for (size_t k = 0; k < m->nproj(); ++k) {
-        const double *R = &m->R[(size_t)m->cam_idx[k] * 9], *t = &m->t[(size_t)m->cam_idx[k] * 3], *X = &m->xyz[(size_t)m->pt_idx[k] * 3];
-        double q[3];
-        for (int r = 0; r < 3; ++r) q[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2] + t[r];
-        const double fx = m->f[m->cam_idx[k]];
-        const double ex = m->xy[2 * k] - fx * q[0] / q[2], ey = m->xy[2 * k + 1] - fx * q[1] / q[2];
-        s += ex * ex + ey * ey;
+    // (large models: the sum in a few pieces on host threads, added in piece order -- the same value whatever the thread timing)
+    const size_t np = m->nproj();
+    const unsigned nt = np < (1u << 20) ? 1u : io_threads();
+    std::vector<double> part(nt, 0.0);
+    auto piece = [&](unsigned k) {
+        double s = 0.0;
+        for (size_t o = np * k / nt, e = np * (k + 1) / nt; o < e; ++o) {
+            const double *R = &m->R[(size_t)m->cam_idx[o] * 9], *t = &m->t[(size_t)m->cam_idx[o] * 3], *X = &m->xyz[(size_t)m->pt_idx[o] * 3];
+            double q[3];
+            for (int r = 0; r < 3; ++r) q[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2] + t[r];
+            const double fx = m->f[m->cam_idx[o]];
+            const double ex = m->xy[2 * o] - fx * q[0] / q[2], ey = m->xy[2 * o + 1] - fx * q[1] / q[2];
+            s += ex * ex + ey * ey;
+        }
+        part[k] = s;
+    };
+    if (nt == 1) piece(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < nt; ++k) th.emplace_back(piece, k);
+        for (auto &t : th) t.join();
     }
-    return std::sqrt(s / (double)m->nproj());
+    double s = 0.0;
+    for (double v : part) s += v;
+    return std::sqrt(s / (double)np);
 }
 
 int mi_model_set_focal_mask(mi_model *m, const int *mask, double weight)
