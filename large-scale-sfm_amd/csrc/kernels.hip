@@ -1626,7 +1626,7 @@ __device__ __forceinline__ void publish_partials(const PcgArgs &a, int slot, dou
 // odd ones; lane (r, c2) of a half multiplies elements (r, c2) and (r, c2 + 1) with the neighbour's vector elements c2, c2 + 1
 // (one 16-B load).  Eight loads = 8 KB per wavefront in flight: a launch has only ~m wavefronts, and the bytes in flight set
 // the rate at which a matrix that lives in the Infinity Cache or HBM streams (8-B loads, 4 KB in flight: 3.2 TB/s on C4's
-// 208 MB).  The sum over the four lanes of a row by two DPP moves, the two halves by a cross-half read; the result is left
+// 208 MB; sixteen loads per wavefront instead of eight: slower, C4 2.70 -> 3.91 ms per solve).  The sum over the four lanes of a row by two DPP moves, the two halves by a cross-half read; the result is left
 // where the callers expect it: row r's value in all lanes 8r .. 8r + 7.
 template <int NV>
 __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, int stride, int lane, const double *const (&vec)[NV], double (&out)[NV])
