@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-c3", action="store_true", help="time one real sba-1.5 iteration on C3 itself (minutes)")
     ap.add_argument("--deterministic", type=int, default=0, help="1: every point on the block-major row path, no f64 atomics")
+    ap.add_argument("--shared-focal", type=float, default=0.0, help="weight of a ring of focal-length couplings between the cameras (PBA's SetFocalMask with one group); 0 = every camera its own focal length")
     ap.add_argument("--pcg-tol", type=float, default=1e-3)
     ap.add_argument("--pcg-maxit", type=int, default=100)
     args = ap.parse_args()
@@ -146,6 +147,10 @@ def main():
         eng.comm_init(bytes(uid.cpu().numpy().tobytes()))
     eng.set_timing_detail(1)            # HIP events around the build kernels: the roofline figure is measured in the timed steps
     eng.load_scene(sc)
+    if args.shared_focal > 0:           # BASELINE's C4 is a shared-intrinsics problem: one focal length for all cameras, as PBA's SetFocalMask
+        la = np.arange(sc.m, dtype=np.int32); lb = (la + 1) % sc.m      # does it -- a ring of quadratic couplings between the cameras' focal lengths
+        w = np.zeros((sc.m, sc.cnp)); w[:, 6] = (np.sqrt(sc.nobs / sc.m) * args.shared_focal) ** 2 / cfg.f_scale ** 2   # (pba_shim.cpp, ProcessWeightCameraQ)
+        eng.set_camera_links(la, lb, w)
     t0 = time.time()
     eng.prepare()
     t_plan = time.time() - t0
@@ -216,7 +221,7 @@ def main():
             **({"rehearsal": "ranks share one GPU, host transport: control flow only, not a measurement"} if rehearsal else {}),
             "config": {"workload": f"{args.config}: {sc.m} cams / {sc.n} pts / {sc.nobs} obs, cnp 7 (pose + focal), "
                        "point-sharded Schur + block-Jacobi PCG", "parallelism": f"points/{world}",
-                       "pcg_tol": args.pcg_tol, "pcg_maxit": args.pcg_maxit, "deterministic": args.deterministic},
+                       "pcg_tol": args.pcg_tol, "pcg_maxit": args.pcg_maxit, "deterministic": args.deterministic, "shared_focal_weight": args.shared_focal},
             "rmse_px": {"initial": rmse0, "after_timed_steps": rmse_after, "final_of_last_completed_solve": done["rmse"]},
             "accepted_steps": int(done["accepted"]), "completed_solves": done["solves"], "lm_iterations_of_last_completed_solve": done["iters"],
             "pcg_iters_per_step": tm["pcg_iters"] / max(tm["pcg_solves"], 1), "pcg_resumes": int(tm["pcg_resumes"]),
