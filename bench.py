@@ -97,7 +97,8 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-c3", action="store_true", help="time one real sba-1.5 iteration on C3 itself (minutes)")
-    ap.add_argument("--deterministic", type=int, default=0, help="1: every point on the block-major row path, no f64 atomics")
+    ap.add_argument("--deterministic", type=int, default=0, help="0: f64 atomics (default); 1: ordered hand-over, per-tile copies summed in tile order (no f64 atomics, full speed); "
+                    "2: every point on the block-major row path")
     ap.add_argument("--shared-focal", type=float, default=0.0, help="weight of a ring of focal-length couplings between the cameras (PBA's SetFocalMask with one group); 0 = every camera its own focal length")
     ap.add_argument("--pcg-tol", type=float, default=1e-3)
     ap.add_argument("--pcg-maxit", type=int, default=100)
@@ -147,6 +148,8 @@ def main():
         eng.comm_init(bytes(uid.cpu().numpy().tobytes()))
     eng.set_timing_detail(1)            # HIP events around the build kernels: the roofline figure is measured in the timed steps
     eng.load_scene(sc)
+    if args.shared_focal > 0 and not (cfg.est_focal and sc.cnp >= 7):
+        raise SystemExit("--shared-focal couples focal lengths: the scene must estimate them (cnp >= 7)")
     if args.shared_focal > 0:           # BASELINE's C4 is a shared-intrinsics problem: one focal length for all cameras, as PBA's SetFocalMask
         la = np.arange(sc.m, dtype=np.int32); lb = (la + 1) % sc.m      # does it -- a ring of quadratic couplings between the cameras' focal lengths
         w = np.zeros((sc.m, sc.cnp)); w[:, 6] = (np.sqrt(sc.nobs / sc.m) * args.shared_focal) ** 2 / cfg.f_scale ** 2   # (pba_shim.cpp, ProcessWeightCameraQ)
@@ -206,10 +209,16 @@ def main():
         build_ms = tm["build_ms"] / max(tm["build_launches"], 1)
         # HBM traffic of one k_build launch from the PMC passes committed under profiles/ (rocprofv3 cannot run
         # inside this process); only quoted for the configuration it was measured on
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02b_build_traffic_%s.json" % args.config)
-        if world == 1 and not args.deterministic and os.path.exists(tpath):
-            traffic = json.load(open(tpath))["hbm_bytes_gfx950_corrected"]
+        traffic, tpath = None, None
+        if world == 1 and not args.deterministic:
+            import glob
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from build_traffic import build_source_sha
+            for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_build_traffic_%s.json" % args.config)), reverse=True):
+                rec = json.load(open(cand))
+                if rec.get("build_source_sha") == build_source_sha():      # measured on these very kernels and this planner
+                    traffic, tpath = rec["hbm_bytes_gfx950_corrected"], cand
+                    break
         achieved = tm["build_bytes"] / (build_ms * 1e-3) / 1e9 if build_ms > 0 else 0.0
         out = {
             "metric": "LM iterations/sec (+ final reprojection RMSE), 1k cams / 1M pts",
@@ -238,7 +247,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "the build: k_build (fused linearise + Schur complement in register tiles) + the row path "
                                                     "(k_build row tiles, k_long_reduce, k_schur_blocks) between one pair of HIP events",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": os.path.relpath(tpath, ROOT) + " (rocprofv3 FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
+                         "traffic": traffic, "traffic_source": os.path.relpath(tpath, ROOT) + " (rocprofv3 FETCH_SIZE / WRITE_SIZE passes)" if traffic
+                         else "none: no PMC pass under profiles/ was taken on the present kernels.hip / plan.cpp (tools/profile_round.sh)",
                          "algorithmic_bytes_per_launch": tm["build_bytes"],
                          "algorithmic_bytes_formula": "24 k + 96 n + 192 m + 512 nb_up (SURVEY 8d Pass A in f64; the engine's own tables are not in it)",
                          "engine_table_bytes_per_launch": tm["build_index_bytes"], "avg_launch_ms": build_ms,

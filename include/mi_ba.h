@@ -85,7 +85,9 @@ typedef struct {
      * [opts[3], opts[4]] after a success (__lm_minimum_damp, __lm_maximum_damp), mu <- mu nu, nu <- 2 nu after a failure;
      * stops: sqrt(d'D d) <= opts[2] (__lm_delta_threshold; stop code 2), gradient |g|_inf <= opts[1] when opts[1] > 0
      * (__lm_check_gradient; stop code 1), itmax TRIALS (stop code 3).  The mean-squared-error and time-budget rules are the
-     * caller's (pba_shim.cpp).  opts[5] is not used.  2: the same controller with PBA's identity damping (mu I; its
+     * caller's (pba_shim.cpp).  opts[5] > 0 is PBA's __lm_damping_auto_switch (:3962-3966): after a failed trial whose mu is above
+     * it the solve continues as variant 2 from mu = opts[5]; the upper bound opts[4] holds under variant 1 only (:3948).
+     * 2: the same controller with PBA's identity damping (mu I; its
      * __lm_use_diagonal_damp off). */
     int lm_variant;
     int pcg_minit;          /* the reduced solve's tolerance test counts from this iteration on (PBA: __cg_min_iteration = 10) */
@@ -185,8 +187,13 @@ typedef struct {
      * update): the part of a trial that does not shrink with the number of GPUs */
     double exchange_ms, exchanges_timed;
     double replicated_ms, replicated_timed;
+    double reserved[11];                   /* the struct stays 32 doubles from here on: new figures come out of this tail */
 } mi_ba_timing;
+/* ABI note: the struct grew twice before it got its tail (17 doubles in round 1, 21 in round 2, 32 now).  A caller compiled
+ * against an older header passes a smaller struct: it must use mi_ba_get_timing_n with ITS sizeof (at most that many bytes are
+ * written); mi_ba_get_timing writes sizeof(mi_ba_timing) of THIS header. */
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
+int mi_ba_get_timing_n(const mi_ba_engine *e, void *t, size_t bytes);
 int mi_ba_reset_timing(mi_ba_engine *e);
 /* which phases are bracketed by HIP events: 0 (default) none, 1 the build kernels, 2 also the reduced solve and the
  * back-substitution.  An event on the stream costs ~6 us of idle GPU, so device-side times are something to ask for

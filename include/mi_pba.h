@@ -29,7 +29,9 @@ public:
     int __bundle_time_budget;       /* "-budg" / SetNextTimeBudget: seconds, 0 = none ('T')            */
     int __bundle_mode_next;         /* "-moti" 1 / "-stru" 2 (ConfigBA.cpp:528-533)                     */
     int __cg_max_iteration;         /* "-cgi": PCG iteration cap                                        */
-    float __cg_norm_threshold;      /* "-cgn": PCG stop, sqrt(r'z/r0'z0)                                */
+    float __cg_norm_threshold;      /* "-cgn": PCG stop, sqrt(r'z/r0'z0).  DELIBERATELY 1e-3 here, not the reference's 0.1
+                                     * (ConfigBA.cpp:62): the reduced system is explicit and L2-resident, an iteration costs
+                                     * microseconds, and the tighter solve saves LM trials; "-cgn 0.1" gives PBA's schedule */
     bool __fixed_intrinsics;        /* SetFixedIntrinsics                                               */
     int __use_radial_distortion;    /* EnableRadialDistortion / "-pd" 1 / "-md", "-radi" -1              */
     int __verbose_level;
@@ -53,7 +55,8 @@ public:
      * diagonals ("-id": on the identity) started at __lm_initial_damp ("-damp") and kept within [__lm_minimum_damp ("-dmin"),
      * __lm_maximum_damp ("-dmax")]; stop 'S' once the step's norm (in the metric of diag J'J) is at or below __lm_delta_threshold
      * ("-lmd"), 'G' on the gradient when __lm_check_gradient ("-chkg", "-lmg"); the CG looks at its tolerance from iteration
-     * __cg_min_iteration ("-cgim") on.  Run as mi_ba.h's lm_variant 1 / 2; MI_PBA_SBA_LM=1 in the environment runs sba's
+     * __cg_min_iteration ("-cgim") on; __lm_damping_auto_switch ("-das [x]", :3962-3966): once a failed trial's damping
+     * is above it the run goes on with identity damping from that value (mi_ba.h opts[5] under lm_variant 1).  Run as mi_ba.h's lm_variant 1 / 2; MI_PBA_SBA_LM=1 in the environment runs sba's
      * controller instead (round 1's behaviour: same minima, two to three times the iterations on the golden cases). */
     float __lm_initial_damp, __lm_minimum_damp, __lm_maximum_damp, __lm_delta_threshold, __lm_gradient_threshold, __lm_damping_auto_switch;
     bool __lm_use_diagonal_damp, __lm_check_gradient;

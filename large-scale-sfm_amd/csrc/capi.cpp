@@ -84,6 +84,13 @@ int mi_ba_debug_linearize(mi_ba_engine *h, double mu, double *S, double *E, doub
 int mi_ba_debug_solve(mi_ba_engine *h, double mu, double *da, double *db, double *cost_new)
 { return h ? h->e->debug_solve(mu, da, db, cost_new) : MI_BA_ERROR; }
 int mi_ba_get_timing(const mi_ba_engine *h, mi_ba_timing *t) { if (!h || !t) return MI_BA_ERROR; *t = h->e->timing; return 0; }
+static_assert(sizeof(mi_ba_timing) == 32 * sizeof(double), "mi_ba_timing keeps its size: take new fields out of reserved[]");
+int mi_ba_get_timing_n(const mi_ba_engine *h, void *t, size_t bytes)
+{
+    if (!h || !t) return MI_BA_ERROR;
+    std::memcpy(t, &h->e->timing, std::min(bytes, sizeof(mi_ba_timing)));
+    return 0;
+}
 int mi_ba_set_timing_detail(mi_ba_engine *h, int level) { if (!h) return MI_BA_ERROR; h->e->timing_detail = level; return 0; }
 int mi_ba_reset_timing(mi_ba_engine *h)
 {

@@ -32,15 +32,22 @@ constexpr int kTwoLevelFrom = 12;           // ... and built from the first tria
 // program may have changed since the constructor ran (ParallelBA with device != 0, the sharded C ABI used in-process).
 struct DeviceGuard {
     int prev = -1, want;
+    hipError_t status = hipSuccess;             // of the switch to the engine's device: entry points that allocate or create check it
     explicit DeviceGuard(int dev) : want(dev)   // dev < 0: nothing to do (an engine that never opened its device)
     {
         if (want < 0) return;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != want) (void)hipSetDevice(want);
+        if (prev != want) status = hipSetDevice(want);
     }
     ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard &) = delete;
     DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// a host thread that is joined on every way out of the scope that started it (an exception from the planner included)
+struct JoinOnExit {
+    std::thread &t;
+    ~JoinOnExit() { if (t.joinable()) t.join(); }
 };
 
 double now_ms()
@@ -63,6 +70,7 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
     if (cfg.nk != 0 && cfg.nk != 1 && cfg.nk != 2) { err = "nk must be 1 (k1) or 2 (k1 and k2)"; return; }
     if (cfg.lm_variant < 0 || cfg.lm_variant > 2) { err = "lm_variant must be 0 (sba), 1 (PBA) or 2 (PBA, identity damping)"; return; }
     if (cfg.nk == 0) cfg.nk = 1;
+    lm_variant_cfg_ = cfg.lm_variant;
     cnp = 6 + (cfg.est_focal ? 1 : 0) + (cfg.undistort == 1 ? cfg.nk : cfg.undistort == 2 ? 1 : 0);
     split_ = cnp == 9;       // Bundler's full camera (sfm.c:648-649): blocks wider than the 8 x 8 the camera-side kernels are shaped for
     if (cfg.mode < 0 || cfg.mode > 2) { err = "bad bundle mode"; return; }
@@ -75,6 +83,7 @@ Engine::Engine(const mi_ba_config &c) : cfg(c)
     }
     if (cfg.device < 0 || cfg.device >= ndev) { err = "bad device ordinal"; return; }
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return;
     if (!hipok(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking), "hipStreamCreate")) return;
     for (auto &ev : ev_) if (!hipok(hipEventCreate(&ev), "hipEventCreate")) return;
     for (auto &ev : evx_) if (!hipok(hipEventCreate(&ev), "hipEventCreate")) return;
@@ -205,6 +214,7 @@ int Engine::set_observations(int64_t nobs, const double *xy, const int *pt_idx, 
 int Engine::comm_init(const char *id)
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (cfg.world <= 1) return 0;
     ncclUniqueId uid;
     static_assert(sizeof(uid) <= MI_BA_UNIQUE_ID_BYTES, "unique id size");
@@ -220,6 +230,7 @@ int Engine::prepare()
 {
     DeviceGuard on_device(cfg.device);
     if (!created_) return MI_BA_ERROR;
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!m_ || !n_ || !nobs_) { err = "prepare: cameras, points and observations must be set first"; return MI_BA_ERROR; }
     if (cfg.mcon < 0 || cfg.mcon > m_) { err = "prepare: bad mcon"; return MI_BA_ERROR; }
     if (cfg.world > 1 && !comm_ && !host_ar_) { err = "prepare: world > 1 needs mi_ba_comm_init first"; return MI_BA_ERROR; }
@@ -252,6 +263,7 @@ int Engine::prepare()
     // the observation streams are final long before the planner is done (plan.h shard_arrays_ready): a second host thread gathers
     // the measurements into the plan's order and uploads them with the two index streams while the tiling runs
     std::thread early_upload;
+    JoinOnExit join_early_upload{early_upload};
     hipError_t early_err = hipSuccess;
     auto start_early_upload = [&]() {
         early_upload = std::thread([&]() {
@@ -270,8 +282,11 @@ int Engine::prepare()
             early_err = d_obs_xy_.upload(xy);
         });
     };
-    std::string perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches,
-                                  h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic == 2, split_, start_early_upload);
+    std::string perr;
+    try {
+        perr = build_plan(plan_, n_, m_, nobs_, h_pt_.data(), h_cam_.data(), cfg.rank, cfg.world, cfg.tile_max_batches,
+                          h_link_cam_.empty() ? nullptr : &h_link_cam_, cfg.deterministic == 2, split_, start_early_upload);
+    } catch (const std::exception &ex) { perr = std::string("out of host memory or worse (") + ex.what() + ")"; }
     if (early_upload.joinable()) early_upload.join();
     if (perr.empty() && !hipok(early_err, "upload of the observation streams")) return MI_BA_ERROR;
     if (!perr.empty()) { err = "plan: " + perr; return MI_BA_ERROR; }
@@ -438,7 +453,7 @@ int Engine::prepare()
         !hipok(d_E_.alloc((size_t)mv_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)mv_ * kCP), "alloc dA") ||
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)mv_ * kCP * 8), "alloc pcg") ||
         !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)mv_), "alloc rz/pq") ||
-        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), 16384) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
+        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGridMax) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
         !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage") ||
         !hipok(d_cam_part_.alloc((size_t)((mv_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
         !hipok(d_cam_part2_.alloc((size_t)((m_ + 63) / 64 + 1) * kPartW), "alloc camera partials"))
@@ -475,6 +490,7 @@ int Engine::prepare()
 int Engine::set_params(const double *a, const double *xyz)
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_) { err = "set_params: prepare first"; return MI_BA_ERROR; }
     std::vector<double> ap((size_t)mv_ * kCP, 0.0);
     for (int j = 0; j < m_; ++j)
@@ -503,6 +519,7 @@ int Engine::set_params(const double *a, const double *xyz)
 int Engine::restart()
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_ || !d_cam_a_init_.p) { err = "restart: prepare first"; return MI_BA_ERROR; }
     cur_ = 0; cam_lin_valid_ = false;
     if (!hipok(hipMemcpyAsync(d_cam_a_[0].p, d_cam_a_init_.p, d_cam_a_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore cam_a")) return MI_BA_ERROR;
@@ -743,10 +760,10 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
 // camera update, back-substitution, cost at the trial point
 // workgroups of k_backsub: whole rounds of what the chip holds at once (3 wavefronts per SIMD at 168 VGPRs: 3 072), so that no
 // SIMD idles through a part-filled last round; MI_BA_BACKSUB_GRID overrides (probe)
-static int backsub_grid()
+static int backsub_grid()   // never above kBacksubGridMax: prepare() sizes the partial rows for that many (+ the long tracks)
 {
     static const int v = std::getenv("MI_BA_BACKSUB_GRID") ? std::atoi(std::getenv("MI_BA_BACKSUB_GRID")) : 0;
-    return v > 0 ? v : kBacksubGrid;
+    return v > 0 ? std::min(v, kBacksubGridMax) : kBacksubGrid;
 }
 
 bool Engine::update_phase(double mu, double *dB_dev, bool peek)
@@ -780,7 +797,9 @@ bool Engine::read_scalars()
 int Engine::begin()
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_) { err = "begin: prepare first"; return MI_BA_ERROR; }
+    cfg.lm_variant = lm_variant_cfg_;   // (a solve that switched to identity damping starts the next one as configured)
     mu_ = 0; nu_ = 2; itno_ = 0; stop_ = 0; nfev_ = 1; njev_ = 0; nlss_ = 0; dp_L2_ = DBL_MAX; new_outer_ = true;
     pcg_pred_ = pcg_pred_prev_ = 0;      // a new solve: nothing to extrapolate from
     co_on_ = false;
@@ -814,6 +833,7 @@ double Engine::measured_maxdiag() const
 int Engine::step()
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!begun_) { err = "step: begin first"; return MI_BA_ERROR; }
     if (stop_ || (cfg.lm_variant >= 1 ? trials_ : itno_) >= cfg.itmax) { if (!stop_) stop_ = 3; return 2; }
     const double t0 = now_ms();
@@ -888,15 +908,18 @@ int Engine::step()
                 tmp = 1.0 - tmp * tmp * tmp;
                 mu_ *= (tmp >= kOneThird) ? tmp : kOneThird;                                  // :3940-3946
                 nu_ = 2;
-                if (mu_ < mu_min) mu_ = mu_min; else if (mu_max > 0.0 && mu_ > mu_max) mu_ = mu_max;
+                if (mu_ < mu_min) mu_ = mu_min; else if (cfg.lm_variant == 1 && mu_max > 0.0 && mu_ > mu_max) mu_ = mu_max;   // :3948 the upper bound holds under diagonal damping only
                 if (trials_ >= cfg.itmax) stop_ = 3;
                 ret = stop_ ? 2 : 1;
                 spec_ready_ = ret == 1 && spec_enqueued_ && s[SC_SPEC_GO] == 1.0 && s[SC_SPEC_MU] == mu_;
                 break;
             }
             push_trace(pdp_eL2, 0);
-            mu_ *= nu_;                                                                       // :3969-3974
-            {
+            if (cfg.lm_variant == 1 && cfg.opts[5] > 0.0 && mu_ > cfg.opts[5]) {            // :3962-3966 __lm_damping_auto_switch: from here on mu I
+                cfg.lm_variant = 2; mu_ = cfg.opts[5]; nu_ = 2;
+                if (cfg.verbose > 1 && cfg.rank == 0) std::printf("[mi_ba] NOTE: switch to damping with an identity matrix\n");
+            } else {
+                mu_ *= nu_;                                                                   // :3969-3974
                 const int nu2 = (int)((unsigned)nu_ << 1);
                 if (nu2 <= nu_ || !std::isfinite(mu_)) { stop_ = 6; ret = 2; break; }
                 nu_ = nu2;
@@ -970,6 +993,7 @@ void Engine::fill_info(double info[MI_BA_INFOSZ]) const
 int Engine::run(double info[MI_BA_INFOSZ])
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (begin() != 0) return MI_BA_ERROR;
     while (!stop_ && itno_ < cfg.itmax) {
         int r = step();
@@ -988,6 +1012,7 @@ int Engine::run(double info[MI_BA_INFOSZ])
 int Engine::get_params(double *a, double *xyz)
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_) { err = "get_params: prepare first"; return MI_BA_ERROR; }
     const Plan &pl = plan_;
     if (a) {
@@ -1023,6 +1048,7 @@ int Engine::get_params(double *a, double *xyz)
 int Engine::get_rotations(double *R)
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_) { err = "get_rotations: prepare first"; return MI_BA_ERROR; }
     launch_cam_prep(st_, m_, cnp, model(), d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p);
     DevBuf<double> tmp;
@@ -1035,6 +1061,7 @@ int Engine::get_rotations(double *R)
 int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double *eb, double *V, double *diagU, double *cost)
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_) { err = "debug_linearize: prepare first"; return MI_BA_ERROR; }
     if (cfg.world > 1 && (eb || V)) { err = "debug_linearize: point outputs need world == 1"; return MI_BA_ERROR; }
     spec_ready_ = false;   // whatever was enqueued for the next trial is overwritten here
@@ -1100,6 +1127,7 @@ int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double 
 int Engine::debug_solve(double mu, double *da, double *db, double *cost_new)
 {
     DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_) { err = "debug_solve: prepare first"; return MI_BA_ERROR; }
     if (cfg.world > 1 && db) { err = "debug_solve: point outputs need world == 1"; return MI_BA_ERROR; }
     spec_ready_ = false;

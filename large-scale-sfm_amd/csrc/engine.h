@@ -176,6 +176,7 @@ private:
     // LM state (names follow sba_levmar.c:596-613)
     double mu_ = 0, p_eL2_ = 0, init_p_eL2_ = 0, eab_inf_ = 0, dp_L2_ = 0, p_L2_ = 0, maxdiag_ = 0;
     int nu_ = 2, itno_ = 0, stop_ = 0, nfev_ = 0, njev_ = 0, nlss_ = 0;
+    int lm_variant_cfg_ = 0;        // cfg.lm_variant as configured (PBA's auto-switch, opts[5], turns 1 into 2 inside a solve)
     int trials_ = 0;                // lm_variant 1: passes of PBA's loop (its iteration cap counts trials, SparseBundleCPU.cpp:3843)
     bool new_outer_ = true;
     int nfree_cams_ = 0;

@@ -20,6 +20,7 @@ namespace miba {
 constexpr int kCamLin = 24;
 constexpr int kPtOut = 12;
 constexpr int kPartW = 8;      // per-workgroup partial row: [0,4) sums, [4,8) maxima
+constexpr int kBacksubGridMax = 16384; // the most the MI_BA_BACKSUB_GRID probe may ask for: the partial-row buffer holds that many rows
 constexpr int kBacksubGrid = 6144;    // workgroups of k_backsub (each walks a contiguous chunk of batches): two rounds of the 3 072 the chip holds at 3 wavefronts per SIMD
 constexpr int kReduceStage = 64;      // first-stage workgroups of k_reduce_partials
 

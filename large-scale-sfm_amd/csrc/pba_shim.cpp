@@ -50,6 +50,10 @@ void ConfigBA::ParseParam(int argc, char **argv)
         else if (!std::strcmp(a, "-dmin") && v) { if (std::atof(v) > 0) __lm_minimum_damp = (float)std::atof(v); ++i; }
         else if (!std::strcmp(a, "-dmax") && v) { if (std::atof(v) > 0) __lm_maximum_damp = (float)std::atof(v); ++i; }
         else if (!std::strcmp(a, "-id")) __lm_use_diagonal_damp = false;                                              // :473-482
+        else if (!std::strcmp(a, "-das")) {   // :477-480 switch to identity damping once a failed trial's damping passes this (default 2, at least 0.1)
+            float f = 0;
+            if (v && std::sscanf(v, "%f", &f) == 1 && f > 0) __lm_damping_auto_switch = f > 0.1f ? f : 0.1f; else __lm_damping_auto_switch = 2.0f;
+        }
         else if (!std::strcmp(a, "-chkg")) __lm_check_gradient = true;
         else if (!std::strcmp(a, "-cgn") && v) { __cg_norm_threshold = (float)std::atof(v); ++i; }
         else if (!std::strcmp(a, "-dev") && v) { __selected_device = std::atoi(v); ++i; }
@@ -146,6 +150,7 @@ int ParallelBA::RunBundleAdjustment()
         cfg.opts[2] = c.__lm_delta_threshold;
         cfg.opts[3] = c.__lm_minimum_damp;
         cfg.opts[4] = (c.__lm_damping_auto_switch == 0 && c.__lm_use_diagonal_damp) ? c.__lm_maximum_damp : 0.0;   // :3950
+        cfg.opts[5] = (c.__lm_damping_auto_switch > 0 && c.__lm_use_diagonal_damp) ? c.__lm_damping_auto_switch : 0.0; // :3962-3966, the switch to mu I
         cfg.pcg_minit = c.__cg_min_iteration;
     }
     cfg.device = o.device; cfg.verbose = c.__verbose_level >= 3 ? 2 : 0;   // level 2 prints the reference-style lines below, 3 the engine's too

@@ -27,6 +27,22 @@ def test_library_exports_every_declared_symbol():
     assert L.ParallelBA_GetVersion() == 105            # pba.cpp:151-154
 
 
+def test_timing_block_keeps_its_size():
+    """mi_ba_timing is 32 doubles from round 3 on (it grew twice before it got a reserved tail); mi_ba_get_timing_n serves callers
+    compiled against a shorter struct and refuses a null engine"""
+    capi = pkg("capi")
+    assert C.sizeof(capi.Timing) == 32 * 8
+    hdr = open(os.path.join(ROOT, "include", "mi_ba.h")).read()
+    body = re.search(r"typedef struct \{([^}]*)\} mi_ba_timing;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    ndbl = sum(int(mm.group(1)) if (mm := re.search(r"\[(\d+)\]", f)) else 1 for decl in re.findall(r"double([^;]*);", body) for f in decl.split(","))
+    assert ndbl == 32
+    L = capi.lib()
+    L.mi_ba_get_timing_n.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    buf = (C.c_double * 4)()
+    assert L.mi_ba_get_timing_n(None, buf, 32) == -1
+
+
 def test_parallelba_has_the_reference_cxx_abi():
     """mangled names of class ParallelBA = those of the reference's own libpba (symbol table data)"""
     import subprocess

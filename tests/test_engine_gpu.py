@@ -154,6 +154,58 @@ def test_pba_controller_trajectory(oracle, name):
     assert info[6] == 2 or not decided.all()                   # "quit on too small change"
 
 
+def test_pba_damping_auto_switch(oracle):
+    """__lm_damping_auto_switch (SparseBundleCPU.cpp:3962-3966; mi_ba.h opts[5] under lm_variant 1): a failed trial whose damping is
+    above the threshold ends the diagonal damping -- the solve goes on with mu I from mu = threshold, nu = 2, and the upper damping
+    bound no longer applies (:3948).  A badly perturbed start with almost no damping makes the first trials fail; numpy replay."""
+    sc = pkg("scene").make_scene("x", m=12, n=400, d=5, seed=4242, cam_noise=0.04, pt_noise=0.08, f_noise=0.05)
+    opts = (1e-9, 0.0, 1e-6, 1e-10, 1e5, 1e-7)      # hardly any damping to start with; switch once a failure is above 1e-7
+    eng = make_engine(sc, pcg_tol=1e-13, pcg_maxit=400, pcg_minit=10, lm_variant=1, opts=opts, itmax=25)
+    ret, info = eng.run()
+    tr = eng.trace()
+    p = sc.p0.copy(); m, n, cnp = sc.m, sc.n, sc.cnp
+    mu, nu, diag, switched_at = opts[0], 2.0, True, None
+    cost = oracle.cost(sc, p)
+    rows = []
+    for trial in range(25):
+        lin = oracle.linearize(sc, fd_jacobian=0, p=p)
+        S, E, Vinv = reduced_system(lin, sc, mu, damp_diag=diag)
+        da = np.linalg.solve(S, E).reshape(m, cnp)
+        t = np.zeros((n, 3)); np.add.at(t, sc.obs_pt(), np.einsum("oab,oa->ob", lin["W"], da[sc.obs_cam]))
+        db = np.einsum("iab,ib->ia", Vinv, lin["eb"] - t)
+        DU = np.einsum("jaa->ja", lin["U"]) if diag else 1.0
+        DV = np.einsum("iaa->ia", lin["V"]) if diag else 1.0
+        if np.sqrt((DU * da * da).sum() + (DV * db * db).sum()) <= opts[2]:
+            break
+        dL = (da * (mu * DU * da + lin["ea"])).sum() + (db * (mu * DV * db + lin["eb"])).sum()
+        p_new = p + np.concatenate([da.reshape(-1), db.reshape(-1)])
+        c_new = oracle.cost(sc, p_new)
+        ok = np.isfinite(c_new) and c_new < cost
+        rows.append((mu, cost, c_new, ok))
+        if ok:
+            rho = (cost - c_new) / dL
+            p, cost = p_new, c_new
+            mu = max(mu * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3), opts[3]); nu = 2.0
+            if diag: mu = min(mu, opts[4])
+        elif diag and mu > opts[5]:
+            diag, mu, nu, switched_at = False, opts[5], 2.0, len(rows)
+        else:
+            mu *= nu; nu *= 2.0
+    rows = np.array(rows, dtype=float)
+    assert switched_at is not None and switched_at < len(rows), "the scene no longer makes an early trial fail: pick another start"
+    k = min(len(rows), len(tr))
+    decided = np.abs(rows[:k, 2] - rows[:k, 1]) > 1e-10 * rows[:k, 1]
+    kk = k if decided.all() else int(np.argmin(decided)) + 1
+    assert kk > switched_at + 1                                        # the comparison covers trials after the switch
+    assert np.allclose(tr[:kk, 1], rows[:kk, 0], rtol=1e-6) and np.allclose(tr[:kk, 3], rows[:kk, 2], rtol=1e-7)
+    assert np.array_equal(tr[:kk, 4][decided[:kk]], rows[:kk, 3][decided[:kk]])
+    # the engine starts its next solve as configured (diagonal damping again): same trace
+    eng.restart()
+    ret2, info2 = eng.run()
+    tr2 = eng.trace()
+    assert len(tr2) == len(tr) and np.allclose(tr2[:kk, 1], tr[:kk, 1], rtol=1e-12) and np.allclose(tr2[:kk, 3], tr[:kk, 3], rtol=1e-9)
+
+
 @pytest.mark.parametrize("name", ["micro", "C1", "C1t"])
 def test_full_solve_matches_reference(oracle, name):
     """north_star parity bar: final reprojection RMSE within max(1e-3 px, 0.5 %) of the

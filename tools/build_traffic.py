@@ -2,9 +2,21 @@
 'rocprofv3 PMC slots'):  python tools/build_traffic.py <fetch.db> <write.db> <config> <out.json>
 Sums, per linearisation, the build kernels (k_build*, k_long_reduce, k_schur_*) and applies the guide's gfx950 correction: FETCH_SIZE
 tallies a 128-B request of a wide coalesced stream as 64 B, so the read side is doubled (an upper estimate for narrow streams)."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_source_sha():
+    """what the build kernels' traffic depends on: bench.py quotes a traffic file only while this is unchanged"""
+    h = hashlib.sha256()
+    for f in ("large-scale-sfm_amd/csrc/kernels.hip", "large-scale-sfm_amd/csrc/plan.cpp"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(db_path, counter):
@@ -40,6 +52,8 @@ def main():
     raw = (fk + wk) * 1024.0
     json.dump({"workload": config + " 1 GPU", "kernels": rows, "linearisations": lin, "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
                "hbm_bytes_raw": raw, "hbm_bytes_gfx950_corrected": (2.0 * fk + wk) * 1024.0,
+               "build_source_sha": build_source_sha(),
+               "build_source_files": "sha256 over csrc/kernels.hip + csrc/plan.cpp, first 16 hex digits (bench.py quotes this file only while they are unchanged)",
                "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --no-cpu-baseline --steps 4 --warmup 1 "
                        "--config %s`; per linearisation = summed over the build kernels; MI355X_MICROARCH.md: FETCH_SIZE on gfx950 counts 64 B per 128-B "
                        "request of a wide coalesced stream, hence the doubled read side; narrow (4-8 B/lane) streams are uncalibrated, so the corrected "
