@@ -820,6 +820,351 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
 }
 
 // ------------------------------------------------------------------------------------------
+// k_build_mfma: the tile of ONE camera set (plan.h tile mode 3: every point of the tile is seen by the same d cameras,
+// kMfmaMinViews <= d <= kMaxViewsLds) with its Schur blocks on the matrix pipe.
+//
+// With V*^-1 = F F^T (Cholesky factor of the damped inverse, per point) a point's contribution to block (a, b) is
+//     Y_ia W_ib^T = W_ia V*^-1 W_ib^T = Z_ia Z_ib^T,      Z_ia = (A_ia^T B_ia) F_i      (cnp x 3),
+// i.e. over a batch of points  S_ab -= Zt_a^T Zt_b  with  Zt[k = 3 p + c][a cnp + r] = Z_pa[r][c]:  a GEMM with K = 3 x points whose
+// operands are ONE array.  v_mfma_f64_4x4x4_4b_f64 does four independent 4x4x4 products per instruction -- the four 4x4
+// quarters of one 8x8-padded block (a, b) --, so a K-chunk of 4 costs one instruction per block, d (d + 1) / 2 <= 55 of them, fed by
+// 2 d operand loads (ds_read_b64, one f64 per lane: the left operand of camera a serves all b, the right operand of b all a).
+// U_a = sum A^T A goes the same way from At[k = 2 p + e][a cnp + r] = A_pa[e][r] (K = 2 x points, diagonal blocks only).
+// Lane maps of the instruction (tools/mfma_f64_layout_probe.hip, measured): A operand lane = 16 k + 4 blk + i, B operand
+// lane = 16 k + 4 blk + j, D lane = 16 i + 4 blk + j; blk = 2 ti + tj is the quarter (rows 4 ti.., columns 4 tj..).
+// The f64 matrix pipe has the vector pipe's rate (tools/mfma_f64_probe.hip) -- what this buys is issue slots: 1 instruction
+// instead of 16, so the wavefront's per-point phases (and the SIMD's other wavefront) overlap with the products instead of
+// queueing behind 1 100 v_fma_f64 per batch; the 98 accumulator VGPRs + pair-entry bookkeeping of the vector form are gone,
+// and the blocks never leave their registers before the tile ends (one camera set = no hand-over inside the tile).
+// ------------------------------------------------------------------------------------------
+constexpr int mfma_row_stride(int cnp, int d)   // doubles per K row of Zt / At: the d cameras' rows, room for the padded rows 4 ti + i >= cnp of
+{                                               // the last camera, and a stride = 8 mod 16 doubles (four K rows of 8 parameters fall into distinct banks)
+    int zs = d * cnp + (8 - cnp);
+    while (zs % 16 != 8) ++zs;
+    return zs;
+}
+constexpr int mfma_k_rows(int d) { return ((3 * (kWave / d) + 3) / 4) * 4; }   // K rows of a full batch, padded to whole chunks of 4
+constexpr int mfma_big_doubles(int cnp)
+{
+    int best = kWave * 9;                        // phases 1-2: B (6) | e (2) per observation, stride 9
+    for (int d = kMfmaMinViews; d <= kMaxViewsLds; ++d) { const int v = mfma_k_rows(d) * mfma_row_stride(cnp, d); if (v > best) best = v; }
+    return best;
+}
+
+// the three parts of k_build_mfma whose shape is the number of views D: straight-line code per D (a uniform branch around every
+// matrix instruction would cost as much as the instruction), the accumulators indexed statically
+constexpr int mfma_q(int a, int b) { return a * kMaxViewsLds - a * (a - 1) / 2 + (b - a); }   // block (a <= b) in the enumeration of kMaxViewsLds cameras
+constexpr int kMfmaNQ = kMaxViewsLds * (kMaxViewsLds + 1) / 2;
+
+template <int D, int CNP>
+__device__ __forceinline__ void mfma_u_pass(double (&acc)[kMfmaNQ], const double *sBig, int nch, int lane)
+{
+    constexpr int ZS = mfma_row_stride(CNP, D);
+    const double *pl_ = sBig + (lane >> 4) * ZS + 4 * ((lane >> 3) & 1) + (lane & 3), *pr_ = sBig + (lane >> 4) * ZS + 4 * ((lane >> 2) & 1) + (lane & 3);
+    for (int ch = 0; ch < nch; ++ch, pl_ += 4 * ZS, pr_ += 4 * ZS) {
+#pragma unroll
+        for (int a = 0; a < D; ++a)      // (the diagonal block's accumulator holds Z Z^T - A^T A: the right operand negated)
+            acc[mfma_q(a, a)] = __builtin_amdgcn_mfma_f64_4x4x4f64(pl_[a * CNP], -pr_[a * CNP], acc[mfma_q(a, a)], 0, 0, 0);
+    }
+}
+
+template <int D, int CNP>
+__device__ __forceinline__ void mfma_z_pass(double (&acc)[kMfmaNQ], const double *sBig, int nch, int lane)
+{
+    constexpr int ZS = mfma_row_stride(CNP, D);
+    const double *pl_ = sBig + (lane >> 4) * ZS + 4 * ((lane >> 3) & 1) + (lane & 3), *pr_ = sBig + (lane >> 4) * ZS + 4 * ((lane >> 2) & 1) + (lane & 3);
+    for (int ch = 0; ch < nch; ++ch, pl_ += 4 * ZS, pr_ += 4 * ZS) {
+        double zl[D], zr[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) { zl[a] = pl_[a * CNP]; zr[a] = pr_[a * CNP]; }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = a; b < D; ++b) acc[mfma_q(a, b)] = __builtin_amdgcn_mfma_f64_4x4x4f64(zl[a], zr[b], acc[mfma_q(a, b)], 0, 0, 0);
+    }
+}
+
+// the tile's blocks: registers -> HBM.  D lane = 16 i + 4 blk + j: row 4 ti + i, column 4 tj + j of the block
+template <int D, int CNP>
+__device__ __forceinline__ void mfma_flush(const double (&acc)[kMfmaNQ], const BuildArgs &g, int tile, int my_gblk, int lane)
+{
+    constexpr int BLK = CNP * CNP;
+    const int row = 4 * ((lane >> 3) & 1) + (lane >> 4), col = 4 * ((lane >> 2) & 1) + (lane & 3);
+    const bool inside = row < CNP && col < CNP;
+    int slot = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = a; b < D; ++b, ++slot) {
+            const double val = -acc[mfma_q(a, b)];
+            if (g.tile_blk) { if (inside) g.tile_blk[((size_t)tile * kNSlot + slot) * BLK + row * CNP + col] = val; }
+            else {
+                const int gb = rl(my_gblk, slot);
+                if (inside) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + row * kCP + col], val);
+            }
+        }
+}
+
+#define MFMA_FOR_D(d, CALL)                                                                     \
+    switch (d) {                                                                                \
+    case 4: { constexpr int D = 4; CALL; } break;  case 5: { constexpr int D = 5; CALL; } break;      \
+    case 6: { constexpr int D = 6; CALL; } break;  case 7: { constexpr int D = 7; CALL; } break;      \
+    case 8: { constexpr int D = 8; CALL; } break;  case 9: { constexpr int D = 9; CALL; } break;      \
+    default: { constexpr int D = 10; CALL; } break;                                             \
+    }
+static_assert(kMfmaMinViews == 4 && kMaxViewsLds == 10, "MFMA_FOR_D lists the view counts");
+
+template <int CNP, bool FULL>
+__global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_mfma(const BuildArgs g)
+{
+    if (g.tile_mode[g.tile0 + blockIdx.x] != 3) return;
+    if (g.spec && g.spec[0] == 0.0) return;
+    const double mu_lin = g.spec ? g.spec[1] : g.mu;
+#ifdef MIBA_STAMPS
+    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    constexpr int SB = 9, SV = 10, SC = (3 * CNP) | 1;
+    constexpr int kMaxD = kMaxViewsLds, kMaxPts = kWave / kMfmaMinViews;
+    constexpr int NQ = kMfmaNQ;
+    __shared__ __attribute__((aligned(16))) double sBig[mfma_big_doubles(CNP)];   // phases 1-2: B | e rows; then At, then Zt
+    __shared__ __attribute__((aligned(16))) double sV[kMaxPts * SV];              // per point: h (3) at 6.., F (6) at 0..
+    __shared__ __attribute__((aligned(16))) double sC[kMaxD * SC];
+    __shared__ __attribute__((aligned(16))) double sCam[kMaxD * kCamLin];
+    __shared__ int sStart[kMaxPts + 1];
+    __shared__ int sFix[kMaxD];
+
+    const int lane = threadIdx.x;
+    const int tile = g.tile0 + blockIdx.x;
+    const ModelCfg cfg = g.cfg;
+    const int d = g.tile_cslot[tile + 1] - g.tile_cslot[tile];           // views per point = cameras of the tile
+    const int nslots = g.tile_slot[tile + 1] - g.tile_slot[tile];        // = d (d + 1) / 2, slot of (a, b) = its rank in the a <= b enumeration
+    int ZS = 0;
+#pragma unroll
+    for (int dd = kMfmaMinViews; dd <= kMaxD; ++dd) if (d == dd) ZS = mfma_row_stride(CNP, dd);
+    for (int i = lane; i < d * SC; i += kWave) sC[i] = 0.0;
+    for (int i = lane; i < d * (kCamLin / 2); i += kWave) {
+        const int c = i / (kCamLin / 2), piece = i - c * (kCamLin / 2);
+        const int cam = g.cslot_cam[g.tile_cslot[tile] + c];
+        reinterpret_cast<double2 *>(sCam)[i] = reinterpret_cast<const double2 *>(g.cam_lin + (size_t)cam * kCamLin)[piece];
+    }
+    const int my_gblk = lane < nslots ? g.slot_gblk[g.tile_slot[tile] + lane] : 0;
+    const int my_cam = lane < d ? g.cslot_cam[g.tile_cslot[tile] + lane] : 0;
+    if (lane < d) sFix[lane] = g.cam_fixed[my_cam];
+    double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0, ccost = 0.0;
+    double acc[NQ];                          // sum Z_a Z_b^T (- U_a on the diagonal) of the blocks a <= b, in the enumeration of kMaxD cameras
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) acc[i] = 0.0;
+
+    const int b_begin = g.tile_batch[tile], b_end = g.tile_batch[tile + 1];
+    TileDesc td;
+    {
+        const int bi = min(b_begin + lane, b_end);
+        td.obs = g.batch_obs[bi]; td.pt = g.batch_pt[bi]; td.pair_lo = 0; td.pair_hi = 0;
+    }
+    BatchRegs<true> cur, nxt;
+    double X[3];
+    load_batch_level1<true>(g, td, 0, lane, cur);
+    X[0] = g.pts[3 * (size_t)cur.ip]; X[1] = g.pts[3 * (size_t)cur.ip + 1]; X[2] = g.pts[3 * (size_t)cur.ip + 2];
+    nxt = cur;
+    wave_lds_sync();
+    STAMP(0);
+
+    for (int b = b_begin; b < b_end; ++b) {
+        const bool have_next = b + 1 < b_end;
+        const int nob = cur.nob, p0 = cur.p0, npt = cur.npt;
+        const bool active = lane < nob;
+        double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
+        const int lp = cur.ip - p0, cs = cur.cs;
+        bool head = false, cam_is_fixed = false;
+        double pcw = 0.0, pcd[3] = { 0.0, 0.0, 0.0 };
+        // ---- phase 1: residual and Jacobian of the lane's observation
+        {
+            double cl[kCamLin];
+            const double2 *src = reinterpret_cast<const double2 *>(sCam + cs * kCamLin);
+#pragma unroll
+            for (int k = 0; k < kCamLin / 2; ++k) { const double2 v = src[k]; cl[2 * k] = v.x; cl[2 * k + 1] = v.y; }
+            if (have_next) load_batch_level1<true>(g, td, b + 1 - b_begin, lane, nxt);
+            if (active) {
+                cam_is_fixed = sFix[cs] != 0;
+                linearize_obs<CNP, FULL>(cfg, cl, X, cur.xy, cam_is_fixed, e, A, B);
+                cost += e[0] * e[0] + e[1] * e[1];
+                double *row = sBig + lane * SB;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { row[t] = B[0][t]; row[3 + t] = B[1][t]; }
+                row[6] = e[0]; row[7] = e[1];
+            } else {
+#pragma unroll
+                for (int t = 0; t < CNP; ++t) { A[0][t] = 0.0; A[1][t] = 0.0; }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { B[0][t] = 0.0; B[1][t] = 0.0; }
+            }
+            const int lp_prev = __builtin_amdgcn_update_dpp(-2, active ? lp : -2, 0x138, 0xF, 0xF, false);
+            head = active && (lane == 0 || lp != lp_prev);
+            if (head) {
+                sStart[lp] = lane; pl2 += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+                if (FULL && g.pt_cw) {
+                    pcw = g.pt_cw[cur.ip];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) pcd[t] = g.pt_cv[3 * (size_t)cur.ip + t] - X[t];
+                }
+            }
+            if (lane == 0) sStart[npt] = nob;
+        }
+        if (have_next) { X[0] = g.pts[3 * (size_t)nxt.ip]; X[1] = g.pts[3 * (size_t)nxt.ip + 1]; X[2] = g.pts[3 * (size_t)nxt.ip + 2]; }
+        wave_lds_sync();
+        STAMP(1);
+        // ---- phase 2: V_i (00 01 02 11 12 22) and eb_i, 7 points per sweep
+        for (int base = 0; base < npt; base += 7) {
+            const int qd = lane / 9, comp = lane - 9 * qd, lpp = base + qd;
+            if (lane < 63 && lpp < npt) {
+                const int os = sStart[lpp], oe = sStart[lpp + 1];
+                const int r = comp < 3 ? 0 : (comp < 5 ? 1 : (comp < 6 ? 2 : comp - 6));
+                const int c0 = comp < 3 ? comp : (comp < 5 ? comp - 2 : (comp < 6 ? 2 : 6));
+                const int c1 = comp < 6 ? c0 + 3 : 7;
+                double s0 = 0.0, s1 = 0.0;
+                int o = os;
+                for (; o + 1 < oe; o += 2) {
+                    const double *r0 = sBig + o * SB, *r1 = r0 + SB;
+                    s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0));
+                    s1 = fma(r1[3 + r], r1[c1], fma(r1[r], r1[c0], s1));
+                }
+                if (o < oe) { const double *r0 = sBig + o * SB; s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0)); }
+                sV[lpp * SV + comp] = s0 + s1;
+            }
+        }
+        wave_lds_sync();
+        STAMP(2);
+        // ---- phase 3: damped inverse per point, h, and the Cholesky factor F of the inverse (V*^-1 = F F^T, F lower triangular)
+        if (head) {
+            double v00 = sV[lp * SV], v01 = sV[lp * SV + 1], v02 = sV[lp * SV + 2];
+            double v11 = sV[lp * SV + 3], v12 = sV[lp * SV + 4], v22 = sV[lp * SV + 5];
+            double eb0 = sV[lp * SV + 6], eb1 = sV[lp * SV + 7], eb2 = sV[lp * SV + 8];
+            if (FULL && pcw != 0.0) {
+                v00 += pcw; v11 += pcw; v22 += pcw;
+                eb0 += pcw * pcd[0]; eb1 += pcw * pcd[1]; eb2 += pcw * pcd[2];
+                ccost += pcw * (pcd[0] * pcd[0] + pcd[1] * pcd[1] + pcd[2] * pcd[2]);
+            }
+            maxdv = fmax(maxdv, fmax(v00, fmax(v11, v22)));
+            ebinf = fmax(ebinf, fmax(fabs(eb0), fmax(fabs(eb1), fabs(eb2))));
+            if (cfg.damp_diag) { v00 = fma(mu_lin, v00, v00); v11 = fma(mu_lin, v11, v11); v22 = fma(mu_lin, v22, v22); }
+            else { v00 += mu_lin; v11 += mu_lin; v22 += mu_lin; }
+            const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
+            const double det = v00 * c00 + v01 * c01 + v02 * c02;
+            double i00 = 0, i01 = 0, i02 = 0, i11 = 0, i12 = 0, i22 = 0;
+            const bool zero_on_purpose = cfg.points_fixed && cfg.damp_diag;
+            if (det == 0.0 || !isfinite(det)) { if (!zero_on_purpose) sing = 1.0; }
+            else {
+                const double id = 1.0 / det;
+                i00 = c00 * id; i01 = c01 * id; i02 = c02 * id;
+                i11 = (v00 * v22 - v02 * v02) * id; i12 = (v01 * v02 - v00 * v12) * id; i22 = (v00 * v11 - v01 * v01) * id;
+            }
+            const double h0 = i00 * eb0 + i01 * eb1 + i02 * eb2, h1 = i01 * eb0 + i11 * eb1 + i12 * eb2,
+                         h2 = i02 * eb0 + i12 * eb1 + i22 * eb2;
+            // F: a pivot that is not positive means V* is not positive definite to working precision (V = sum B^T B is, and mu > 0):
+            // reported like a singular V*_i -- "increasing damping", sba_levmar.c:1156-1158 -- unless the inverse is zero on purpose
+            double f00 = 0, f10 = 0, f20 = 0, f11 = 0, f21 = 0, f22 = 0;
+            if (i00 > 0.0) {
+                f00 = sqrt(i00);
+                const double r0 = 1.0 / f00;
+                f10 = i01 * r0; f20 = i02 * r0;
+                const double t11 = i11 - f10 * f10;
+                if (t11 > 0.0) {
+                    f11 = sqrt(t11);
+                    f21 = (i12 - f20 * f10) / f11;
+                    const double t22 = i22 - f20 * f20 - f21 * f21;
+                    if (t22 > 0.0) f22 = sqrt(t22); else sing = 1.0;
+                } else sing = 1.0;
+            } else if (!(i00 == 0.0 && i11 == 0.0 && i22 == 0.0)) sing = 1.0;
+            double *sv = sV + lp * SV;
+            sv[0] = f00; sv[1] = f10; sv[2] = f20; sv[3] = f11; sv[4] = f21; sv[5] = f22; sv[6] = h0; sv[7] = h1; sv[8] = h2;
+            double *po = g.ptout + (size_t)cur.ip * kPtOut;
+            po[0] = i00; po[1] = i01; po[2] = i02; po[3] = i11; po[4] = i12; po[5] = i22;
+            po[6] = h0; po[7] = h1; po[8] = h2; po[9] = eb0; po[10] = eb1; po[11] = eb2;
+        }
+        wave_lds_sync();
+        STAMP(3);
+        // ---- phase 4: camera-side vectors; At = the observation's A, transposed into K rows (the B | e rows are dead by now)
+        double Z[CNP][3];
+        {
+            const double *sv = sV + lp * SV;
+            const double2 f01 = reinterpret_cast<const double2 *>(sv)[0], f23 = reinterpret_cast<const double2 *>(sv)[1], f45 = reinterpret_cast<const double2 *>(sv)[2];
+            double er[2] = { 0.0, 0.0 };
+            if (active && !cam_is_fixed) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) er[r] = e[r] - (B[r][0] * sv[6] + B[r][1] * sv[7] + B[r][2] * sv[8]);
+#pragma unroll
+                for (int t = 0; t < CNP; ++t) {
+                    const double vea = fma(A[1][t], e[1], A[0][t] * e[0]);
+                    const double vE = fma(A[1][t], er[1], A[0][t] * er[0]);
+                    ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE);
+                    if (g.want_diag) ladd(&sC[cs * SC + 2 * CNP + t], fma(A[1][t], A[1][t], A[0][t] * A[0][t]));
+                }
+            }
+            // Z = (A^T B) F
+#pragma unroll
+            for (int r = 0; r < CNP; ++r) {
+                const double w0 = fma(A[1][r], B[1][0], A[0][r] * B[0][0]), w1 = fma(A[1][r], B[1][1], A[0][r] * B[0][1]),
+                             w2 = fma(A[1][r], B[1][2], A[0][r] * B[0][2]);
+                Z[r][0] = fma(w2, f23.x, fma(w1, f01.y, w0 * f01.x));
+                Z[r][1] = fma(w2, f45.x, w1 * f23.y);
+                Z[r][2] = w2 * f45.y;
+            }
+            if (active) {
+                double *dst = sBig + (2 * lp) * ZS + cs * CNP;
+#pragma unroll
+                for (int t = 0; t < CNP; ++t) { dst[t] = A[0][t]; dst[ZS + t] = A[1][t]; }
+            }
+            // K rows beyond this batch's points, up to whole chunks, are zero (at most 3 rows)
+            for (int i = 2 * npt * ZS + lane; i < ((2 * npt + 3) & ~3) * ZS; i += kWave) sBig[i] = 0.0;
+        }
+        wave_lds_sync();
+        STAMP(4);
+        // ---- phase 5a: U_a = sum At_a^T At_a on the matrix pipe, into the diagonal blocks' accumulators
+        MFMA_FOR_D(d, (mfma_u_pass<D, CNP>(acc, sBig, (2 * npt + 3) >> 2, lane)));
+        wave_lds_sync();
+        STAMP(5);
+        // ---- Zt over At
+        if (active) {
+            double *dst = sBig + (3 * lp) * ZS + cs * CNP;
+#pragma unroll
+            for (int t = 0; t < CNP; ++t) { dst[t] = Z[t][0]; dst[ZS + t] = Z[t][1]; dst[2 * ZS + t] = Z[t][2]; }
+        }
+        for (int i = 3 * npt * ZS + lane; i < ((3 * npt + 3) & ~3) * ZS; i += kWave) sBig[i] = 0.0;
+        wave_lds_sync();
+        STAMP(7);
+        // ---- phase 5b: S_ab -= Zt_a^T Zt_b: per K-chunk of 4 the 2 d operands, then one instruction per block
+        MFMA_FOR_D(d, (mfma_z_pass<D, CNP>(acc, sBig, (3 * npt + 3) >> 2, lane)));
+        wave_lds_sync();
+        STAMP(5);
+        if (have_next) cur = nxt;
+    }
+    {
+        MFMA_FOR_D(d, (mfma_flush<D, CNP>(acc, g, tile, my_gblk, lane)));
+        wave_lds_sync();
+        const int which = lane / CNP, t = lane - which * CNP;
+        for (int k = 0; k < d; ++k) {
+            if (g.tile_blk) { if (lane < 3 * CNP) g.tile_cam[((size_t)tile * kNCSlot + k) * (3 * kCP) + lane] = sC[k * SC + lane]; }
+            else {
+                const int cam = rl(my_cam, k);
+                if (lane < 3 * CNP) gadd(&g.camvec[((size_t)which * g.m + cam) * kCP + t], sC[k * SC + lane]);
+            }
+        }
+    }
+    STAMP(6);
+#ifdef MIBA_STAMPS
+    if (lane == 0 && g.dbg)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g.dbg[i], stamp_acc[i]);
+#endif
+    cost = wave_sum(cost); pl2 = wave_sum(pl2); ccost = wave_sum(ccost);
+    ebinf = wave_max(ebinf); maxdv = wave_max(maxdv); sing = wave_max(sing);
+    if (lane == 0) {
+        double *pr = g.part + (size_t)tile * kPartW;
+        pr[0] = cost; pr[1] = pl2; pr[2] = ccost; pr[3] = 0.0; pr[4] = ebinf; pr[5] = maxdv; pr[6] = sing; pr[7] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Ordered hand-over (mi_ba_config.deterministic = 1): the register and table tiles leave their blocks and camera vectors in
 // per-tile copies (k_build above) instead of adding them to S with f64 atomics; these two kernels sum the copies in tile order --
 // one wavefront per block of S / per camera, the plan's list of (tile, slot) contributors -- so two runs give the same bits.
@@ -2411,7 +2756,8 @@ static void launch_build_t(hipStream_t st, bool lds_mode, int ntiles, const Buil
 {
     if (lds_mode) {
         // both variants walk the same tile range; a workgroup whose tile belongs to the other variant leaves at once
-        hipLaunchKernelGGL((k_build<CNP, true, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
+        if (a.has_mfma) hipLaunchKernelGGL((k_build_mfma<CNP, FULL>), dim3(ntiles), dim3(64), 0, st, a);
+        if (a.has_reg) hipLaunchKernelGGL((k_build<CNP, true, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
         if (a.has_table) hipLaunchKernelGGL((k_build<CNP, true, FULL, true>), dim3(ntiles), dim3(64), 0, st, a);
     } else hipLaunchKernelGGL((k_build<CNP, false, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
 }

@@ -361,6 +361,10 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     int t = 0, t_rows = 0;            // t_rows: first local point of the row path
     std::string tiling_error;
     // dry: only the shape of the LDS tiles (tile_log) is wanted -- no pair entries, no slots per observation, class 0 only
+    // opt-in (MI_BA_MFMA=1): measured SLOWER than the vector form of the same tiles (C3 build 1.15 ms against 0.82: the f64 matrix
+    // pipe has the vector pipe's rate, and 8 x 8-padded blocks with K padded to 4 are 1.37x the vector form's arithmetic)
+    const char *mf = std::getenv("MI_BA_MFMA");
+    const bool use_mfma = !cam_split && mf && mf[0] == '1';
     auto do_tiling = [&](int tile_max_batches, bool dry) {
     tile_log.clear();
     pl.pair.clear(); pl.slot_gblk.clear(); pl.cslot_cam.clear(); pl.tile_mode.clear();
@@ -377,7 +381,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     const int *sig_cams = nullptr; int sig_d = -1;
     int cur_obs = 0, batches_in_tile = 0, sig_runs_in_tile = 0;
     t = 0;
-    pl.ntile_table = 0;
+    pl.ntile_table = 0; pl.ntile_mfma = 0;
 
     std::vector<uint32_t> round_buf;  // pair entries of the round being filled (LDS tiles)
     bool rounds_mode = true;
@@ -451,9 +455,13 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         pl.tile_cslot.push_back((int)pl.cslot_cam.size());
         // many camera sets in one tile: a lane would hand its register block to HBM almost every round (the L2's f64
         // atomic rate is the bound then) -> the tile sums its <= kNSlot blocks in LDS instead
-        const uint8_t m2 = (mode == 1 && sig_runs_in_tile > kTableRuns) ? 2 : mode;
+        uint8_t m2 = (mode == 1 && sig_runs_in_tile > kTableRuns) ? 2 : mode;
+        // one camera set of >= kMfmaMinViews views for the whole tile: lane = (point, camera) in every batch, the slots are the
+        // a <= b enumeration of its cameras -- the tile's blocks go through the matrix pipe (k_build_mfma)
+        if (mode == 1 && sig_runs_in_tile == 1 && sig_d >= kMfmaMinViews && use_mfma) m2 = 3;
         pl.tile_mode.push_back(m2);
         if (m2 == 2) pl.ntile_table++;
+        if (m2 == 3) pl.ntile_mfma++;
         sig_runs_in_tile = 0;
         if (mode == 1) tile_log.emplace_back(batches_in_tile, batches_in_tile >= tile_max_batches);
         pl.max_slots = std::max(pl.max_slots, (int)smap.size());
@@ -475,6 +483,11 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             if (batches_in_tile >= tile_max_batches) { close_tile(1); same_sig = false; }
         }
         if (!same_sig) {
+            // a tile that so far holds ONE camera set of a long run ends here, so that it can take the matrix pipe (mode 3)
+            if (use_mfma && sig_runs_in_tile == 1 && sig_d >= kMfmaMinViews && batches_in_tile + (cur_obs > 0 ? 1 : 0) >= kMfmaMinBatches) {
+                close_batch(t);
+                close_tile(1);
+            }
             int newb = 0, newc = 0;
             for (int a = 0; a < d; ++a) {
                 if (!cmap.count(c[a])) newc++;

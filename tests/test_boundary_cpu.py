@@ -334,7 +334,16 @@ def _check_plan(sc, rank=0, world=1, tmb=0, all_rows=False):
         o0, o1 = g["batch_obs"][b], g["batch_obs"][b + 1]
         assert 0 < o1 - o0 <= 64 and g["batch_pt"][b + 1] - g["batch_pt"][b] <= 32
         t = tile_of_batch[b]
-        lds = g["tile_mode"][t] in (1, 2)
+        lds = g["tile_mode"][t] in (1, 2, 3)
+        if g["tile_mode"][t] == 3:  # one camera set (k_build_mfma): lane = point * d + camera slot, slot of (a, b) = its rank in the a <= b enumeration
+            d = g["tile_cslot"][t + 1] - g["tile_cslot"][t]
+            assert 4 <= d <= 10 and g["tile_slot"][t + 1] - g["tile_slot"][t] == d * (d + 1) // 2 and (o1 - o0) % d == 0
+            cams = g["cslot_cam"][g["tile_cslot"][t]:g["tile_cslot"][t + 1]]
+            assert np.all(np.diff(cams) > 0)
+            assert np.array_equal(g["obs_cam"][o0:o1], np.tile(cams, (o1 - o0) // d)) and np.array_equal(g["obs_cslot"][o0:o1], np.tile(np.arange(d), (o1 - o0) // d))
+            assert np.array_equal(g["obs_pt"][o0:o1] - g["batch_pt"][b], np.repeat(np.arange((o1 - o0) // d), d))
+            want_blk = [up[(cams[a], cams[c])] for a in range(d) for c in range(a, d)]
+            assert list(g["slot_gblk"][g["tile_slot"][t]:g["tile_slot"][t + 1]]) == want_blk
         off, nr = int(g["batch_pair"][b]) & ((1 << 48) - 1), int(g["batch_pair"][b]) >> 48      # batches of one camera set share their entries
         ents = g["pair"][off:off + 64 * nr]
         if not lds:                 # a row tile: no pair entries, every observation has a record
@@ -402,6 +411,17 @@ def test_plan_tables_coherent_scene():
     assert st["nbatch_rows"] == 0 and st["npts_local"] == sc.n and st["nb_upper"] == len(g["up_col"]) and st["nrec"] == 0
     st, g = _check_plan(sc, all_rows=True)        # the deterministic mode: every point on the row path
     assert st["nbatch_rows"] == st["nbatch"] and st["nrec"] == sc.nobs and st["npair"] == 0
+
+
+def test_plan_tables_with_matrix_pipe_tiles(monkeypatch):
+    """MI_BA_MFMA=1: tiles of one camera set become mode 3 and end where the set changes; what k_build_mfma relies on (lane =
+    point * d + camera slot, slots in the a <= b enumeration) is checked by _check_plan"""
+    monkeypatch.setenv("MI_BA_MFMA", "1")
+    for d in (4, 7, 10):
+        sc = pkg("scene").make_scene("x", m=24, n=2400, d=d, seed=100 + d, strides=(1,))
+        assert (pkg("capi").Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).get("tile_mode") == 3).mean() > 0.6
+        _check_plan(sc)
+        _check_plan(sc, rank=1, world=2)
 
 
 def test_plan_tables_ragged_scene():
