@@ -959,8 +959,8 @@ int Engine::step()
                     if (cfg.mode == 0 && s[SC_MAX_PCT] < eps5 && itno_ >= 4) { stop_ = 8; discard = true; } // motstr only
                 }
                 if (cfg.verbose > 1 && cfg.rank == 0)   // per accepted step: iteration, damping, cost, PCG iterations, Bundler's max_pct_change (:1563)
-                    std::printf("[mi_ba] it %3d  mu %.3e  cost %.9g -> %.9g  pcg %3d  max_pct_change %.4g\n", itno_, mu, p_eL2_, pdp_eL2,
-                                (int)s[SC_PCG_ITERS], s[SC_MAX_PCT]);
+                    std::printf("[mi_ba] it %3d  mu %.3e  cost %.9g -> %.9g  pcg %3d  max_pct_change %s eps5\n", itno_, mu, p_eL2_, pdp_eL2,
+                                (int)s[SC_PCG_ITERS], s[SC_MAX_PCT] < eps5 ? "<" : ">=");   // (the kernels keep one bit of it: pct_change_flag)
                 if (!discard) { accept_trial(); p_eL2_ = pdp_eL2; c_lag_ = c_cur; }
                 end_outer();
                 ret = stop_ ? 2 : 1;

@@ -202,6 +202,20 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
     }
 }
 
+// Bundler's "residuals changed by less than eps5" exit (sba_levmar.c:1552-1572) only ever compares the largest relative change
+// with eps5, so a trial needs ONE bit of it: did some residual component change by eps5 or more?  |e - en| / |e| >= eps5 is
+// tested as |e - en| >= eps5 |e| -- no f64 division per observation (two of them were a tenth of k_backsub's instructions) --
+// with the reference's quirks kept: the signed comparison that exempts a component (:1554), 0 / 0 skipped, x / 0 = a change.
+// SC_MAX_PCT carries +inf ("some component moved") or 0; "SC_MAX_PCT < eps5" reads as before for every eps5.
+__device__ __forceinline__ double pct_change_flag(double e, double en, double eps5)
+{
+    const double dd = fabs(e - en), ae = fabs(e);
+    const bool exempt = (e < eps5) & (en < eps5);                                 // the reference's signed test
+    const bool skip = ((dd == 0.0) & (ae == 0.0)) | (ae == __builtin_inf());      // 0 / 0 and x / inf: NaN or 0 there, never the maximum
+    const bool moved = dd >= eps5 * ae;                                           // false when a residual is NaN: the reference's max skips NaN too
+    return (moved & !exempt & !skip) ? __builtin_inf() : 0.0;                     // (no branches: selects)
+}
+
 // What the back-substitution needs of an observation: the residual e, and t = B^T (A da) -- the camera block A only
 // through its product with the camera's update.  With the per-camera vectors v0 = dq/d(centre or translation) . dC
 // (= -R dC with explicit centres, dt otherwise) and u = J_l(w) dw, A da = Pq (v0 - qr x u) + the intrinsics columns,
@@ -495,6 +509,10 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
     __shared__ double sTab[TABLE ? kNSlot * BLK : 1];
     __shared__ int sStart[kMaxPtsBatch + 1];  // first lane of every point of the batch
     __shared__ int sFix[LDS ? kNCSlot : 1];   // per camera slot: the camera is held fixed
+#ifdef MIBA_OCC1   // probe build (make occ1): 24 KB of unused LDS = ONE tile per SIMD, to see what the second wavefront buys
+    __shared__ double sPad[3072];
+    if (g.m < 0) sPad[threadIdx.x] = 1.0;
+#endif
 
     const int lane = threadIdx.x;
     const int tile = g.tile0 + blockIdx.x;
@@ -647,13 +665,32 @@ __global__ __launch_bounds__(64, (CNP <= 7 && LDS && !TABLE ? 2 : 1)) void k_bui
                 const int c0 = comp < 3 ? comp : (comp < 5 ? comp - 2 : (comp < 6 ? 2 : 6));
                 const int c1 = comp < 6 ? c0 + 3 : 7;
                 double s0 = 0.0, s1 = 0.0;
-                int o = os;
-                for (; o + 1 < oe; o += 2) {
-                    const double *r0 = sR + o * SR + OB, *r1 = r0 + SR;
-                    s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0));
-                    s1 = fma(r1[3 + r], r1[c1], fma(r1[r], r1[c0], s1));
+                if constexpr (LDS) {
+                    // a point of an LDS tile has <= kMaxViewsLds views: all operand loads issued at once instead of a loop of
+                    // dependent LDS round trips (the wavefront has nothing else to do here)
+                    constexpr int H = kMaxViewsLds / 2;           // two groups of five views: 20 loads in flight (more would spill)
+#pragma unroll
+                    for (int k0 = 0; k0 < kMaxViewsLds; k0 += H) {
+                        double x0[H], x1[H], y0[H], y1[H];
+#pragma unroll
+                        for (int k = 0; k < H; ++k) {
+                            const double *r0 = sR + min(os + k0 + k, oe - 1) * SR + OB;   // (past the point's end: the last row again, the product is dropped)
+                            x0[k] = r0[r]; y0[k] = r0[c0]; x1[k] = r0[3 + r]; y1[k] = r0[c1];
+                        }
+#pragma unroll
+                        for (int k = 0; k < H; ++k) {
+                            if (os + k0 + k < oe) { if (k & 1) s1 = fma(x1[k], y1[k], fma(x0[k], y0[k], s1)); else s0 = fma(x1[k], y1[k], fma(x0[k], y0[k], s0)); }
+                        }
+                    }
+                } else {
+                    int o = os;
+                    for (; o + 1 < oe; o += 2) {
+                        const double *r0 = sR + o * SR + OB, *r1 = r0 + SR;
+                        s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0));
+                        s1 = fma(r1[3 + r], r1[c1], fma(r1[r], r1[c0], s1));
+                    }
+                    if (o < oe) { const double *r0 = sR + o * SR + OB; s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0)); }
                 }
-                if (o < oe) { const double *r0 = sR + o * SR + OB; s0 = fma(r0[3 + r], r0[c1], fma(r0[r], r0[c0], s0)); }
                 sV[lpp * SV + comp] = s0 + s1;
             }
         }
@@ -1600,10 +1637,7 @@ __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
         project_obs<true>(g.cfg, g.cam_lin_new + (size_t)j * kCamLin, Xn, xy, u, v);
         const double en0 = xy.x - u, en1 = xy.y - v, e0 = row[L::E], e1 = row[L::E + 1];
         cn += en0 * en0 + en1 * en1;
-        double pc = 0.0;
-        if (!(e0 < g.eps5 && en0 < g.eps5)) pc = fmax(pc, fabs((e0 - en0) / e0));
-        if (!(e1 < g.eps5 && en1 < g.eps5)) pc = fmax(pc, fabs((e1 - en1) / e1));
-        if (pc == pc) pct = fmax(pct, pc);
+        pct = fmax(pct, fmax(pct_change_flag(e0, en0, g.eps5), pct_change_flag(e1, en1, g.eps5)));
     }
     cn = block_sum_256(cn, sh);
     pct = wave_max(pct);
@@ -2605,8 +2639,11 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
 // (sba_levmar.c:1393-1433), trial point, cost at p + dp (:1468-1476), dL and ||dp||^2 point parts,
 // and Bundler's max relative residual change (:1552-1561).  One wavefront per batch.
 // ------------------------------------------------------------------------------------------
+#ifndef MIBA_BS_WAVES
+#define MIBA_BS_WAVES 3
+#endif
 template <int CNP, bool FULL>
-__global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
+__global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const BacksubArgs g)   // three wavefronts per SIMD: 168 VGPRs (two more and the allocation granule makes it two wavefronts: 0.20 -> 0.25 ms on C3)
 {
     __shared__ double sT[kWave * 3], sX[kMaxPtsBatch * 3], sD[kWave * 3];
     __shared__ int sStart[kMaxPtsBatch + 1];
@@ -2721,11 +2758,8 @@ __global__ __launch_bounds__(64) void k_backsub(const BacksubArgs g)
             double en0 = xy.x - gg * mx, en1 = xy.y - gg * my;
             if (md) { const double kk = cln[14] * (xy.x * xy.x + xy.y * xy.y); en0 = fma(kk, xy.x, en0); en1 = fma(kk, xy.y, en1); }
             cn += en0 * en0 + en1 * en1;
-            // QUIRK kept from sba_levmar.c:1554: signed comparison against eps5
-            double pc = 0.0;
-            if (!(e[0] < g.eps5 && en0 < g.eps5)) pc = fmax(pc, fabs((e[0] - en0) / e[0]));
-            if (!(e[1] < g.eps5 && en1 < g.eps5)) pc = fmax(pc, fabs((e[1] - en1) / e[1]));
-            if (pc == pc) pct = fmax(pct, pc); // skip 0/0 when both residuals vanish
+            // QUIRK kept from sba_levmar.c:1554: signed comparison against eps5 (pct_change_flag)
+            pct = fmax(pct, fmax(pct_change_flag(e[0], en0, g.eps5), pct_change_flag(e[1], en1, g.eps5)));
         }
         wave_lds_sync();
     }
