@@ -195,7 +195,8 @@ typedef struct {
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_get_timing_n(const mi_ba_engine *e, void *t, size_t bytes);
 int mi_ba_reset_timing(mi_ba_engine *e);
-/* which phases are bracketed by HIP events: 0 (default) none, 1 the build kernels, 2 also the reduced solve and the
+/* which phases are bracketed by HIP events: 0 (default) none, 1 the build kernels (every fourth build: build_ms / build_launches is
+ * the mean over those), 2 every build, the reduced solve and the
  * back-substitution.  An event on the stream costs ~6 us of idle GPU, so device-side times are something to ask for
  * (bench.py: level 1 in its timed steps, level 2 in a second, untimed pass), not something every trial pays. */
 int mi_ba_set_timing_detail(mi_ba_engine *e, int level);

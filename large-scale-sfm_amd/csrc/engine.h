@@ -97,6 +97,7 @@ private:
     hipEvent_t ev_[10] = {};      // build bracket: [0],[1] and [6],[7] alternate from one linear phase to the next (the next trial's
                                   // may be enqueued before this trial's is read); [2..5] reduced solve, back-substitution; [8] scalars copied
     int lin_count_ = 0, lin_pair_ = 0, spec_pair_ = 0;
+    bool lin_timed_[2] = { false, false };   // whether the build of either event pair was bracketed (timing_detail 1 samples)
     // the next trial's linear phase enqueued before the host has seen this trial's outcome (solve_phase)
     bool speculate_ = true, spec_enqueued_ = false, spec_ready_ = false;
     PcgArgs upd_p_{};               // the solve k_cam_update ends (it, last, tail set by solve_phase)
