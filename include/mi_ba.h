@@ -187,7 +187,8 @@ typedef struct {
      * update): the part of a trial that does not shrink with the number of GPUs */
     double exchange_ms, exchanges_timed;
     double replicated_ms, replicated_timed;
-    double reserved[11];                   /* the struct stays 32 doubles from here on: new figures come out of this tail */
+    double pcg_persistent;                 /* reduced solves done by the one persistent launch (k_pcg_persist) instead of a launch per iteration */
+    double reserved[10];                   /* the struct stays 32 doubles from here on: new figures come out of this tail */
 } mi_ba_timing;
 /* ABI note: the struct grew twice before it got its tail (17 doubles in round 1, 21 in round 2, 32 now).  A caller compiled
  * against an older header passes a smaller struct: it must use mi_ba_get_timing_n with ITS sizeof (at most that many bytes are

@@ -466,6 +466,7 @@ int Engine::prepare()
     if (std::getenv("MI_BA_STAMPS")) {
         if (!hipok(d_dbg_.alloc(8), "alloc dbg") || !hipok(hipMemset(d_dbg_.p, 0, 64), "memset dbg")) return MI_BA_ERROR;
     }
+    setup_persist();
     stage("parameters, buffers");
     prepared_ = true;
     if (set_params(h_a0_.data(), h_xyz_.data()) != 0) return MI_BA_ERROR;
@@ -486,6 +487,50 @@ int Engine::prepare()
                      cfg.rank, cfg.world, (long long)npl, (long long)pl.nobs_local(), pl.nbatch(), pl.ntile(), pl.ntile_lds,
                      pl.pair.size(), (long long)pl.nrow_pts, pl.rec_cam[m_], pl.rpair.size() / 2, pl.wk_blk.size(), pl.wk_diag_cam.size(), pl.nb_up(), pl.nb_full());
     return 0;
+}
+
+// The reduced solve in one cooperative launch (k_pcg_persist), OPT-IN (MI_BA_PCG_PERSIST=1): measured slower than a launch per
+// iteration -- C3 12.0 us per iteration against 7.4, C2 8.8 against 6.2 (profiles/r03_persistent_cg_probe.txt): the grid barrier's
+// three dependent cross-XCD round trips cost more than a kernel boundary, and the rest of the iteration is the same chain either way.
+// Usable when every workgroup's share of S~ -- the blocks of <= 8 consecutive block rows -- fits its LDS and all workgroups are
+// resident at once with a margin (a stranded workgroup would stall a barrier until its timeout).  Not with the coarse space (its own
+// kernels), not under the host transport (test set-ups put several ranks' cooperative launches on ONE GPU, where none may be fully resident).
+void Engine::setup_persist()
+{
+    persist_ok_ = false;
+    const char *ev = std::getenv("MI_BA_PCG_PERSIST");
+    if (!(ev && ev[0] == '1')) return;
+    if (co_.ng || host_ar_ || cfg.mode == 2 || mv_ <= 0) return;
+    const Plan &pl = plan_;
+    for (int rows = 4; rows <= 8; ++rows) {
+        const int nwg = (mv_ + rows - 1) / rows;
+        // per workgroup: its blocks, and the distinct columns they reach (its window of the neighbours' vectors)
+        std::vector<int> win_ptr(nwg + 1, 0), win_col, blk_loc(pl.nb_full(), 0), mark(mv_, -1);
+        size_t lds = 0;
+        for (int b = 0; b < nwg; ++b) {
+            const int q0 = pl.bsr_row[b * rows], q1 = pl.bsr_row[std::min(mv_, (b + 1) * rows)];
+            std::vector<int> cols(pl.bsr_col.begin() + q0, pl.bsr_col.begin() + q1);
+            std::sort(cols.begin(), cols.end());
+            cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+            for (size_t k = 0; k < cols.size(); ++k) mark[cols[k]] = (int)k;
+            for (int q = q0; q < q1; ++q) blk_loc[q] = mark[pl.bsr_col[q]];
+            win_col.insert(win_col.end(), cols.begin(), cols.end());
+            win_ptr[b + 1] = (int)win_col.size();
+            lds = std::max(lds, (size_t)(q1 - q0) * (64 * sizeof(double) + sizeof(int)) + cols.size() * (24 * sizeof(double) + sizeof(int)));
+        }
+        lds = (lds + 15) & ~(size_t)15;
+        if (lds > 150 * 1024) break;                               // more rows per workgroup only need more
+        const int cap = pcg_persist_capacity(lds);
+        if (cap <= 0 || nwg > cap - cap / 8) continue;             // a margin of an eighth of the chip
+        const int group = std::max(8, (nwg + kBarMaxGroups - 1) / kBarMaxGroups);
+        if (!hipok(d_bar_.alloc(kBarWords), "alloc barrier words") || !hipok(hipMemset(d_bar_.p, 0, kBarWords * sizeof(unsigned long long)), "memset barrier words") ||
+            !hipok(d_win_ptr_.upload(win_ptr), "upload windows") || !hipok(d_win_col_.upload(win_col), "upload windows") || !hipok(d_blk_loc_.upload(blk_loc), "upload windows")) return;
+        persist_rows_ = rows; persist_nwg_ = nwg; persist_lds_ = lds; persist_group_ = group;
+        persist_ok_ = true;
+        if (cfg.verbose && cfg.rank == 0)
+            std::fprintf(stderr, "[mi_ba] reduced solve: one persistent launch, %d workgroups x %d block rows, %zu KB of LDS each, barrier groups of %d\n", nwg, rows, lds >> 10, group);
+        return;
+    }
 }
 
 int Engine::set_params(const double *a, const double *xyz)
@@ -655,7 +700,7 @@ PeekArgs Engine::peek_args(double mu) const
 PcgStart Engine::pcg_start()
 {
     const PcgArgs p = pcg_args();
-    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1 };
+    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr };
 }
 
 PcgArgs Engine::pcg_args()
@@ -710,15 +755,24 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
     // (histories and partials need no reset: every slot a launch reads was written by an earlier launch of this solve)
     if (timing_detail >= 2) (void)hipEventRecord(ev_[2], st_);
     if (!cg_start_fresh_) launch_pcg_reinit(st_, p);   // a second solve on the same linearisation (parity hooks)
+    const bool fresh = cg_start_fresh_;
     cg_start_fresh_ = false;
-    launch_pcg_init(st_, p);
+    bool persistent = persist_ok_ && !co_active_ && fresh;   // (a second solve's barrier words are not at zero: the launched iteration then)
+    if (persistent) {
+        PersistArgs pg{};
+        pg.a = p; pg.bar = d_bar_.p; pg.rows_per_wg = persist_rows_; pg.maxit = cfg.pcg_maxit; pg.group = persist_group_;
+        pg.win_ptr = d_win_ptr_.p; pg.win_col = d_win_col_.p; pg.blk_loc = d_blk_loc_.p;
+        if (!launch_pcg_persist(st_, pg, persist_nwg_, persist_lds_)) { persist_ok_ = false; persistent = false; }   // refused: never again
+        else timing.pcg_persistent += 1;
+    }
+    if (!persistent) launch_pcg_init(st_, p);
     // the count grows geometrically from trial to trial while the damping falls by 1/3 (measured on C3: 9, 14, 20, 33, 54, 93,
     // then the cap): extrapolate the last ratio, with a margin -- an iteration too many costs 2 us, one too few a round trip
     const double ratio = pcg_pred_prev_ > 0 ? std::min(2.0, std::max(1.0, (double)pcg_pred_ / pcg_pred_prev_)) : 1.0;
     int it0 = std::min(cfg.pcg_maxit, std::max(kPcgChunk, (int)std::ceil(pcg_pred_ * ratio * 1.25) + 3));
     if (const char *force = std::getenv("MI_BA_PCG_FIRST_RUN")) it0 = std::min(cfg.pcg_maxit, std::max(1, std::atoi(force)));   // test hook: make the guess fall short
-    for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
-    p.it = it0; p.last = it0 >= cfg.pcg_maxit; p.tail = 1;
+    if (!persistent) for (int it = 0; it < it0; ++it) { p.it = it; launch_pcg_iter(st_, p); }
+    p.it = it0; p.last = it0 >= cfg.pcg_maxit; p.tail = persistent ? 0 : 1;   // (the persistent launch has set the flags itself)
     upd_p_ = p;                  // k_cam_update: what k_pcg_tail does, then da = Linv^T x~
     p.tail = 0;
     if (timing_detail >= 2) (void)hipEventRecord(ev_[3], st_);
@@ -744,9 +798,14 @@ bool Engine::solve_phase(double mu, double *dB_dev, bool may_speculate)
         spec_enqueued_ = true;
         if (!hipok(hipEventSynchronize(ev_[8]), "sync (scalars)")) return false;
     } else if (!read_scalars()) return false;
-    if (h_scal_[SC_PCG_FINAL] == 0.0) { // the guess fell short
+    if (h_scal_[SC_PCG_FINAL] == 0.0) { // the guess fell short -- or the persistent launch gave up at a barrier (status 3)
         timing.pcg_resumes += 1;
-        if (spec_enqueued_) {           // the linear phase enqueued behind it has overwritten this trial's system: build it again
+        const bool gave_up = persistent && h_scal_[SC_PCG_STATUS] == 3.0;
+        if (persistent) {
+            persist_ok_ = false;        // whatever happened, the launched iteration from here on
+            if (cfg.verbose && cfg.rank == 0) std::fprintf(stderr, "[mi_ba] persistent reduced solve %s: launched iterations from now on\n", gave_up ? "timed out at a barrier" : "did not finish");
+        }
+        if (spec_enqueued_ || persistent) {   // the linear phase enqueued behind it has overwritten this trial's system (or the vectors are a half-done persistent solve's): build it again
             spec_enqueued_ = false;
             if (!linear_phase(mu, false)) return false;
             cg_start_fresh_ = false;
@@ -1137,6 +1196,10 @@ int Engine::debug_solve(double mu, double *da, double *db, double *cost_new)
     if (cfg.world > 1 && db) { err = "debug_solve: point outputs need world == 1"; return MI_BA_ERROR; }
     spec_ready_ = false;
     if (!solve_phase(mu, d_dB_.p)) return MI_BA_ERROR;
+    {
+        float ms = 0;   // (the solve's device time, for tools/pcg_persist_timing.py)
+        if (timing_detail >= 2 && hipEventElapsedTime(&ms, ev_[2], ev_[3]) == hipSuccess) { timing.pcg_ms += ms; timing.pcg_timed += 1; }
+    }
     const Plan &pl = plan_;
     if (cost_new) *cost_new = h_scal_[SC_COST_NEW];
     if (da) {

@@ -47,7 +47,7 @@ public:
     int set_cameras(int m, const double *a0, const double *R0, const double *f_fixed);
     int set_fixed_cameras(const unsigned char *mask);
     int set_fixed_params(const unsigned char *mask);
-    int set_host_allreduce(mi_ba_host_allreduce_fn fn, void *user) { host_ar_ = fn; host_ar_user_ = user; return 0; }
+    int set_host_allreduce(mi_ba_host_allreduce_fn fn, void *user) { host_ar_ = fn; host_ar_user_ = user; if (fn) persist_ok_ = false; return 0; }   // (ranks that share a GPU: no cooperative launches)
     int set_camera_constraints(const double *weights, const double *values);
     int set_camera_links(int nlink, const int *cam_a, const int *cam_b, const double *weights);
     int set_point_constraints(const double *weight, const double *values);
@@ -149,6 +149,13 @@ private:
     DevBuf<long long> d_wk_q_;
     DevBuf<double> d_rec_;                                                             // kRec doubles per row-path observation
     DevBuf<unsigned long long> d_dbg_;
+    // the reduced solve as one persistent cooperative launch (kernels.hip k_pcg_persist) when S~ fits the chip's LDS
+    DevBuf<unsigned long long> d_bar_;       // its grid-barrier words
+    DevBuf<int> d_win_ptr_, d_win_col_, d_blk_loc_;   // per workgroup: the distinct columns of its rows; per block: where its column sits among them
+    bool persist_ok_ = false;                // usable for this problem; cleared for good when a launch is refused or a barrier gives up
+    int persist_rows_ = 0, persist_nwg_ = 0, persist_group_ = 0;
+    size_t persist_lds_ = 0;
+    void setup_persist();
     DevBuf<int> d_long_pts_;
     DevBuf<double> d_cam_cw_, d_cam_cv_, d_pt_cw_, d_pt_cv_;
     DevBuf<int> d_link_row_, d_link_other_, d_link_blk_;

@@ -131,7 +131,9 @@ struct SchurArgs {
 };
 
 // where the CG starts: written by k_block_inv, which holds L^-1 of every camera's diagonal block anyway
-struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; };
+struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
+// grid-barrier words of the persistent reduced solve (u64, 64-byte apart): root counter, generation, abort, one counter per group
+constexpr int kBarRoot = 0, kBarGen = 8, kBarAbort = 16, kBarGroup0 = 32, kBarMaxGroups = 32, kBarWords = kBarGroup0 + 8 * kBarMaxGroups;
 
 // Two-level preconditioner of the reduced solve: block-Jacobi (the scaling) + an additive coarse correction on aggregates of
 // consecutive cameras, M~^-1 = I + Z~ (Z'SZ)^-1 Z~', Z~ = L'Z -- applied INSIDE the one launch an iteration is (kernels.hip, k_pcg2_*).
@@ -163,6 +165,17 @@ struct PcgArgs {
                                                        // every workgroup adding up all nwg partials itself is O(nwg^2) loads per iteration)
     CoarseArgs co;                                     // co.ng == 0: plain block-Jacobi
 };
+
+// the whole reduced solve in one cooperative launch (kernels.hip k_pcg_persist): the scaled matrix in LDS, a grid barrier per iteration
+struct PersistArgs {
+    PcgArgs a;
+    unsigned long long *bar;      // kBarWords barrier words, zeroed by k_block_inv every trial
+    int rows_per_wg, maxit, group; // block rows per workgroup (<= 8), iteration cap, workgroups per barrier group
+    const int *win_ptr, *win_col;  // per workgroup the distinct columns of its rows, ascending (CSR over workgroups): its window of r, w, s
+    const int *blk_loc;            // per block of the full pattern: the position of its column in its workgroup's window
+};
+int pcg_persist_capacity(size_t lds_bytes);                                    // co-resident workgroups at that much dynamic LDS, 0 = cannot run
+bool launch_pcg_persist(hipStream_t st, const PersistArgs &g, int nwg, size_t lds_bytes);   // false: the cooperative launch was refused
 
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
                      const double *f_fixed, double *cam_lin);

@@ -1868,6 +1868,8 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
     __shared__ double sb[4][64], so[4][64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv;
     const bool live = j < m;
+    if (ps.bar && blockIdx.x == 0)        // the persistent solve's barrier words start every trial from zero (k_pcg_persist)
+        for (int i = threadIdx.x; i < kBarWords; i += blockDim.x) ps.bar[i] = 0ull;
     sb[wv][lane] = live ? finalized_element(f, bsr_diag[j], lane) : (lane % 9 == 0 ? 1.0 : 0.0);
     wave_lds_sync();
     // right-looking Cholesky in LDS, lane (r, c): eight steps of (pivot, column, trailing update), the lower triangle of sb
@@ -2570,6 +2572,218 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
+// k_pcg_persist (opt-in, MI_BA_PCG_PERSIST=1: measured SLOWER than a launch per iteration, 12.0 against 7.4 us per iteration on C3 --
+// engine.cpp setup_persist): the whole reduced solve in ONE launch, for systems whose scaled matrix fits the chip's LDS (C3: 28 MB
+// over 200 workgroups).  The same iteration as k_pcg_iter -- Chronopoulos-Gear on S~, the neighbours' new residuals recomputed inside the
+// product, one synchronisation per iteration -- with the launch boundary replaced by a grid barrier:
+//   * a workgroup owns rows_per_wg consecutive block rows; their blocks and column indices are copied into LDS once and stay;
+//     the rows' own vectors (r, w, s, p, x~) live in registers for the whole solve;
+//   * what the neighbours need -- r, w, s of the rows, two dot-product partials per workgroup -- goes through HBM with agent-scope
+//     (sc1) stores, drained (vmcnt 0) before the workgroup arrives at the barrier, and is read with agent-scope loads after it:
+//     the per-XCD L2s are not coherent with each other, a plain load may see a stale line (MI355X_MICROARCH.md, correctness
+//     boundaries; tools/xcd_barrier_probe2.hip: 0 stale values in 2 000 rounds);
+//   * the barrier is a two-level tree of monotonic counters (groups of `group` workgroups, the last arrival of a group reports to the
+//     root, the last of all bumps a generation word everybody polls): 5.2 us per round at 256 workgroups with the exchange against
+//     10 with one counter (profiles/r03_persistent_cg_probe.txt).  Every spin is BOUNDED (50 ms): a workgroup that gives up raises the
+//     abort word, everybody leaves, SC_PCG_STATUS = 3 and SC_PCG_FINAL stays 0 -- the host then solves with the launched iteration
+//     (engine.cpp) and stops using this kernel.  Launched with hipLaunchCooperativeKernel (all workgroups resident, checked).
+// Every workgroup reads the same partials in the same order, so all take the same decisions (convergence, breakdown, the cap) in
+// the same round: no workgroup ever waits at a barrier others have left.  Several ranks: the replicated solve stays bit-identical.
+// ------------------------------------------------------------------------------------------
+typedef unsigned long long u64;
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool persist_barrier(u64 *bar, int group, u64 round /* 1, 2, ... */)
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wavefront's agent-scope stores have reached the coherence point
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        const int n = gridDim.x, b = blockIdx.x;
+        const int grp = b / group, ng = (n + group - 1) / group, gsz = min(group, n - grp * group);
+        const u64 v = __hip_atomic_fetch_add(bar + kBarGroup0 + 8 * grp, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v + 1 == (u64)gsz * round) {                         // last of its group this round
+            const u64 rr = __hip_atomic_fetch_add(bar + kBarRoot, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rr + 1 == (u64)ng * round) __hip_atomic_store(bar + kBarGen, round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const long long t0 = wall_clock64();                     // 100 MHz
+        while (__hip_atomic_load(bar + kBarGen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < round) {
+            if (wall_clock64() - t0 > 5000000ll || __hip_atomic_load(bar + kBarAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+                __hip_atomic_store(bar + kBarAbort, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return __syncthreads_and(ok);
+}
+
+// products of one block row held in LDS (blocks tb .. te of the workgroup's copy) with the NV vectors of the workgroup's window
+// (sWin[local column][vector][8], staged from HBM once per iteration).  Lane (half, r, c2) as in row_products: the lower
+// half-wave takes the row's even blocks, the upper the odd ones.  The result: row r's value in all lanes 8r .. 8r + 7.
+template <int NV>
+__device__ __forceinline__ void row_products_lds(const double *sS, const int *sLoc, const double *sWin, int tb, int te, int lane, double (&out)[NV])
+{
+    const int half = lane >> 5, c2 = (lane & 3) * 2, el = ((lane & 31) >> 2) * 8 + c2;
+    double acc[NV][2];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = 0.0;
+    int t = tb + half;
+    for (; t + 2 < te; t += 4) {
+        const double2 sa = *reinterpret_cast<const double2 *>(sS + (size_t)t * 64 + el), sb = *reinterpret_cast<const double2 *>(sS + (size_t)(t + 2) * 64 + el);
+        const double *xa = sWin + sLoc[t] * 24 + c2, *xb = sWin + sLoc[t + 2] * 24 + c2;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const double2 va = *reinterpret_cast<const double2 *>(xa + 8 * v), vb = *reinterpret_cast<const double2 *>(xb + 8 * v);
+            acc[v][0] = fma(sa.y, va.y, fma(sa.x, va.x, acc[v][0]));
+            acc[v][1] = fma(sb.y, vb.y, fma(sb.x, vb.x, acc[v][1]));
+        }
+    }
+    for (; t < te; t += 2) {
+        const double2 sa = *reinterpret_cast<const double2 *>(sS + (size_t)t * 64 + el);
+        const double *xa = sWin + sLoc[t] * 24 + c2;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { const double2 va = *reinterpret_cast<const double2 *>(xa + 8 * v); acc[v][0] = fma(sa.y, va.y, fma(sa.x, va.x, acc[v][0])); }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        double tt = acc[v][0] + acc[v][1];
+        tt += dpp_move<0xB1>(tt); tt += dpp_move<0x4E>(tt);
+        tt += __shfl_xor(tt, 32);
+        out[v] = __shfl(tt, (lane >> 3) * 4);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pcg_persist(const PersistArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+    __shared__ double sh[4][2], sgd[2];
+    const PcgArgs &a = g.a;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7, nwg = gridDim.x, b = blockIdx.x;
+    const int j0 = b * g.rows_per_wg, j1 = min(a.m, j0 + g.rows_per_wg);
+    const int qb = a.bsr_row[j0], nblk = a.bsr_row[j1] - qb;
+    const int wq0 = g.win_ptr[b], ncol = g.win_ptr[b + 1] - wq0;     // the distinct columns of this workgroup's rows (engine.cpp setup_persist)
+    double *sS = lds_dyn;                                            // nblk x 64: the rows' blocks of S~
+    double *sWin = sS + (size_t)nblk * 64;                           // ncol x 3 x 8: r, w, s of those columns, this iteration's
+    int *sLoc = reinterpret_cast<int *>(sWin + (size_t)ncol * 24);   // nblk: window position of each block's column
+    int *sWcol = sLoc + nblk;                                        // ncol: the columns
+    for (int i = threadIdx.x; i < nblk * 32; i += 256) reinterpret_cast<double2 *>(sS)[i] = reinterpret_cast<const double2 *>(a.S + (size_t)qb * 64)[i];
+    for (int i = threadIdx.x; i < nblk; i += 256) sLoc[i] = g.blk_loc[qb + i];
+    for (int i = threadIdx.x; i < ncol; i += 256) sWcol[i] = g.win_col[wq0 + i];
+    // this wavefront's rows: j0 + wv and j0 + wv + 4 (rows_per_wg <= 8)
+    int jr[2], tb[2], te[2];
+    bool live[2];
+    double r_own[2], w_own[2], s_own[2], p_own[2], x_own[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        jr[k] = j0 + wv + 4 * k;
+        live[k] = jr[k] < j1;
+        const int jj = live[k] ? jr[k] : j0;
+        tb[k] = a.bsr_row[jj] - qb; te[k] = live[k] ? a.bsr_row[jj + 1] - qb : tb[k];
+        r_own[k] = live[k] ? a.r0[jj * 8 + r] : 0.0;
+        w_own[k] = s_own[k] = p_own[k] = x_own[k] = 0.0;
+    }
+    __syncthreads();
+    // the window: 8 consecutive doubles per (column, vector) -- 64-byte pieces, agent-scope loads, all in flight at once
+    auto stage = [&](const double *v0, const double *v1, const double *v2, int nv) {
+        for (int i = threadIdx.x; i < ncol * 24; i += 256) {
+            const int cc = i / 24, rem = i - cc * 24, v = rem >> 3, e = rem & 7;
+            if (v < nv) sWin[i] = ld_agent((v == 0 ? v0 : v == 1 ? v1 : v2) + sWcol[cc] * 8 + e);
+        }
+    };
+    auto publish = [&](int slot, double gg, double dd) {   // the workgroup's two partials, four wavefronts in a fixed order
+        gg = wave_sum(gg); dd = wave_sum(dd);
+        if (lane == 0) { sh[wv][0] = gg; sh[wv][1] = dd; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            st_agent(a.gp + (size_t)slot * nwg + b, (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]));
+            st_agent(a.dp + (size_t)slot * nwg + b, (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]));
+        }
+    };
+    // ---- start: w_0 = S~ r_0 (r_0: k_block_inv, an earlier launch), partials of r_0.r_0 and w_0.r_0
+    {
+        stage(a.r0, a.r0, a.r0, 1);
+        __syncthreads();
+        double gg = 0.0, dd = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double w[1];
+            row_products_lds<1>(sS, sLoc, sWin, tb[k], te[k], lane, w);
+            if (live[k]) {
+                w_own[k] = w[0];
+                if (c == 0) { st_agent(a.w0 + jr[k] * 8 + r, w[0]); gg += r_own[k] * r_own[k]; dd += w[0] * r_own[k]; }
+            }
+        }
+        publish(0, gg, dd);
+    }
+    u64 round = 1;
+    bool alive = persist_barrier(g.bar, g.group, round);
+    double g_zero = 0.0, g_prev = 0.0, a_prev = 0.0;
+    int iters = 0, status = 0, done = 0;
+    for (int it = 0; alive; ++it) {
+        const int par = it & 1;
+        const double *__restrict__ rc = par ? a.r1 : a.r0, *__restrict__ wc = par ? a.w1 : a.w0, *__restrict__ so = par ? a.s1 : a.s0;
+        // one round trip: the two dot products' partials (every workgroup sums all of them in the same order) and the window
+        double gs = 0.0, ds = 0.0;
+        if (wv == 0)
+            for (int i = lane; i < nwg; i += 64) { gs += ld_agent(a.gp + (size_t)par * nwg + i); ds += ld_agent(a.dp + (size_t)par * nwg + i); }
+        stage(rc, wc, so, 3);
+        if (wv == 0) {
+            gs = wave_sum(gs); ds = wave_sum(ds);
+            if (lane == 0) { sgd[0] = gs; sgd[1] = ds; }
+        }
+        __syncthreads();
+        const double gamma = sgd[0], delta = sgd[1];
+        if (it == 0) g_zero = gamma;
+        const bool conv = it == 0 ? !(gamma > 0.0) : (!(g_zero > 0.0) || sqrt(fabs(gamma) / g_zero) < (it >= a.minit ? a.tol : fmin(a.tol, kPcgFloor)));
+        if (conv) { done = 1; break; }
+        if (it >= g.maxit) break;
+        const double beta = it ? gamma / g_prev : 0.0;
+        const double den = it ? delta - beta * gamma / a_prev : delta;   // = p.S~p
+        if (!(den > 0.0) || !isfinite(den)) { status = 2; break; }
+        const double alpha = gamma / den;
+        double *rn = par ? a.r0 : a.r1, *wn = par ? a.w0 : a.w1, *sn = par ? a.s0 : a.s1;
+        double gg = 0.0, dd = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double S3[3];
+            row_products_lds<3>(sS, sLoc, sWin, tb[k], te[k], lane, S3);
+            if (live[k]) {
+                const double s_new = fma(beta, s_own[k], w_own[k]), r_new = fma(-alpha, s_new, r_own[k]), p_new = fma(beta, p_own[k], r_own[k]);
+                const double w_new = fma(-alpha, fma(beta, S3[2], S3[1]), S3[0]);
+                x_own[k] = fma(alpha, p_new, x_own[k]);
+                s_own[k] = s_new; r_own[k] = r_new; p_own[k] = p_new; w_own[k] = w_new;
+                if (c == 0) {
+                    const int idx = jr[k] * 8 + r;
+                    st_agent(sn + idx, s_new); st_agent(rn + idx, r_new); st_agent(wn + idx, w_new);
+                    gg += r_new * r_new; dd += w_new * r_new;
+                }
+            }
+        }
+        publish(par ^ 1, gg, dd);          // (its barrier also orders this iteration's window reads against the next one's staging)
+        g_prev = gamma; a_prev = alpha; iters = it + 1;
+        alive = persist_barrier(g.bar, g.group, ++round);
+    }
+    // ---- the end of the solve: x~ of the rows for k_cam_update (a later launch: plain stores), the flags the host and k_backsub read
+    if (alive) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (live[k] && c == 0) a.x[jr[k] * 8 + r] = x_own[k];
+    }
+    if (b == 0 && threadIdx.x == 0) {
+        a.scal[SC_PCG_ITERS] = (double)iters;
+        if (!alive) a.scal[SC_PCG_STATUS] = 3.0;          // a barrier gave up: nothing of this solve is usable, SC_PCG_FINAL stays 0
+        else {
+            if (done) a.scal[SC_PCG_DONE] = 1.0;
+            if (status) a.scal[SC_PCG_STATUS] = (double)status;
+            a.scal[SC_PCG_FINAL] = 1.0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // camera update: a_new = a + da, new camera record, dL and ||dp||^2 camera parts
 // (sba_levmar.c:1444-1447, 1524-1525)
 // ------------------------------------------------------------------------------------------
@@ -2863,6 +3077,28 @@ void launch_pcg_iter(hipStream_t st, const PcgArgs &a)
 
 
 void launch_pcg_tail(hipStream_t st, const PcgArgs &a) { hipLaunchKernelGGL(k_pcg_tail, dim3(1), dim3(64), 0, st, a); }
+
+// how many workgroups of k_pcg_persist with lds_bytes of dynamic LDS the device holds at once (0: the kernel cannot run like that)
+int pcg_persist_capacity(size_t lds_bytes)
+{
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_pcg_persist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pcg_persist, 256, lds_bytes) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return 0; }
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return per_cu * cus;
+}
+
+bool launch_pcg_persist(hipStream_t st, const PersistArgs &g, int nwg, size_t lds_bytes)
+{
+    PersistArgs args = g;
+    void *params[] = { &args };
+    const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(k_pcg_persist), dim3(nwg), dim3(256), params, lds_bytes, st);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return true;
+}
 
 // after a SUM all-reduce over a block of world x 8 slots in which every rank had filled only its own: the maximum over the
 // ranks (the values are norms and flags, >= 0); the slots are cleared for the next use

@@ -250,6 +250,40 @@ def test_tight_pcg_reproduces_oracle_trajectory(oracle):
     assert abs(info[4] - o["info"][4]) < 1e-6 * o["info"][4]
 
 
+@pytest.mark.parametrize("scene", ["C1", "ring240", "k2"])
+def test_persistent_reduced_solve_equals_the_launched_one(oracle, monkeypatch, scene):
+    """k_pcg_persist: the whole CG in one cooperative launch (S~ in LDS, a grid barrier per iteration) against a launch per iteration
+    (MI_BA_PCG_PERSIST=0): the same iterates up to the order of the dot products' partial sums -- step, trial cost, iteration counts --
+    and the same Levenberg-Marquardt run.  Twenty cameras (5 workgroups), a ring of 240 (60), nine-parameter cameras (split rows)."""
+    if scene == "C1":
+        sc, _ = scene_from_golden("C1")
+    elif scene == "ring240":
+        sc = pkg("scene").make_scene("x", m=240, n=6000, d=6, seed=77, strides=(1,))
+    else:
+        sc = pkg("scene").make_scene("x", m=16, n=600, d=6, seed=5, undistort=1, nk=2)
+    kw = dict(nk=2) if scene == "k2" else {}
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-4 * max(lin["U"].max(), lin["V"].max())
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MI_BA_PCG_PERSIST", mode)
+        eng = make_engine(sc, pcg_tol=1e-10, pcg_maxit=300, **kw)
+        eng.debug_linearize(mu)
+        g = eng.debug_solve(mu)
+        eng.reset_timing()
+        ret, info = eng.run()
+        res[mode] = (g, ret, np.array(info), eng.packed_params().copy(), eng.trace().copy(), eng.timing())
+        eng.close()
+    (g1, ret1, info1, p1, tr1, tm1), (g0, ret0, info0, p0, tr0, tm0) = res["1"], res["0"]
+    assert tm1["pcg_persistent"] >= tm1["pcg_solves"] > 0 and tm1["pcg_resumes"] == 0 and tm0["pcg_persistent"] == 0
+    assert rel(g1["da"], g0["da"]) < 1e-9 and rel(g1["db"], g0["db"]) < 1e-9 and abs(g1["cost_new"] - g0["cost_new"]) < 1e-12 * g0["cost_new"]
+    assert abs(g1["pcg_iters"] - g0["pcg_iters"]) <= 1
+    # (the two runs' CG iterates differ at rounding level -- the partial sums are grouped by different workgroups --, and a whole
+    #  Levenberg-Marquardt run amplifies that to ~1e-8 of the cost)
+    assert ret1 == ret0 and info1[6] == info0[6] and abs(info1[1] - info0[1]) < 1e-6 * info0[1] and np.abs(p1 - p0).max() < 1e-4
+    assert len(tr1) == len(tr0) and np.abs(tr1[:, 5] - tr0[:, 5]).max() <= 2          # CG iterations trial by trial
+
+
 @pytest.mark.parametrize("two_level", ["1", "-1"])
 def test_two_level_preconditioner_same_trajectory_fewer_iterations(oracle, monkeypatch, two_level):
     """MI_BA_TWO_LEVEL (opt-in): block-Jacobi + an additive coarse space on aggregates of cameras inside the one-launch CG
