@@ -2938,6 +2938,7 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
             }
         }
         wave_lds_sync();
+        __builtin_amdgcn_s_setprio(3);   // the six head lanes' chain of latency goes ahead of the SIMD's other wavefronts (0.1985 -> 0.191 ms on C3)
         if (head) { // the head lane of a point owns the point: it already holds X and the ptout row
             const int oe = sStart[lp + 1];
             double t0 = 0.0, t1 = 0.0, t2 = 0.0;
@@ -2959,6 +2960,7 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
             dp2 += D0 * d0 * d0 + D1 * d1 * d1 + D2 * d2 * d2;
         }
         wave_lds_sync();
+        __builtin_amdgcn_s_setprio(0);
         if (active) {
             const double Xn[3] = { sX[lp * 3], sX[lp * 3 + 1], sX[lp * 3 + 2] };
             // project_obs on the compact new record: R = cln[0..8], c = cln[10..12], f = cln[13], k1, k2 = cln[14..15]
