@@ -572,17 +572,38 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         int run = 0;
         for (auto &tl : tile_log) { run += tl.first; if (!tl.second) { segs.push_back(run); run = 0; } }
         if (run) segs.push_back(run);
-        // cost model: the grid runs in rounds of kTileSlots tiles; a round lasts as long as its longest tile,
-        // a tile costs (batches x Tb + Tf) with Tf the fixed prologue/flush share (~1.5 batches, measured)
+        // cost model: a tile costs (batches x Tb + Tf) with Tf the fixed prologue / flush share (~2.5 batch times: the stamps of round 3); the
+        // hardware hands tiles in launch order to whichever of the kTileSlots resident slots frees first, so the build lasts as
+        // long as the longest slot of that list schedule (simulated per candidate length: a heap over the slots).  (Until round 3
+        // the model was "rounds of kTileSlots tiles, each as long as its longest tile".  Measured on C3, build ms by length cap:
+        // 12: 0.854, 16: 0.856, 20: 0.816, 24: 0.834, 28: 0.866 -- many runs of 57-63 batches then end in a tile of a few batches
+        // that pays a whole flush --, 29 / 30: 0.80, 32: 0.787, 40: 1.01.)
+        constexpr double kTileFixed = 2.5;
         double best = 1e300; int best_tmb = tile_max_batches;
+        std::vector<double> slot;
         for (int tmb = kMaxTileBatches; tmb >= 2; --tmb) {
-            long long tiles = 0; int longest = 0;
-            for (int sg : segs) { tiles += (sg + tmb - 1) / tmb; longest = std::max(longest, std::min(sg, tmb)); }
+            long long tiles = 0;
+            for (int sg : segs) tiles += (sg + tmb - 1) / tmb;
             if (!tiles) break;
-            const long long rounds = (tiles + kTileSlots - 1) / kTileSlots;
-            const double cost = (double)rounds * ((double)longest + 1.5);
+            double cost;
+            if (tiles <= kTileSlots) {            // everything resident at once: the longest tile
+                int longest = 0;
+                for (int sg : segs) longest = std::max(longest, std::min(sg, tmb));
+                cost = longest + kTileFixed;
+            } else {
+                slot.assign(kTileSlots, 0.0);     // min-heap of the slots' finish times
+                auto later = [](double a, double b) { return a > b; };
+                for (int sg : segs)
+                    for (int left = sg; left > 0; left -= tmb) {
+                        std::pop_heap(slot.begin(), slot.end(), later);
+                        slot.back() += std::min(left, tmb) + kTileFixed;
+                        std::push_heap(slot.begin(), slot.end(), later);
+                    }
+                cost = *std::max_element(slot.begin(), slot.end());
+            }
             if (cost < best * 0.999) { best = cost; best_tmb = tmb; }
         }
+        if (timing) std::fprintf(stderr, "[mi_ba plan]   tile length %d batches (model: %.1f batch times)\n", best_tmb, best);
         do_tiling(best_tmb, false);
         if (!tiling_error.empty()) return tiling_error;
         stage("tile length + tiling");
