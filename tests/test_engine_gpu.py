@@ -213,6 +213,35 @@ def test_pba_damping_auto_switch(oracle):
     assert len(tr2) == len(tr) and np.allclose(tr2[:kk, 1], tr[:kk, 1], rtol=1e-12) and np.allclose(tr2[:kk, 3], tr[:kk, 3], rtol=1e-9)
 
 
+@pytest.mark.parametrize("det", [0, 1])
+def test_ladybug_shaped_scene_matches_the_reference(oracle, det):
+    """config C4's shape against the REAL reference (tests/golden/ref_ladybug.npz: sba-1.5's own solve of a 120-camera scene with
+    tracks of 3..80 views, every point on the row path, 30 tracks longer than a wavefront): the block-major kernels and the long-track
+    kernels give the reference's trajectory -- same iterations, stop rule and linear systems solved, the accepted-step cost trace to 1e-4, the final
+    RMSE within the stated tolerance; also with three cameras held"""
+    sc, z = scene_from_golden("ladybug")
+    capi = pkg("capi")
+    pl = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam)
+    assert (pl.get("tile_mode") == 0).any() and pl.stats()["nlong"] > 0            # row tiles and tracks longer than a wavefront
+    eng = make_engine(sc, deterministic=det)
+    ret, info = eng.run()
+    want = z["info_final"]
+    assert ret == int(z["ret_final"]) and info[6] == want[6] and info[9] == want[9]
+    assert abs(info[0] - want[0]) <= 1e-9 * want[0]
+    rm, rw = np.sqrt(info[1] / sc.nobs), np.sqrt(want[1] / sc.nobs)
+    assert abs(rm - rw) <= max(1e-3, 0.005 * rw)
+    tr = eng.trace()
+    acc = tr[tr[:, 4] == 1][:, 3]
+    k = min(len(acc), len(z["cost_trace"]))
+    assert k >= 10 and np.allclose(acc[:k], z["cost_trace"][:k], rtol=1e-4)
+    assert abs(oracle.cost(sc, eng.packed_params()) - info[1]) < 1e-9 * info[1]
+    eng.close()
+    eng = make_engine(sc, deterministic=det, mcon=3)
+    ret3, info3 = eng.run()
+    assert ret3 == int(z["ret_mcon3"]) and info3[6] == z["info_mcon3"][6] and abs(info3[1] - z["info_mcon3"][1]) < 1e-5 * z["info_mcon3"][1]
+    assert np.abs(eng.packed_params() - z["p_mcon3"]).max() < 1e-3
+
+
 @pytest.mark.parametrize("name", ["micro", "C1", "C1t"])
 def test_full_solve_matches_reference(oracle, name):
     """north_star parity bar: final reprojection RMSE within max(1e-3 px, 0.5 %) of the

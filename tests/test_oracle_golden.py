@@ -159,6 +159,18 @@ def test_radial_models_match_the_reference(oracle, nk):
         assert np.abs(r["p"] - a["p"]).max() < 1e-4
 
 
+def test_ladybug_shaped_scene_matches_the_reference(oracle):
+    """ref_ladybug.npz (make_golden_ladybug.py): the real sba-1.5 on a scene of config C4's shape -- tracks of 3..80 views, camera
+    sets that do not repeat: the restatement follows it iteration for iteration, free and with three cameras held"""
+    sc, z = scene_from_golden("ladybug")
+    r = oracle.run(sc, itmax=150)
+    assert r["ret"] == int(z["ret_final"]) and all(r["info"][k] == z["info_final"][k] for k in (5, 6, 7, 8, 9))
+    assert abs(r["info"][0] - z["info_final"][0]) <= 1e-12 * z["info_final"][0] and abs(r["info"][1] - z["info_final"][1]) <= 1e-7 * z["info_final"][1]
+    assert np.abs(r["p"] - z["p_final"]).max() < 1e-5
+    r3 = oracle.run(sc, itmax=150, mcon=3)
+    assert r3["ret"] == int(z["ret_mcon3"]) and r3["info"][6] == z["info_mcon3"][6] and np.abs(r3["p"] - z["p_mcon3"]).max() < 1e-5
+
+
 def test_too_few_measurements_is_an_error(oracle):
     sc, _ = scene_from_golden("micro")
     sc.n = 2   # 2 points -> 2*nobs < unknowns (sba_levmar.c:647-650)
