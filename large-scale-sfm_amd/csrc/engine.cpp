@@ -636,7 +636,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     if (!cam_lin_valid_) { launch_cam_prep(st_, m_, cnp, mc, d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p); cam_lin_valid_ = true; }
     BuildArgs a{};
     a.tile_batch = d_tile_batch_.p; a.tile_slot = d_tile_slot_.p; a.tile_cslot = d_tile_cslot_.p;
-    a.tile_mode = d_tile_mode_.p; a.has_table = pl.ntile_table > 0; a.has_mfma = pl.ntile_mfma > 0; a.has_reg = pl.ntile_lds - pl.ntile_table - pl.ntile_mfma > 0;
+    a.tile_mode = d_tile_mode_.p; a.has_table = pl.ntile_table > 0; a.has_mfma = pl.ntile_mfma > 0; a.has_uni = pl.ntile_uni > 0; a.has_reg = pl.ntile_lds - pl.ntile_table - pl.ntile_mfma - pl.ntile_uni > 0;
     a.slot_gblk = d_slot_gblk_.p; a.cslot_cam = d_cslot_cam_.p;
     a.batch_obs = d_batch_obs_.p; a.batch_pt = d_batch_pt_.p; a.batch_pair = d_batch_pair_.p; a.pt_obs = d_pt_obs_.p;
     a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p; a.cam_fixed = d_fixed_real_.p;

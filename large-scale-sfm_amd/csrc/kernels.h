@@ -67,8 +67,8 @@ struct CamLinks {
 };
 
 struct BuildArgs {
-    const unsigned char *tile_mode; // per tile: 1 register-accumulated blocks, 2 LDS block table, 3 one camera set on the matrix pipe, 0 row tiles
-    int has_table, has_reg, has_mfma; // some tile of this launch range has mode 2 / 1 / 3
+    const unsigned char *tile_mode; // per tile: 1 register-accumulated blocks, 2 LDS block table, 3 one camera set on the matrix pipe, 4 one camera set on the vector pipe (k_build_uni), 0 row tiles
+    int has_table, has_reg, has_mfma, has_uni; // some tile of this launch range has mode 2 / 1 / 3 / 4
     const int *tile_batch, *tile_slot, *tile_cslot, *slot_gblk, *cslot_cam;
     const int *batch_obs, *batch_pt;
     const long long *batch_pair;

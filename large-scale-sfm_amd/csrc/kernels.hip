@@ -1207,6 +1207,312 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_mfma(const Build
 }
 
 // ------------------------------------------------------------------------------------------
+// k_build_uni: the tile of ONE camera set (plan.h tile mode 4: every point of the tile is seen by the same D cameras,
+// kUniMinViews <= D <= kMaxViewsLds) on the vector pipe -- what k_build does for any tile, with everything the uniform shape makes
+// constant taken out of the loops:
+//   * lane = point * D + camera in every batch: no per-observation camera / point / slot indices are loaded, the batch
+//     descriptors are arithmetic on the tile's first point, the lane's camera record and fixed flag are per-tile constants;
+//   * the lane's pair (a <= b) and block never change: no pair entries, no decode, no hand-over inside the tile; a round's
+//     operand rows are lane constants + one uniform offset (2 vector adds per round instead of ~45 instructions of
+//     select / decode / address arithmetic); several points per round while D (D + 1) / 2 <= 32;
+//   * G = B V*^-1 per OBSERVATION (phase 4, written over the dead e of the row) instead of per pair: the pair core is
+//     M = delta_ab I - G_a B_b^T (12 FMA, 6 + 6 doubles from LDS) -- 138 instead of 156 FMA and 40 instead of 46 doubles per pair
+//     [the per-pair product that sba_levmar.c:1195-1268 forms as Y_ij = W_ij V*^-1 once per observation as well];
+//   * phase 3 runs on every lane of the point (same instructions as on the head lane alone) straight into phase 4: V*^-1 and h
+//     stay in registers, one LDS round trip and one wave synchronisation less per batch.
+// The blocks leave their registers once, when the tile ends (staged through the rows' LDS, dead by then).
+// ------------------------------------------------------------------------------------------
+template <int CNP, bool FULL>
+__global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildArgs g)
+{
+    if (g.tile_mode[g.tile0 + blockIdx.x] != 4) return;
+    if (g.spec && g.spec[0] == 0.0) return;
+    const double mu_lin = g.spec ? g.spec[1] : g.mu;
+#ifdef MIBA_STAMPS
+    unsigned long long stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stamp_prev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
+    // one 16-byte aligned LDS row per observation: A (2 x CNP) | B (6) | e (2), then G (6) over e.  Row stride SR doubles with SR / 2
+    // odd: 16 distinct rows fall into 16 distinct 16-byte bank slots (conflict-free ds_read_b128 in the pair phase)
+    constexpr int OB = 2 * CNP, OG = OB + 6;
+    constexpr int SR = (((OB + 12) / 2) % 2 == 1) ? OB + 12 : OB + 14;
+    constexpr int SV = 10, BLK = CNP * CNP, SC = (3 * CNP) | 1;
+    constexpr int kMaxD = kMaxViewsLds, kMaxPts = kWave / kUniMinViews;
+    constexpr int kStageBlocks = (kWave * SR) / BLK;         // blocks the rows' LDS holds when the tile hands over
+    __shared__ __attribute__((aligned(16))) double sR[kWave * SR];
+    __shared__ __attribute__((aligned(16))) double sV[kMaxPts * SV];
+    __shared__ __attribute__((aligned(16))) double sC[kMaxD * SC];
+    __shared__ __attribute__((aligned(16))) double sCam[kMaxD * kCamLin];
+
+    const int lane = threadIdx.x;
+    const int tile = g.tile0 + blockIdx.x;
+    const ModelCfg cfg = g.cfg;
+    const int D = g.tile_cslot[tile + 1] - g.tile_cslot[tile];           // views per point = cameras of the tile
+    const int NB = g.tile_slot[tile + 1] - g.tile_slot[tile];            // = D (D + 1) / 2, slot of (a, b) = its rank in the a <= b enumeration
+    const int PB = kWave / D, PPR = kWave / NB;                            // points per batch, points per pair round
+    for (int i = lane; i < D * SC; i += kWave) sC[i] = 0.0;
+    for (int i = lane; i < D * (kCamLin / 2); i += kWave) {
+        const int c = i / (kCamLin / 2), piece = i - c * (kCamLin / 2);
+        const int cam = g.cslot_cam[g.tile_cslot[tile] + c];
+        reinterpret_cast<double2 *>(sCam)[i] = reinterpret_cast<const double2 *>(g.cam_lin + (size_t)cam * kCamLin)[piece];
+    }
+    const int my_gblk = lane < NB ? g.slot_gblk[g.tile_slot[tile] + lane] : 0;
+    const int my_cam = lane < D ? g.cslot_cam[g.tile_cslot[tile] + lane] : 0;
+    // the lane as an observation: point lp of the batch, camera slot cs
+    const int lp = lane / D, cs = lane - lp * D;
+    const bool cam_is_fixed = g.cam_fixed[g.cslot_cam[g.tile_cslot[tile] + cs]] != 0;
+    // the lane as a pair: sub-point ps of the round, block pq = (pa <= pb)
+    const int ps = lane / NB, pq = lane - ps * NB;
+    int pa = 0, pb = pq;
+    while (pb >= D - pa) { pb -= D - pa; ++pa; }
+    pb += pa;
+    const bool pair_lane = ps < PPR;
+    const double dg = (pa == pb) ? 1.0 : 0.0;
+    double cost = 0.0, pl2 = 0.0, ebinf = 0.0, maxdv = 0.0, sing = 0.0, ccost = 0.0;
+    double acc[BLK];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
+
+    const int b_begin = g.tile_batch[tile], b_end = g.tile_batch[tile + 1];
+    const int tp0 = g.batch_pt[b_begin], tp1 = g.batch_pt[b_end], to0 = g.batch_obs[b_begin];
+    const int nbatch = b_end - b_begin;                                    // = ceil((tp1 - tp0) / PB): whole batches but the last (plan.cpp)
+    // first batch's streams; from then on one batch ahead
+    double2 xy = make_double2(0.0, 0.0);
+    double X[3] = { 0.0, 0.0, 0.0 };
+    {
+        const int npt0 = min(PB, tp1 - tp0);
+        if (lp < npt0) {
+            xy = g.obs_xy[to0 + lane];
+            const double *px = g.pts + 3 * (size_t)(tp0 + lp);
+            X[0] = px[0]; X[1] = px[1]; X[2] = px[2];
+        }
+    }
+    wave_lds_sync();   // the camera records are in place
+    STAMP(0);
+
+    for (int k = 0; k < nbatch; ++k) {
+        __builtin_amdgcn_s_setprio(3);
+        const int p0 = tp0 + k * PB, npt = min(PB, tp1 - p0);
+        const bool active = lp < npt;
+        const int ip = p0 + lp;
+        const bool head = active && cs == 0;
+        double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
+        double pcw = 0.0, pcd[3] = { 0.0, 0.0, 0.0 };
+        double *const row = sR + lane * SR;
+        // ---- phase 1: residual and Jacobian of the lane's observation
+        {
+            double cl[kCamLin];
+            const double2 *src = reinterpret_cast<const double2 *>(sCam + cs * kCamLin);
+#pragma unroll
+            for (int t = 0; t < kCamLin / 2; ++t) { const double2 v = src[t]; cl[2 * t] = v.x; cl[2 * t + 1] = v.y; }
+            STAMP(7);
+            if (active) {
+                linearize_obs<CNP, FULL>(cfg, cl, X, xy, cam_is_fixed, e, A, B);
+                cost += e[0] * e[0] + e[1] * e[1];
+#pragma unroll
+                for (int t = 0; t < CNP; ++t) { row[t] = A[0][t]; row[CNP + t] = A[1][t]; }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { row[OB + t] = B[0][t]; row[OB + 3 + t] = B[1][t]; }
+                row[OG] = e[0]; row[OG + 1] = e[1];
+            }
+            if (head) {
+                pl2 += X[0] * X[0] + X[1] * X[1] + X[2] * X[2];
+                if (FULL && g.pt_cw) { // soft point constraint (sba_levmar.c:1017-1029): needs X, which the prefetch below replaces
+                    pcw = g.pt_cw[ip];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) pcd[t] = g.pt_cv[3 * (size_t)ip + t] - X[t];
+                }
+            }
+        }
+        // the next batch's streams: issued now, consumed in its phase 1
+        if (k + 1 < nbatch) {
+            const int p1 = p0 + PB;
+            if (lp < min(PB, tp1 - p1)) {
+                xy = g.obs_xy[to0 + (k + 1) * PB * D + lane];
+                const double *px = g.pts + 3 * (size_t)(p1 + lp);
+                X[0] = px[0]; X[1] = px[1]; X[2] = px[2];
+            }
+        }
+        wave_lds_sync();
+        STAMP(1);
+        // ---- phase 2: V_i upper triangle (00 01 02 11 12 22) and eb_i, lane = (point, component), 7 points per sweep; a point's
+        // rows are lanes lpp D .. lpp D + D - 1.  (the sums in k_build's order: the same bits)
+        for (int base = 0; base < npt; base += 7) {
+            const int qd = lane / 9, comp = lane - 9 * qd, lpp = base + qd;
+            if (lane < 63 && lpp < npt) {
+                const int os = lpp * D, oe = os + D;
+                const int r = comp < 3 ? 0 : (comp < 5 ? 1 : (comp < 6 ? 2 : comp - 6));
+                const int c0 = comp < 3 ? comp : (comp < 5 ? comp - 2 : (comp < 6 ? 2 : 6));
+                const int c1 = comp < 6 ? c0 + 3 : 7;
+                double s0 = 0.0, s1 = 0.0;
+                constexpr int H = kMaxViewsLds / 2;
+#pragma unroll
+                for (int k0 = 0; k0 < kMaxViewsLds; k0 += H) {
+                    double x0[H], x1[H], y0[H], y1[H];
+#pragma unroll
+                    for (int t = 0; t < H; ++t) {
+                        const double *r0 = sR + min(os + k0 + t, oe - 1) * SR + OB;   // (past the point's end: the last row again, the product is dropped)
+                        x0[t] = r0[r]; y0[t] = r0[c0]; x1[t] = r0[3 + r]; y1[t] = r0[c1];
+                    }
+#pragma unroll
+                    for (int t = 0; t < H; ++t) {
+                        if (os + k0 + t < oe) { if (t & 1) s1 = fma(x1[t], y1[t], fma(x0[t], y0[t], s1)); else s0 = fma(x1[t], y1[t], fma(x0[t], y0[t], s0)); }
+                    }
+                }
+                sV[lpp * SV + comp] = s0 + s1;
+            }
+        }
+        wave_lds_sync();
+        STAMP(2);
+        // ---- phases 3 + 4 on every lane of the point: damped inverse (role of sba_symat_invert_BK on a 3x3), h, then the observation's
+        // G = B V*^-1 into its row and the camera-side vectors e_a, E = A^T (e - B h) (+ diag U on request)
+        if (active) {
+            const double2 *sv2 = reinterpret_cast<const double2 *>(sV + lp * SV);
+            const double2 q01 = sv2[0], q23 = sv2[1], q45 = sv2[2], q67 = sv2[3];
+            double v00 = q01.x, v01 = q01.y, v02 = q23.x, v11 = q23.y, v12 = q45.x, v22 = q45.y;
+            double eb0 = q67.x, eb1 = q67.y, eb2 = sV[lp * SV + 8];
+            if (FULL && g.pt_cw) {          // (pcw, pcd live on the head lane: handed to the point's other lanes)
+                const int hl = lp * D;
+                pcw = __shfl(pcw, hl);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) pcd[t] = __shfl(pcd[t], hl);
+                if (pcw != 0.0) {
+                    v00 += pcw; v11 += pcw; v22 += pcw;
+                    eb0 += pcw * pcd[0]; eb1 += pcw * pcd[1]; eb2 += pcw * pcd[2];
+                    if (head) ccost += pcw * (pcd[0] * pcd[0] + pcd[1] * pcd[1] + pcd[2] * pcd[2]);
+                }
+            }
+            maxdv = fmax(maxdv, fmax(v00, fmax(v11, v22)));
+            ebinf = fmax(ebinf, fmax(fabs(eb0), fmax(fabs(eb1), fabs(eb2))));
+            if (cfg.damp_diag) { v00 = fma(mu_lin, v00, v00); v11 = fma(mu_lin, v11, v11); v22 = fma(mu_lin, v22, v22); }
+            else { v00 += mu_lin; v11 += mu_lin; v22 += mu_lin; }
+            const double c00 = v11 * v22 - v12 * v12, c01 = v02 * v12 - v01 * v22, c02 = v01 * v12 - v02 * v11;
+            const double det = v00 * c00 + v01 * c01 + v02 * c02;
+            double i00 = 0, i01 = 0, i02 = 0, i11 = 0, i12 = 0, i22 = 0;
+            if (det == 0.0 || !isfinite(det)) { if (!(cfg.points_fixed && cfg.damp_diag)) sing = 1.0; } // "singular matrix V*_i, increasing damping", :1156-1158
+            else {
+                const double id = 1.0 / det;
+                i00 = c00 * id; i01 = c01 * id; i02 = c02 * id;
+                i11 = (v00 * v22 - v02 * v02) * id; i12 = (v01 * v02 - v00 * v12) * id; i22 = (v00 * v11 - v01 * v01) * id;
+            }
+            const double h0 = i00 * eb0 + i01 * eb1 + i02 * eb2, h1 = i01 * eb0 + i11 * eb1 + i12 * eb2,
+                         h2 = i02 * eb0 + i12 * eb1 + i22 * eb2;
+            if (head) {
+                double *po = g.ptout + (size_t)ip * kPtOut;
+                po[0] = i00; po[1] = i01; po[2] = i02; po[3] = i11; po[4] = i12; po[5] = i22;
+                po[6] = h0; po[7] = h1; po[8] = h2; po[9] = eb0; po[10] = eb1; po[11] = eb2;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                row[OG + 3 * r] = fma(B[r][2], i02, fma(B[r][1], i01, B[r][0] * i00));
+                row[OG + 3 * r + 1] = fma(B[r][2], i12, fma(B[r][1], i11, B[r][0] * i01));
+                row[OG + 3 * r + 2] = fma(B[r][2], i22, fma(B[r][1], i12, B[r][0] * i02));
+            }
+            if (!cam_is_fixed) {
+                double er[2];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) er[r] = e[r] - (B[r][0] * h0 + B[r][1] * h1 + B[r][2] * h2);
+#pragma unroll
+                for (int t = 0; t < CNP; ++t) {
+                    const double vea = fma(A[1][t], e[1], A[0][t] * e[0]);
+                    const double vE = fma(A[1][t], er[1], A[0][t] * er[0]);
+                    ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE);
+                    if (g.want_diag) ladd(&sC[cs * SC + 2 * CNP + t], fma(A[1][t], A[1][t], A[0][t] * A[0][t]));
+                }
+            }
+        }
+        wave_lds_sync();
+        STAMP(4);
+        // ---- phase 5: the lane's block += A_a^T (delta_ab I - G_a B_b^T) A_b of the round's point
+        __builtin_amdgcn_s_setprio(0);
+        {
+            const int nrounds = (npt + PPR - 1) / PPR;
+            const double *ra = sR + (ps * D + pa) * SR, *rb = sR + (ps * D + pb) * SR;
+            const int step = PPR * D * SR;
+            for (int r = 0; r < nrounds; ++r, ra += step, rb += step) {
+                if (pair_lane && r * PPR + ps < npt) {
+                    const double2 *Ga2 = reinterpret_cast<const double2 *>(ra + OG), *Bb2 = reinterpret_cast<const double2 *>(rb + OB);
+                    const double2 g01 = Ga2[0], g23 = Ga2[1], g45 = Ga2[2], b01 = Bb2[0], b23 = Bb2[1], b45 = Bb2[2];
+                    const double2 *Ab2 = reinterpret_cast<const double2 *>(rb), *Aa2 = reinterpret_cast<const double2 *>(ra);
+                    double Ab[2 * CNP], Aa[2 * CNP];
+#pragma unroll
+                    for (int t = 0; t < CNP; ++t) { const double2 v = Ab2[t]; Ab[2 * t] = v.x; Ab[2 * t + 1] = v.y; }
+#pragma unroll
+                    for (int t = 0; t < CNP; ++t) { const double2 v = Aa2[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
+                    // M = delta I - G_a B_b^T  (G rows: g01.x g01.y g23.x | g23.y g45.x g45.y; B rows alike)
+                    const double M00 = fma(-g23.x, b23.x, fma(-g01.y, b01.y, fma(-g01.x, b01.x, dg)));
+                    const double M01 = -fma(g23.x, b45.y, fma(g01.y, b45.x, g01.x * b23.y));
+                    const double M10 = -fma(g45.y, b23.x, fma(g45.x, b01.y, g23.y * b01.x));
+                    const double M11 = fma(-g45.y, b45.y, fma(-g45.x, b45.x, fma(-g23.y, b23.y, dg)));
+                    double T0[CNP], T1[CNP];
+#pragma unroll
+                    for (int c = 0; c < CNP; ++c) {
+                        T0[c] = fma(M01, Ab[CNP + c], M00 * Ab[c]);
+                        T1[c] = fma(M11, Ab[CNP + c], M10 * Ab[c]);
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < CNP; ++rr) {
+                        const double a0 = Aa[rr], a1 = Aa[CNP + rr];
+#pragma unroll
+                        for (int c = 0; c < CNP; ++c) acc[rr * CNP + c] = fma(a1, T1[c], fma(a0, T0[c], acc[rr * CNP + c]));
+                    }
+                }
+            }
+        }
+        wave_lds_sync();
+        STAMP(5);
+    }
+    // ---- the tile hands over: blocks registers -> the rows' LDS (dead now) -> HBM, one contiguous f64 atomic instruction per block;
+    // with several points per round the copies of a block are summed in lane order first
+    {
+        const int rr = lane / CNP, cc = lane - rr * CNP;
+        for (int c0 = 0; c0 < NB; c0 += kStageBlocks) {
+            for (int s2 = 0; s2 < PPR; ++s2) {
+                if (ps == s2 && pq >= c0 && pq < c0 + kStageBlocks) {
+                    double *dst = sR + (pq - c0) * BLK;
+                    if (s2 == 0) {
+#pragma unroll
+                        for (int i = 0; i < BLK; ++i) dst[i] = acc[i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < BLK; ++i) dst[i] += acc[i];
+                    }
+                }
+                wave_lds_sync();
+            }
+            const int c1 = min(NB, c0 + kStageBlocks);
+            for (int q = c0; q < c1; ++q) {
+                if (g.tile_blk) { if (lane < BLK) g.tile_blk[((size_t)tile * kNSlot + q) * BLK + lane] = sR[(q - c0) * BLK + lane]; }
+                else {
+                    const int gb = rl(my_gblk, q);
+                    if (lane < BLK) gadd(&g.S_up[(size_t)gb * (kCP * kCP) + rr * kCP + cc], sR[(q - c0) * BLK + lane]);
+                }
+            }
+            wave_lds_sync();
+        }
+        const int which = lane / CNP, t = lane - which * CNP;
+        for (int c = 0; c < D; ++c) {
+            if (g.tile_blk) { if (lane < 3 * CNP) g.tile_cam[((size_t)tile * kNCSlot + c) * (3 * kCP) + lane] = sC[c * SC + lane]; }
+            else {
+                const int cam = rl(my_cam, c);
+                if (lane < 3 * CNP) gadd(&g.camvec[((size_t)which * g.m + cam) * kCP + t], sC[c * SC + lane]);
+            }
+        }
+    }
+    STAMP(6);
+#ifdef MIBA_STAMPS
+    if (lane == 0 && g.dbg)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g.dbg[i], stamp_acc[i]);
+#endif
+    cost = wave_sum(cost); pl2 = wave_sum(pl2); ccost = wave_sum(ccost);
+    ebinf = wave_max(ebinf); maxdv = wave_max(maxdv); sing = wave_max(sing);
+    if (lane == 0) {
+        double *pr = g.part + (size_t)tile * kPartW;
+        pr[0] = cost; pr[1] = pl2; pr[2] = ccost; pr[3] = 0.0; pr[4] = ebinf; pr[5] = maxdv; pr[6] = sing; pr[7] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Ordered hand-over (mi_ba_config.deterministic = 1): the register and table tiles leave their blocks and camera vectors in
 // per-tile copies (k_build above) instead of adding them to S with f64 atomics; these two kernels sum the copies in tile order --
 // one wavefront per block of S / per camera, the plan's list of (tile, slot) contributors -- so two runs give the same bits.
@@ -3012,6 +3318,7 @@ static void launch_build_t(hipStream_t st, bool lds_mode, int ntiles, const Buil
     if (lds_mode) {
         // both variants walk the same tile range; a workgroup whose tile belongs to the other variant leaves at once
         if (a.has_mfma) hipLaunchKernelGGL((k_build_mfma<CNP, FULL>), dim3(ntiles), dim3(64), 0, st, a);
+        if (a.has_uni) hipLaunchKernelGGL((k_build_uni<CNP, FULL>), dim3(ntiles), dim3(64), 0, st, a);
         if (a.has_reg) hipLaunchKernelGGL((k_build<CNP, true, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
         if (a.has_table) hipLaunchKernelGGL((k_build<CNP, true, FULL, true>), dim3(ntiles), dim3(64), 0, st, a);
     } else hipLaunchKernelGGL((k_build<CNP, false, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);

@@ -365,6 +365,11 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     // pipe has the vector pipe's rate, and 8 x 8-padded blocks with K padded to 4 are 1.37x the vector form's arithmetic)
     const char *mf = std::getenv("MI_BA_MFMA");
     const bool use_mfma = !cam_split && mf && mf[0] == '1';
+    // uniform tiles (mode 4, k_build_uni) are the default for a tile of one camera set; MI_BA_UNI=0 keeps the general kernel (probes, parity tests)
+    const char *un = std::getenv("MI_BA_UNI");
+    const bool use_uni = !cam_split && !use_mfma && !(un && un[0] == '0');
+    static_assert(kUniMinViews == kMfmaMinViews && kUniMinBatches == kMfmaMinBatches, "modes 3 and 4 share the tiling rule");
+    const bool one_set_tiles = use_mfma || use_uni;
     auto do_tiling = [&](int tile_max_batches, bool dry) {
     tile_log.clear();
     pl.pair.clear(); pl.slot_gblk.clear(); pl.cslot_cam.clear(); pl.tile_mode.clear();
@@ -381,7 +386,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     const int *sig_cams = nullptr; int sig_d = -1;
     int cur_obs = 0, batches_in_tile = 0, sig_runs_in_tile = 0;
     t = 0;
-    pl.ntile_table = 0; pl.ntile_mfma = 0;
+    pl.ntile_table = 0; pl.ntile_mfma = 0; pl.ntile_uni = 0;
 
     std::vector<uint32_t> round_buf;  // pair entries of the round being filled (LDS tiles)
     bool rounds_mode = true;
@@ -458,10 +463,12 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         uint8_t m2 = (mode == 1 && sig_runs_in_tile > kTableRuns) ? 2 : mode;
         // one camera set of >= kMfmaMinViews views for the whole tile: lane = (point, camera) in every batch, the slots are the
         // a <= b enumeration of its cameras -- the tile's blocks go through the matrix pipe (k_build_mfma)
-        if (mode == 1 && sig_runs_in_tile == 1 && sig_d >= kMfmaMinViews && use_mfma) m2 = 3;
+        // (k_build_mfma, opt-in) or stay on the vector pipe with everything that is constant over such a tile taken out of the loops (k_build_uni)
+        if (mode == 1 && sig_runs_in_tile == 1 && sig_d >= kMfmaMinViews && one_set_tiles) m2 = use_mfma ? 3 : 4;
         pl.tile_mode.push_back(m2);
         if (m2 == 2) pl.ntile_table++;
         if (m2 == 3) pl.ntile_mfma++;
+        if (m2 == 4) pl.ntile_uni++;
         sig_runs_in_tile = 0;
         if (mode == 1) tile_log.emplace_back(batches_in_tile, batches_in_tile >= tile_max_batches);
         pl.max_slots = std::max(pl.max_slots, (int)smap.size());
@@ -483,8 +490,8 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             if (batches_in_tile >= tile_max_batches) { close_tile(1); same_sig = false; }
         }
         if (!same_sig) {
-            // a tile that so far holds ONE camera set of a long run ends here, so that it can take the matrix pipe (mode 3)
-            if (use_mfma && sig_runs_in_tile == 1 && sig_d >= kMfmaMinViews && batches_in_tile + (cur_obs > 0 ? 1 : 0) >= kMfmaMinBatches) {
+            // a tile that so far holds ONE camera set of a long run ends here, so that it is a uniform tile (mode 4; mode 3 with MI_BA_MFMA)
+            if (one_set_tiles && sig_runs_in_tile == 1 && sig_d >= kMfmaMinViews && batches_in_tile + (cur_obs > 0 ? 1 : 0) >= kMfmaMinBatches) {
                 close_batch(t);
                 close_tile(1);
             }

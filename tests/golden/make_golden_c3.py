@@ -4,7 +4,9 @@ tests/golden/ref_C3.npz.  One solve, about an hour and ~6 GB here (finite-differ
 7000 x 7000 dense Cholesky per damping trial).  The per-trial costs come from the reference's own verbose output
 (`pdp_eL2: %0.3f`, sba_levmar.c:1535-1540) kept in a log file, so the solve runs once.  Stored: info[], iteration count,
 the accepted-step cost trace, every trial's cost, seconds per iteration as measured here (threads stated), the cameras
-and the first 2000 points of the answer -- the inputs are regenerated from the seed on the other side."""
+and the first 2000 points of the answer -- the inputs are regenerated from the seed on the other side.
+`python make_golden_c3.py C4` does the same for BASELINE config C4 as bench.py --config C4 runs it (make_scene("C4"): 1 700
+cameras, 400 000 points, ~3.7 M observations, tracks up to 120 views; dense S 11 900^2): tests/golden/ref_C4.npz."""
 import importlib
 import os
 import re
@@ -54,7 +56,7 @@ def main():
         name, full["ret"], int(info[6]), int(info[9]), secs, secs / max(info[9], 1),
         np.sqrt(info[0] / sc.nobs), np.sqrt(info[1] / sc.nobs)))
     m, cnp = sc.m, sc.cnp
-    path = os.path.join(HERE if name == "C3" else "/tmp", "ref_%s.npz" % name)
+    path = os.path.join(HERE if name in ("C3", "C4") else "/tmp", "ref_%s.npz" % name)
     np.savez_compressed(path, xsum=np.abs(sc.x).sum(), info_final=info, ret_final=full["ret"],
                         trial_costs=trial, trial_accepted=acc, cost_trace=trial[acc],
                         seconds_total=secs, seconds_per_lm_iteration=secs / max(info[9], 1),

@@ -334,8 +334,8 @@ def _check_plan(sc, rank=0, world=1, tmb=0, all_rows=False):
         o0, o1 = g["batch_obs"][b], g["batch_obs"][b + 1]
         assert 0 < o1 - o0 <= 64 and g["batch_pt"][b + 1] - g["batch_pt"][b] <= 32
         t = tile_of_batch[b]
-        lds = g["tile_mode"][t] in (1, 2, 3)
-        if g["tile_mode"][t] == 3:  # one camera set (k_build_mfma): lane = point * d + camera slot, slot of (a, b) = its rank in the a <= b enumeration
+        lds = g["tile_mode"][t] in (1, 2, 3, 4)
+        if g["tile_mode"][t] in (3, 4):  # one camera set (k_build_uni; k_build_mfma): lane = point * d + camera slot, slot of (a, b) = its rank in the a <= b enumeration
             d = g["tile_cslot"][t + 1] - g["tile_cslot"][t]
             assert 4 <= d <= 10 and g["tile_slot"][t + 1] - g["tile_slot"][t] == d * (d + 1) // 2 and (o1 - o0) % d == 0
             cams = g["cslot_cam"][g["tile_cslot"][t]:g["tile_cslot"][t + 1]]
@@ -422,6 +422,25 @@ def test_plan_tables_with_matrix_pipe_tiles(monkeypatch):
         assert (pkg("capi").Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).get("tile_mode") == 3).mean() > 0.6
         _check_plan(sc)
         _check_plan(sc, rank=1, world=2)
+
+
+def test_plan_tables_with_uniform_tiles(monkeypatch):
+    """the default: tiles of one camera set are mode 4 (k_build_uni) and end where the set changes; what the kernel relies on -- lane =
+    point * d + camera slot, slots in the a <= b enumeration, whole batches of floor(64 / d) points but the tile's last -- is checked
+    here and by _check_plan; MI_BA_UNI=0 keeps the general kernel's tiles"""
+    for d in (4, 7, 10):
+        sc = pkg("scene").make_scene("x", m=24, n=2400, d=d, seed=100 + d, strides=(1,))
+        pl = pkg("capi").Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam)
+        modes = pl.get("tile_mode")
+        assert (modes == 4).mean() > 0.6 and not (modes == 3).any()
+        tb, bp = pl.get("tile_batch"), pl.get("batch_pt")
+        for t in np.where(modes == 4)[0]:
+            npts = np.diff(bp[tb[t]:tb[t + 1] + 1])
+            assert np.all(npts[:-1] == 64 // d) and 0 < npts[-1] <= 64 // d
+        _check_plan(sc)
+        _check_plan(sc, rank=1, world=2)
+    monkeypatch.setenv("MI_BA_UNI", "0")
+    assert not (pkg("capi").Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).get("tile_mode") == 4).any()
 
 
 def test_plan_tables_ragged_scene():

@@ -683,6 +683,45 @@ def test_tiles_of_one_camera_set_on_the_matrix_pipe(oracle, monkeypatch, d, est_
     eng.close()
 
 
+@pytest.mark.parametrize("d,est_focal,undistort,explicit_centers,det", [(10, 1, 0, 1, 0), (7, 1, 0, 0, 1), (4, 0, 0, 1, 0), (6, 1, 1, 1, 0), (9, 1, 2, 0, 0), (5, 1, 0, 1, 0),
+                                                                        (8, 1, 0, 1, 1), (10, 1, 1, 0, 0)])
+def test_uniform_tiles_against_the_oracle_and_the_general_kernel(oracle, monkeypatch, d, est_focal, undistort, explicit_centers, det):
+    """plan.h tile mode 4, k_build_uni (the default for a tile whose points all see the same d cameras): no pair entries, G = B V*^-1 per
+    observation, the blocks in registers until the tile ends.  cnp 6 / 7 / 8, 4..10 views (1..6 points per pair round), both camera
+    parametrisations, lean and full model, the ordered hand-over: S, E, e_a, e_b, V, diag U against the oracle's blocks; the general
+    kernel on the same tiles (MI_BA_UNI=0) gives the same to rounding; a whole solve follows the oracle's trajectory."""
+    sc = pkg("scene").make_scene("x", m=24, n=2400, d=d, seed=100 + d, strides=(1,), est_focal=est_focal, undistort=undistort, nk=1,
+                                 explicit_centers=explicit_centers, proj_sign=-1.0 if explicit_centers else 1.0)
+    capi = pkg("capi")
+    modes = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).get("tile_mode")
+    assert (modes == 4).sum() >= 0.6 * len(modes)              # 24 camera sets, runs of 100 points (a run's short last tile joins the next set: mode 1)
+    lin = oracle.linearize(sc, fd_jacobian=0)
+    mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+    S, E, _ = reduced_system(lin, sc, mu)
+    scale = np.abs(lin["U"]).max()
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, deterministic=det)
+    g = eng.debug_linearize(mu)
+    assert abs(g["cost"] - lin["cost"]) <= 1e-11 * lin["cost"]
+    assert rel(g["ea"], lin["ea"]) < 1e-10 and rel(g["eb"], lin["eb"]) < 1e-10 and rel(g["V"], lin["V"]) < 1e-8
+    assert rel(g["diagU"], np.einsum("jrr->jr", lin["U"])) < 1e-10
+    assert np.abs(g["S"] - S).max() < 1e-10 * scale and rel(g["E"].reshape(-1), E) < 1e-9
+    if det:                                                    # ordered hand-over: two linearisations give the same bits
+        g1 = eng.debug_linearize(mu)
+        assert np.array_equal(g1["S"], g["S"]) and np.array_equal(g1["E"], g["E"])
+    ret, info = eng.run()
+    o = oracle.run(sc, itmax=150, fd_jacobian=0)
+    assert ret == o["ret"] and info[6] == o["info"][6] and abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
+    assert np.abs(eng.packed_params() - o["p"]).max() < 1e-6
+    eng.close()
+    monkeypatch.setenv("MI_BA_UNI", "0")
+    assert not (capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).get("tile_mode") == 4).any()
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, deterministic=det)
+    g2 = eng.debug_linearize(mu)
+    assert np.abs(g2["S"] - g["S"]).max() < 1e-11 * scale and rel(g2["E"], g["E"]) < 1e-10
+    assert rel(g2["V"], g["V"]) < 1e-13 and rel(g2["eb"], g["eb"]) < 1e-13            # phases 1-3 are the same arithmetic (up to the compiler's contractions)
+    eng.close()
+
+
 @pytest.mark.parametrize("min_run", [1, 12])
 def test_mixed_track_lengths_and_unsorted_cameras(oracle, monkeypatch, min_run):
     """ragged input: track lengths 2..14, cameras NOT sorted inside a point, some points unobserved"""
