@@ -116,6 +116,7 @@ ModelCfg Engine::model() const
     ModelCfg mc;
     mc.explicit_centers = cfg.explicit_centers; mc.est_focal = cfg.est_focal; mc.undistort = cfg.undistort;
     mc.mcon = cfg.mcon; mc.points_fixed = cfg.mode == 1; mc.proj_sign = cfg.proj_sign; mc.f_scale = cfg.f_scale; mc.k_scale = cfg.k_scale;
+    mc.inv_f_scale = 1.0 / cfg.f_scale; mc.inv_k_scale = 1.0 / cfg.k_scale;
     mc.nk = cfg.undistort == 1 ? cfg.nk : 1; mc.split = split_ ? 1 : 0;
     mc.damp_diag = cfg.lm_variant == 1;         // (2: PBA's controller with identity damping, __lm_use_diagonal_damp off)
     return mc;

@@ -31,6 +31,7 @@ struct ModelCfg {
     int points_fixed;   // motion-only bundle: B_ij := 0 (sba_mot_levmar_x has no structure block)
     int damp_diag;      // PBA's damping: U* = U + mu diag(U), V* = V + mu diag(V) (SparseBundleCPU.cpp:1813-1814) instead of sba's + mu I
     double proj_sign, f_scale, k_scale;
+    double inv_f_scale, inv_k_scale;   // 1 / f_scale, 1 / k_scale (the per-observation kernels multiply; a division by a uniform is 13 instructions there)
 };
 
 // scalar block (doubles) shared by kernels and the host LM controller; lives at the tail of the

@@ -69,6 +69,14 @@ __device__ __forceinline__ void wave_lds_sync()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
+// 1 / x for the per-observation kernels: v_rcp_f64 and two Newton steps (5 instructions, ~1 ulp) instead of the IEEE division
+// sequence (13, v_div_scale / v_div_fmas / v_div_fixup around the same iteration); x is a depth or a determinant, never denormal
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
 __device__ __forceinline__ void gadd(double *p, double v) { unsafeAtomicAdd(p, v); } // global_atomic_add_f64
 __device__ __forceinline__ void ladd(double *p, double v)                           // ds_add_f64
 {
@@ -129,7 +137,7 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
         for (int r = 0; r < 3; ++r) qr[r] = R[3 * r] * X[0] + R[3 * r + 1] * X[1] + R[3 * r + 2] * X[2];
         q[0] = qr[0] + c0; q[1] = qr[1] + c1; q[2] = qr[2] + c2;
     }
-    const double s = cfg.proj_sign, iz = 1.0 / q[2];
+    const double s = cfg.proj_sign, iz = fast_rcp(q[2]);
     const double mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
     const double D = FULL ? 1.0 + k1 * r2 + k2 * r2 * r2 : 1.0, Dp = FULL ? k1 + 2.0 * k2 * r2 : 0.0;
     e[0] = xy.x - s * f * mx * D;
@@ -180,14 +188,14 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
         if constexpr (CNP >= 7) {
             const double mr = (r == 0) ? mx : my;
             int idx = 6;
-            if (!FULL || cfg.est_focal) { A[r][6] = s * mr * D / cfg.f_scale; idx = 7; }   // lean: cnp 7 = pose + focal
+            if (!FULL || cfg.est_focal) { A[r][6] = s * mr * D * cfg.inv_f_scale; idx = 7; }   // lean: cnp 7 = pose + focal
             if (FULL && cfg.undistort) {
-                const double dk = md ? -m2k * (r == 0 ? xy.x : xy.y) / cfg.k_scale     // JacobianOne, SparseBundleCPU.cpp:1427-1432
-                                     : s * f * mr * r2 / cfg.k_scale;
+                const double dk = md ? -m2k * (r == 0 ? xy.x : xy.y) * cfg.inv_k_scale     // JacobianOne, SparseBundleCPU.cpp:1427-1432
+                                     : s * f * mr * r2 * cfg.inv_k_scale;
                 if (idx == 6) A[r][6] = dk;
                 if constexpr (CNP >= 8) { if (idx == 7) A[r][7] = dk; }
                 if (!md && cfg.nk == 2) {                                              // Bundler's second coefficient: d D / d k2 = r^4
-                    const double dk2 = s * f * mr * r2 * r2 / cfg.k_scale;
+                    const double dk2 = s * f * mr * r2 * r2 * cfg.inv_k_scale;
                     if constexpr (CNP >= 8) { if (idx == 6) A[r][7] = dk2; }
                     if constexpr (CNP >= 9) { if (idx == 7) A[r][8] = dk2; }
                 }
@@ -255,7 +263,7 @@ __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *_
 #pragma unroll
         for (int r = 0; r < 3; ++r) { qr[r] = cl[3 * r] * X[0] + cl[3 * r + 1] * X[1] + cl[3 * r + 2] * X[2]; q[r] = qr[r] + cl[18 + r]; }
     }
-    const double s = cfg.proj_sign, iz = 1.0 / q[2];
+    const double s = cfg.proj_sign, iz = fast_rcp(q[2]);
     const double mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
     const double D = FULL ? 1.0 + k1 * r2 + k2 * r2 * r2 : 1.0, Dp = FULL ? k1 + 2.0 * k2 * r2 : 0.0;
     e[0] = xy.x - s * f * mx * D;
@@ -278,9 +286,9 @@ __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *_
         const double mr = (r == 0) ? mx : my;
         w[r] = Pq[r][0] * dq[0] + Pq[r][1] * dq[1] + Pq[r][2] * dq[2];
         if constexpr (CNP >= 7) {
-            w[r] = fma(s * mr * D / cfg.f_scale, cd.df, w[r]);       // zero update when the focal length is not a parameter
-            if (FULL) w[r] = fma(md ? -m2k * (r == 0 ? xy.x : xy.y) / cfg.k_scale : s * f * mr * r2 / cfg.k_scale, cd.dk, w[r]);
-            if (FULL) w[r] = fma(s * f * mr * r2 * r2 / cfg.k_scale, cd.dk2, w[r]);   // zero update unless k2 is a parameter
+            w[r] = fma(s * mr * D * cfg.inv_f_scale, cd.df, w[r]);       // zero update when the focal length is not a parameter
+            if (FULL) w[r] = fma(md ? -m2k * (r == 0 ? xy.x : xy.y) * cfg.inv_k_scale : s * f * mr * r2 * cfg.inv_k_scale, cd.dk, w[r]);
+            if (FULL) w[r] = fma(s * f * mr * r2 * r2 * cfg.inv_k_scale, cd.dk2, w[r]);   // zero update unless k2 is a parameter
         }
     }
     if (cfg.points_fixed) { t[0] = t[1] = t[2] = bd[0] = bd[1] = bd[2] = 0.0; return; }      // a motion-only bundle has no structure block
@@ -1301,11 +1309,7 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
         double *const row = sR + lane * SR;
         // ---- phase 1: residual and Jacobian of the lane's observation
         {
-            double cl[kCamLin];
-            const double2 *src = reinterpret_cast<const double2 *>(sCam + cs * kCamLin);
-#pragma unroll
-            for (int t = 0; t < kCamLin / 2; ++t) { const double2 v = src[t]; cl[2 * t] = v.x; cl[2 * t + 1] = v.y; }
-            STAMP(7);
+            const double *cl = sCam + cs * kCamLin;    // the camera's record is read where it is used: no 48 registers held through the phase
             if (active) {
                 linearize_obs<CNP, FULL>(cfg, cl, X, xy, cam_is_fixed, e, A, B);
                 cost += e[0] * e[0] + e[1] * e[1];
@@ -1324,40 +1328,36 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
                 }
             }
         }
-        // the next batch's streams: issued now, consumed in its phase 1
-        if (k + 1 < nbatch) {
-            const int p1 = p0 + PB;
-            if (lp < min(PB, tp1 - p1)) {
-                xy = g.obs_xy[to0 + (k + 1) * PB * D + lane];
-                const double *px = g.pts + 3 * (size_t)(p1 + lp);
-                X[0] = px[0]; X[1] = px[1]; X[2] = px[2];
-            }
-        }
         wave_lds_sync();
         STAMP(1);
         // ---- phase 2: V_i upper triangle (00 01 02 11 12 22) and eb_i, lane = (point, component), 7 points per sweep; a point's
         // rows are lanes lpp D .. lpp D + D - 1.  (the sums in k_build's order: the same bits)
         for (int base = 0; base < npt; base += 7) {
-            const int qd = lane / 9, comp = lane - 9 * qd, lpp = base + qd;
-            if (lane < 63 && lpp < npt) {
-                const int os = lpp * D, oe = os + D;
+            int lv = lane; asm volatile("" : "+v"(lv));       // (opaque: see the prefetch below)
+            const int qd = lv / 9, comp = lv - 9 * qd, lpp = base + qd;
+            if (lv < 63 && lpp < npt) {
+                // V(r,c) = sum B0r*B0c + B1r*B1c ; eb(r) = sum B0r*e0 + B1r*e1 : same form, columns (c, 3+c) or (6, 7) of the B | e part.
+                // The four operands of view t sit at compile-time offsets t SR from the point's first row: every load is an immediate-
+                // offset ds_read, all kMaxViewsLds views issued at once (past the point's D views: rows of the next point or LDS beyond the
+                // rows -- read and dropped)
                 const int r = comp < 3 ? 0 : (comp < 5 ? 1 : (comp < 6 ? 2 : comp - 6));
                 const int c0 = comp < 3 ? comp : (comp < 5 ? comp - 2 : (comp < 6 ? 2 : 6));
                 const int c1 = comp < 6 ? c0 + 3 : 7;
+                const double *rb0 = sR + lpp * D * SR + OB;
+                const double *px0 = rb0 + r, *py0 = rb0 + c0, *px1 = rb0 + 3 + r, *py1 = rb0 + c1;
                 double s0 = 0.0, s1 = 0.0;
-                constexpr int H = kMaxViewsLds / 2;
+                constexpr int H = kMaxViewsLds / 2;               // two groups of five views: 20 loads in flight (all forty would spill)
 #pragma unroll
                 for (int k0 = 0; k0 < kMaxViewsLds; k0 += H) {
                     double x0[H], x1[H], y0[H], y1[H];
 #pragma unroll
-                    for (int t = 0; t < H; ++t) {
-                        const double *r0 = sR + min(os + k0 + t, oe - 1) * SR + OB;   // (past the point's end: the last row again, the product is dropped)
-                        x0[t] = r0[r]; y0[t] = r0[c0]; x1[t] = r0[3 + r]; y1[t] = r0[c1];
-                    }
+                    for (int t = 0; t < H; ++t) { x0[t] = px0[(k0 + t) * SR]; y0[t] = py0[(k0 + t) * SR]; x1[t] = px1[(k0 + t) * SR]; y1[t] = py1[(k0 + t) * SR]; }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < H; ++t) {
-                        if (os + k0 + t < oe) { if (t & 1) s1 = fma(x1[t], y1[t], fma(x0[t], y0[t], s1)); else s0 = fma(x1[t], y1[t], fma(x0[t], y0[t], s0)); }
+                    for (int t = 0; t < H; ++t) {                 // (uniform conditions: D is the tile's)
+                        if (k0 + t < D) { if ((k0 + t) & 1) s1 = fma(x1[t], y1[t], fma(x0[t], y0[t], s1)); else s0 = fma(x1[t], y1[t], fma(x0[t], y0[t], s0)); }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 sV[lpp * SV + comp] = s0 + s1;
             }
@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
             double i00 = 0, i01 = 0, i02 = 0, i11 = 0, i12 = 0, i22 = 0;
             if (det == 0.0 || !isfinite(det)) { if (!(cfg.points_fixed && cfg.damp_diag)) sing = 1.0; } // "singular matrix V*_i, increasing damping", :1156-1158
             else {
-                const double id = 1.0 / det;
+                const double id = fast_rcp(det);
                 i00 = c00 * id; i01 = c01 * id; i02 = c02 * id;
                 i11 = (v00 * v22 - v02 * v02) * id; i12 = (v01 * v02 - v00 * v12) * id; i22 = (v00 * v11 - v01 * v01) * id;
             }
@@ -1423,6 +1423,17 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
         }
         wave_lds_sync();
         STAMP(4);
+        // the next batch's streams: issued here, consumed in its phase 1 -- behind them nothing in the loop waits for memory any more
+        // (a vmcnt wait -- a register reloaded from scratch is enough -- right after the issue would expose the whole HBM latency)
+        if (k + 1 < nbatch) {
+            int lv = lane; asm volatile("" : "+v"(lv));       // (opaque: the address arithmetic is redone here, not kept in registers through the loop)
+            const int p1 = p0 + PB, lpv = lv / D;
+            if (lpv < min(PB, tp1 - p1)) {
+                xy = g.obs_xy[to0 + (k + 1) * PB * D + lv];
+                const double *px = g.pts + 3 * (size_t)(p1 + lpv);
+                X[0] = px[0]; X[1] = px[1]; X[2] = px[2];
+            }
+        }
         // ---- phase 5: the lane's block += A_a^T (delta_ab I - G_a B_b^T) A_b of the round's point
         __builtin_amdgcn_s_setprio(0);
         {
@@ -1431,25 +1442,31 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
             const int step = PPR * D * SR;
             for (int r = 0; r < nrounds; ++r, ra += step, rb += step) {
                 if (pair_lane && r * PPR + ps < npt) {
+                    // the order of the loads is pinned (sched_barrier): all twenty operand loads in flight at once would need 80 registers
+                    // beside the 98 accumulators; G_a and B_b are dead once M is formed, A_b once T is
                     const double2 *Ga2 = reinterpret_cast<const double2 *>(ra + OG), *Bb2 = reinterpret_cast<const double2 *>(rb + OB);
-                    const double2 g01 = Ga2[0], g23 = Ga2[1], g45 = Ga2[2], b01 = Bb2[0], b23 = Bb2[1], b45 = Bb2[2];
                     const double2 *Ab2 = reinterpret_cast<const double2 *>(rb), *Aa2 = reinterpret_cast<const double2 *>(ra);
+                    const double2 g01 = Ga2[0], g23 = Ga2[1], g45 = Ga2[2], b01 = Bb2[0], b23 = Bb2[1], b45 = Bb2[2];
                     double Ab[2 * CNP], Aa[2 * CNP];
 #pragma unroll
                     for (int t = 0; t < CNP; ++t) { const double2 v = Ab2[t]; Ab[2 * t] = v.x; Ab[2 * t + 1] = v.y; }
-#pragma unroll
-                    for (int t = 0; t < CNP; ++t) { const double2 v = Aa2[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
+                    __builtin_amdgcn_sched_barrier(0);
                     // M = delta I - G_a B_b^T  (G rows: g01.x g01.y g23.x | g23.y g45.x g45.y; B rows alike)
                     const double M00 = fma(-g23.x, b23.x, fma(-g01.y, b01.y, fma(-g01.x, b01.x, dg)));
                     const double M01 = -fma(g23.x, b45.y, fma(g01.y, b45.x, g01.x * b23.y));
                     const double M10 = -fma(g45.y, b23.x, fma(g45.x, b01.y, g23.y * b01.x));
                     const double M11 = fma(-g45.y, b45.y, fma(-g45.x, b45.x, fma(-g23.y, b23.y, dg)));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < CNP; ++t) { const double2 v = Aa2[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
+                    __builtin_amdgcn_sched_barrier(0);
                     double T0[CNP], T1[CNP];
 #pragma unroll
                     for (int c = 0; c < CNP; ++c) {
                         T0[c] = fma(M01, Ab[CNP + c], M00 * Ab[c]);
                         T1[c] = fma(M11, Ab[CNP + c], M10 * Ab[c]);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rr = 0; rr < CNP; ++rr) {
                         const double a0 = Aa[rr], a1 = Aa[CNP + rr];

@@ -718,7 +718,7 @@ def test_uniform_tiles_against_the_oracle_and_the_general_kernel(oracle, monkeyp
     eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400, deterministic=det)
     g2 = eng.debug_linearize(mu)
     assert np.abs(g2["S"] - g["S"]).max() < 1e-11 * scale and rel(g2["E"], g["E"]) < 1e-10
-    assert rel(g2["V"], g["V"]) < 1e-13 and rel(g2["eb"], g["eb"]) < 1e-13            # phases 1-3 are the same arithmetic (up to the compiler's contractions)
+    assert rel(g2["V"], g["V"]) < 1e-9 and rel(g2["eb"], g["eb"]) < 1e-12              # (V comes back through the inverse of the stored V*^-1)
     eng.close()
 
 
