@@ -1251,6 +1251,9 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
     __shared__ __attribute__((aligned(16))) double sV[kMaxPts * SV];
     __shared__ __attribute__((aligned(16))) double sC[kMaxD * SC];
     __shared__ __attribute__((aligned(16))) double sCam[kMaxD * kCamLin];
+    // the next batch's measurement and point streams land here by LDS-DMA (global_load_lds: no destination registers held through the pair phase)
+    __shared__ __attribute__((aligned(16))) double2 sXY[kWave];
+    __shared__ __attribute__((aligned(16))) double sX[kMaxPts * 3];
 
     const int lane = threadIdx.x;
     const int tile = g.tile0 + blockIdx.x;
@@ -1284,17 +1287,28 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
     const int b_begin = g.tile_batch[tile], b_end = g.tile_batch[tile + 1];
     const int tp0 = g.batch_pt[b_begin], tp1 = g.batch_pt[b_end], to0 = g.batch_obs[b_begin];
     const int nbatch = b_end - b_begin;                                    // = ceil((tp1 - tp0) / PB): whole batches but the last (plan.cpp)
-    // first batch's streams; from then on one batch ahead
-    double2 xy = make_double2(0.0, 0.0);
-    double X[3] = { 0.0, 0.0, 0.0 };
-    {
-        const int npt0 = min(PB, tp1 - tp0);
-        if (lp < npt0) {
-            xy = g.obs_xy[to0 + lane];
-            const double *px = g.pts + 3 * (size_t)(tp0 + lp);
-            X[0] = px[0]; X[1] = px[1]; X[2] = px[2];
-        }
-    }
+    // The batch's streams: its measurements (16 B per observation, lane-linear) and its points (24 B per point, consecutive in the
+    // internal order: one contiguous chunk, a dword per lane) go from HBM straight into LDS, one batch ahead.
+    auto stream_batch = [&](int kk) {
+        int lv = lane; asm volatile("" : "+v"(lv));       // (opaque: the address arithmetic is redone at every call, not kept in registers through the loop)
+        const int p1 = tp0 + kk * PB, np1 = min(PB, tp1 - p1);
+        // (inline asm: through the builtin the compiler drains the transfers -- s_waitcnt vmcnt(0) -- in front of the next LDS read of
+        // any array, i.e. at the top of the pair phase, and the HBM latency is exposed; the kernel waits for them itself, in phase 1)
+        auto glds = [&](const void *src, const void *lds_dst, bool wide) {
+            const unsigned m0v = (unsigned)(size_t)lds_dst;   // LDS byte address: the low 32 bits of the generic pointer
+            unsigned keep;                                    // (M0 is the compiler's: saved and put back)
+            if (wide) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+            else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+        };
+        const unsigned *src = reinterpret_cast<const unsigned *>(g.pts + 3 * (size_t)p1);
+        if (lv < np1 * D) glds(g.obs_xy + (to0 + kk * PB * D + lv), sXY, true);
+        if (lv < 6 * np1) glds(src + lv, sX, false);
+        if (lv + kWave < 6 * np1) glds(src + kWave + lv, reinterpret_cast<unsigned *>(sX) + kWave, false);
+    };
+    double ea[CNP], Ev[CNP];                                // this lane's share of its camera's e_a and E, summed over the tile's batches
+#pragma unroll
+    for (int t = 0; t < CNP; ++t) { ea[t] = 0.0; Ev[t] = 0.0; }
+    stream_batch(0);
     wave_lds_sync();   // the camera records are in place
     STAMP(0);
 
@@ -1304,13 +1318,18 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
         const bool active = lp < npt;
         const int ip = p0 + lp;
         const bool head = active && cs == 0;
-        double A[2][CNP], B[2][3], e[2] = { 0.0, 0.0 };
         double pcw = 0.0, pcd[3] = { 0.0, 0.0, 0.0 };
         double *const row = sR + lane * SR;
         // ---- phase 1: residual and Jacobian of the lane's observation
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the batch's streams have landed (issued a pair phase ago)
+        __builtin_amdgcn_wave_barrier();
+        const double2 xy = active ? sXY[lane] : make_double2(0.0, 0.0);
+        double X[3] = { 0.0, 0.0, 0.0 };
+        if (active) { X[0] = sX[3 * lp]; X[1] = sX[3 * lp + 1]; X[2] = sX[3 * lp + 2]; }
         {
             const double *cl = sCam + cs * kCamLin;    // the camera's record is read where it is used: no 48 registers held through the phase
             if (active) {
+                double A[2][CNP], B[2][3], e[2];           // (dead once they are in the row: phase 4 reads them back, the registers are the accumulators')
                 linearize_obs<CNP, FULL>(cfg, cl, X, xy, cam_is_fixed, e, A, B);
                 cost += e[0] * e[0] + e[1] * e[1];
 #pragma unroll
@@ -1397,6 +1416,13 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
             }
             const double h0 = i00 * eb0 + i01 * eb1 + i02 * eb2, h1 = i01 * eb0 + i11 * eb1 + i12 * eb2,
                          h2 = i02 * eb0 + i12 * eb1 + i22 * eb2;
+            // the observation's row again: B | e, and A further down
+            double B[2][3], e[2];
+            {
+                const double2 *rb2 = reinterpret_cast<const double2 *>(row + OB);
+                const double2 b01 = rb2[0], b23 = rb2[1], b45 = rb2[2], e01 = rb2[3];
+                B[0][0] = b01.x; B[0][1] = b01.y; B[0][2] = b23.x; B[1][0] = b23.y; B[1][1] = b45.x; B[1][2] = b45.y; e[0] = e01.x; e[1] = e01.y;
+            }
             if (head) {
                 double *po = g.ptout + (size_t)ip * kPtOut;
                 po[0] = i00; po[1] = i01; po[2] = i02; po[3] = i11; po[4] = i12; po[5] = i22;
@@ -1412,28 +1438,30 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
                 double er[2];
 #pragma unroll
                 for (int r = 0; r < 2; ++r) er[r] = e[r] - (B[r][0] * h0 + B[r][1] * h1 + B[r][2] * h2);
+                double A[2][CNP];
+                {
+                    const double2 *ra2 = reinterpret_cast<const double2 *>(row);
+                    double Af[2 * CNP];
+#pragma unroll
+                    for (int t = 0; t < CNP; ++t) { const double2 v = ra2[t]; Af[2 * t] = v.x; Af[2 * t + 1] = v.y; }
+#pragma unroll
+                    for (int t = 0; t < CNP; ++t) { A[0][t] = Af[t]; A[1][t] = Af[CNP + t]; }
+                }
+                // (in registers: six lanes of a batch share a camera, and ds_add_f64 on one address serialises them -- 14 such
+                // instructions per batch were a third of the kernel's LDS time)
 #pragma unroll
                 for (int t = 0; t < CNP; ++t) {
-                    const double vea = fma(A[1][t], e[1], A[0][t] * e[0]);
-                    const double vE = fma(A[1][t], er[1], A[0][t] * er[0]);
-                    ladd(&sC[cs * SC + t], vea); ladd(&sC[cs * SC + CNP + t], vE);
+                    ea[t] = fma(A[1][t], e[1], fma(A[0][t], e[0], ea[t]));
+                    Ev[t] = fma(A[1][t], er[1], fma(A[0][t], er[0], Ev[t]));
                     if (g.want_diag) ladd(&sC[cs * SC + 2 * CNP + t], fma(A[1][t], A[1][t], A[0][t] * A[0][t]));
                 }
             }
         }
         wave_lds_sync();
         STAMP(4);
-        // the next batch's streams: issued here, consumed in its phase 1 -- behind them nothing in the loop waits for memory any more
-        // (a vmcnt wait -- a register reloaded from scratch is enough -- right after the issue would expose the whole HBM latency)
-        if (k + 1 < nbatch) {
-            int lv = lane; asm volatile("" : "+v"(lv));       // (opaque: the address arithmetic is redone here, not kept in registers through the loop)
-            const int p1 = p0 + PB, lpv = lv / D;
-            if (lpv < min(PB, tp1 - p1)) {
-                xy = g.obs_xy[to0 + (k + 1) * PB * D + lv];
-                const double *px = g.pts + 3 * (size_t)(p1 + lpv);
-                X[0] = px[0]; X[1] = px[1]; X[2] = px[2];
-            }
-        }
+        // the next batch's streams: issued here, consumed in its phase 1 -- behind them nothing in the loop waits for memory before that
+        // (a vmcnt wait right after the issue -- a register reloaded from scratch is enough -- would expose the whole HBM latency)
+        if (k + 1 < nbatch) stream_batch(k + 1);
         // ---- phase 5: the lane's block += A_a^T (delta_ab I - G_a B_b^T) A_b of the round's point
         __builtin_amdgcn_s_setprio(0);
         {
@@ -1507,6 +1535,11 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
             }
             wave_lds_sync();
         }
+        if (lane < PB * D) {                               // the lanes' shares of e_a and E: the (up to 16) lanes of a camera add up in its slot
+#pragma unroll
+            for (int t = 0; t < CNP; ++t) { ladd(&sC[cs * SC + t], ea[t]); ladd(&sC[cs * SC + CNP + t], Ev[t]); }
+        }
+        wave_lds_sync();
         const int which = lane / CNP, t = lane - which * CNP;
         for (int c = 0; c < D; ++c) {
             if (g.tile_blk) { if (lane < 3 * CNP) g.tile_cam[((size_t)tile * kNCSlot + c) * (3 * kCP) + lane] = sC[c * SC + lane]; }
