@@ -145,16 +145,29 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
     if (md) { const double kk = cl[22] * m2k; e[0] = fma(kk, xy.x, e[0]); e[1] = fma(kk, xy.y, e[1]); }
     const double dmx[3] = { iz, 0.0, -mx * iz }, dmy[3] = { 0.0, iz, -my * iz };
     double Pq[2][3];
+    if constexpr (FULL) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-        double dr2 = 2.0 * (mx * dmx[t] + my * dmy[t]);
-        Pq[0][t] = s * f * (D * dmx[t] + mx * Dp * dr2);
-        Pq[1][t] = s * f * (D * dmy[t] + my * Dp * dr2);
+        for (int t = 0; t < 3; ++t) {
+            double dr2 = 2.0 * (mx * dmx[t] + my * dmy[t]);
+            Pq[0][t] = s * f * (D * dmx[t] + mx * Dp * dr2);
+            Pq[1][t] = s * f * (D * dmy[t] + my * Dp * dr2);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) B[r][t] = Pq[r][0] * R[t] + Pq[r][1] * R[3 + t] + Pq[r][2] * R[6 + t];
+    } else {
+        // no distortion: d xhat / d q = s f [iz 0 -mx iz; 0 iz -my iz] -- the two zeros written out (the general form multiplies by
+        // them at run time: IEEE does not let a compiler drop x * 0); the same values to the bit
+        const double sf = s * f;
+        Pq[0][0] = sf * dmx[0]; Pq[0][1] = 0.0; Pq[0][2] = sf * dmx[2];
+        Pq[1][0] = 0.0; Pq[1][1] = sf * dmy[1]; Pq[1][2] = sf * dmy[2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            B[0][t] = fma(Pq[0][2], R[6 + t], Pq[0][0] * R[t]);
+            B[1][t] = fma(Pq[1][2], R[6 + t], Pq[1][1] * R[3 + t]);
+        }
     }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) B[r][t] = Pq[r][0] * R[t] + Pq[r][1] * R[3 + t] + Pq[r][2] * R[6 + t];
     if (fixed_cam) { // A_ij is taken as zero for the first mcon cameras (sba_levmar.c:460-462)
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -182,7 +195,8 @@ __device__ __forceinline__ void linearize_obs(const ModelCfg &cfg, const double 
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             A[r][t] = cfg.explicit_centers ? -B[r][t] : Pq[r][t];
-            A[r][3 + t] = Pq[r][0] * M[0][t] + Pq[r][1] * M[1][t] + Pq[r][2] * M[2][t];
+            if constexpr (FULL) A[r][3 + t] = Pq[r][0] * M[0][t] + Pq[r][1] * M[1][t] + Pq[r][2] * M[2][t];
+            else A[r][3 + t] = fma(Pq[r][2], M[2][t], Pq[r][r] * M[r][t]);       // (the zero of Pq written out, as above)
         }
         // intrinsics columns, in Bundler's order (sfm.c:679-701): focal length (scaled), then k1 (scaled)
         if constexpr (CNP >= 7) {
@@ -271,11 +285,17 @@ __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *_
     if (md) { const double kk = cl[22] * m2k; e[0] = fma(kk, xy.x, e[0]); e[1] = fma(kk, xy.y, e[1]); }
     const double dmx[3] = { iz, 0.0, -mx * iz }, dmy[3] = { 0.0, iz, -my * iz };
     double Pq[2][3];
+    if constexpr (FULL) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const double dr2 = 2.0 * (mx * dmx[c] + my * dmy[c]);
-        Pq[0][c] = s * f * (D * dmx[c] + mx * Dp * dr2);
-        Pq[1][c] = s * f * (D * dmy[c] + my * Dp * dr2);
+        for (int c = 0; c < 3; ++c) {
+            const double dr2 = 2.0 * (mx * dmx[c] + my * dmy[c]);
+            Pq[0][c] = s * f * (D * dmx[c] + mx * Dp * dr2);
+            Pq[1][c] = s * f * (D * dmy[c] + my * Dp * dr2);
+        }
+    } else {   // (the zeros written out: linearize_obs)
+        const double sf = s * f;
+        Pq[0][0] = sf * dmx[0]; Pq[0][1] = 0.0; Pq[0][2] = sf * dmx[2];
+        Pq[1][0] = 0.0; Pq[1][1] = sf * dmy[1]; Pq[1][2] = sf * dmy[2];
     }
     // dq = v0 + M u with M u = -(qr x u)
     const double dq[3] = { cd.v0[0] - (qr[1] * cd.u[2] - qr[2] * cd.u[1]), cd.v0[1] - (qr[2] * cd.u[0] - qr[0] * cd.u[2]),
@@ -284,7 +304,8 @@ __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *_
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const double mr = (r == 0) ? mx : my;
-        w[r] = Pq[r][0] * dq[0] + Pq[r][1] * dq[1] + Pq[r][2] * dq[2];
+        if constexpr (FULL) w[r] = Pq[r][0] * dq[0] + Pq[r][1] * dq[1] + Pq[r][2] * dq[2];
+        else w[r] = fma(Pq[r][2], dq[2], Pq[r][r] * dq[r]);
         if constexpr (CNP >= 7) {
             w[r] = fma(s * mr * D * cfg.inv_f_scale, cd.df, w[r]);       // zero update when the focal length is not a parameter
             if (FULL) w[r] = fma(md ? -m2k * (r == 0 ? xy.x : xy.y) * cfg.inv_k_scale : s * f * mr * r2 * cfg.inv_k_scale, cd.dk, w[r]);
@@ -294,8 +315,8 @@ __device__ __forceinline__ void backsub_obs(const ModelCfg &cfg, const double *_
     if (cfg.points_fixed) { t[0] = t[1] = t[2] = bd[0] = bd[1] = bd[2] = 0.0; return; }      // a motion-only bundle has no structure block
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double B0 = Pq[0][0] * cl[c] + Pq[0][1] * cl[3 + c] + Pq[0][2] * cl[6 + c];
-        const double B1 = Pq[1][0] * cl[c] + Pq[1][1] * cl[3 + c] + Pq[1][2] * cl[6 + c];
+        const double B0 = FULL ? Pq[0][0] * cl[c] + Pq[0][1] * cl[3 + c] + Pq[0][2] * cl[6 + c] : fma(Pq[0][2], cl[6 + c], Pq[0][0] * cl[c]);
+        const double B1 = FULL ? Pq[1][0] * cl[c] + Pq[1][1] * cl[3 + c] + Pq[1][2] * cl[6 + c] : fma(Pq[1][2], cl[6 + c], Pq[1][1] * cl[3 + c]);
         t[c] = B0 * w[0] + B1 * w[1];
         bd[c] = fma(B1, B1, B0 * B0);                                  // this observation's share of diag V_i (PBA's damping metric)
     }
@@ -1250,7 +1271,10 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
     __shared__ __attribute__((aligned(16))) double sR[kWave * SR];
     __shared__ __attribute__((aligned(16))) double sV[kMaxPts * SV];
     __shared__ __attribute__((aligned(16))) double sC[kMaxD * SC];
-    __shared__ __attribute__((aligned(16))) double sCam[kMaxD * kCamLin];
+    // the cameras' records, 26 doubles apart: at the records' own 24 (192 B = 48 banks) cameras c and c + 4 start in the same bank and every
+    // ds_read_b128 of phase 1 was a 2-3-way conflict; 52 dwords apart sixteen records start in sixteen different 16-byte slots
+    constexpr int SCAM = kCamLin + 2;
+    __shared__ __attribute__((aligned(16))) double sCam[kMaxD * SCAM];
     // the next batch's measurement and point streams land here by LDS-DMA (global_load_lds: no destination registers held through the pair phase)
     __shared__ __attribute__((aligned(16))) double2 sXY[kWave];
     __shared__ __attribute__((aligned(16))) double sX[kMaxPts * 3];
@@ -1265,7 +1289,7 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
     for (int i = lane; i < D * (kCamLin / 2); i += kWave) {
         const int c = i / (kCamLin / 2), piece = i - c * (kCamLin / 2);
         const int cam = g.cslot_cam[g.tile_cslot[tile] + c];
-        reinterpret_cast<double2 *>(sCam)[i] = reinterpret_cast<const double2 *>(g.cam_lin + (size_t)cam * kCamLin)[piece];
+        reinterpret_cast<double2 *>(sCam + c * SCAM)[piece] = reinterpret_cast<const double2 *>(g.cam_lin + (size_t)cam * kCamLin)[piece];
     }
     const int my_gblk = lane < NB ? g.slot_gblk[g.tile_slot[tile] + lane] : 0;
     const int my_cam = lane < D ? g.cslot_cam[g.tile_cslot[tile] + lane] : 0;
@@ -1327,7 +1351,7 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
         double X[3] = { 0.0, 0.0, 0.0 };
         if (active) { X[0] = sX[3 * lp]; X[1] = sX[3 * lp + 1]; X[2] = sX[3 * lp + 2]; }
         {
-            const double *cl = sCam + cs * kCamLin;    // the camera's record is read where it is used: no 48 registers held through the phase
+            const double *cl = sCam + cs * SCAM;    // the camera's record is read where it is used: no 48 registers held through the phase
             if (active) {
                 double A[2][CNP], B[2][3], e[2];           // (dead once they are in the row: phase 4 reads them back, the registers are the accumulators')
                 linearize_obs<CNP, FULL>(cfg, cl, X, xy, cam_is_fixed, e, A, B);
