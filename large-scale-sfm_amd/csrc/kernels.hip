@@ -3281,14 +3281,20 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
         const double X[3] = { g.pts[3 * (size_t)ip], g.pts[3 * (size_t)ip + 1], g.pts[3 * (size_t)ip + 2] };
         const int lp_prev = __builtin_amdgcn_update_dpp(-2, active ? lp : -2, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0 keeps -2)
         const bool head = active && (lane == 0 || lp != lp_prev);
-        double2 po[6];
-        if (head) {
-            const double2 *po2 = reinterpret_cast<const double2 *>(g.ptout + (size_t)ip * kPtOut);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) po[k] = po2[k];
-            sStart[lp] = lane;
-        }
+        if (head) sStart[lp] = lane;
         if (lane == 0) sStart[npt] = nob;
+        // the point side runs on lanes (point, component): four lanes per point, sixteen points per sweep.  What such a lane needs from
+        // HBM -- its row of V*^-1, h_c, eb_c and X_c -- is requested here, for the first sweep (a batch has more than sixteen points only
+        // when tracks are shorter than four views)
+        const int qp = lane >> 2, qc = lane & 3;
+        const int c3 = qc < 3 ? qc : 0;
+        const int vi0 = c3 == 0 ? 0 : c3, vi1 = c3 == 0 ? 1 : (c3 == 1 ? 3 : 4), vi2 = c3 == 0 ? 2 : (c3 == 1 ? 4 : 5);   // row c of the packed inverse (00 01 02 11 12 22)
+        double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0, ph = 0.0, pe = 0.0, pX = 0.0;
+        if (qp < npt && qc < 3) {
+            const double *po = g.ptout + (size_t)(p0 + qp) * kPtOut;
+            pv0 = po[vi0]; pv1 = po[vi1]; pv2 = po[vi2]; ph = po[6 + c3]; pe = po[9 + c3];
+            pX = g.pts[3 * (size_t)(p0 + qp) + c3];
+        }
         double e[2] = { 0.0, 0.0 };
         if (active) {
             if (j != jc) {
@@ -3318,29 +3324,45 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
             }
         }
         wave_lds_sync();
-        __builtin_amdgcn_s_setprio(3);   // the six head lanes' chain of latency goes ahead of the SIMD's other wavefronts (0.1985 -> 0.191 ms on C3)
-        if (head) { // the head lane of a point owns the point: it already holds X and the ptout row
-            const int oe = sStart[lp + 1];
-            double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-            for (int o = lane; o < oe; ++o) { t0 += sT[o * 3]; t1 += sT[o * 3 + 1]; t2 += sT[o * 3 + 2]; }
-            const double2 i01 = po[0], i23 = po[1], i45 = po[2], h01 = po[3], h2e0 = po[4], e12 = po[5];
-            const double d0 = h01.x - (i01.x * t0 + i01.y * t1 + i23.x * t2);
-            const double d1 = h01.y - (i01.y * t0 + i23.y * t1 + i45.x * t2);
-            const double d2 = h2e0.x - (i23.x * t0 + i45.x * t1 + i45.y * t2);
-            const double X0 = X[0] + d0, X1 = X[1] + d1, X2 = X[2] + d2;
-            g.pts_new[3 * (size_t)ip] = X0; g.pts_new[3 * (size_t)ip + 1] = X1; g.pts_new[3 * (size_t)ip + 2] = X2;
-            if (g.dB) { g.dB[3 * (size_t)ip] = d0; g.dB[3 * (size_t)ip + 1] = d1; g.dB[3 * (size_t)ip + 2] = d2; }
-            sX[lp * 3] = X0; sX[lp * 3 + 1] = X1; sX[lp * 3 + 2] = X2;
-            double D0 = 1.0, D1 = 1.0, D2 = 1.0;
-            if (cfg.damp_diag) {                                            // PBA: dL and |d|^2 in the metric of diag V_i
-                D0 = D1 = D2 = 0.0;
-                for (int o = lane; o < oe; ++o) { D0 += sD[o * 3]; D1 += sD[o * 3 + 1]; D2 += sD[o * 3 + 2]; }
+        // ---- the point's update on lanes (point, component): sum of the point's t (and diag V) from LDS, the three sums shared inside the
+        // quad by DPP, one row of V*^-1 per lane.  (Until round 4 the point's head lane did all of it alone: a chain of 30 dependent
+        // LDS loads and adds and the 3 x 3 product on 6 lanes of 64.)
+        for (int base = 0; base < npt; base += 16) {
+            const int lq = base + qp;
+            const bool on = lq < npt && qc < 3;
+            if (base > 0) {                                 // further sweeps: their loads could not be issued ahead
+                pv0 = pv1 = pv2 = ph = pe = pX = 0.0;
+                if (on) {
+                    const double *po = g.ptout + (size_t)(p0 + lq) * kPtOut;
+                    pv0 = po[vi0]; pv1 = po[vi1]; pv2 = po[vi2]; ph = po[6 + c3]; pe = po[9 + c3];
+                    pX = g.pts[3 * (size_t)(p0 + lq) + c3];
+                }
             }
-            dl += d0 * (g.mu * D0 * d0 + h2e0.y) + d1 * (g.mu * D1 * d1 + e12.x) + d2 * (g.mu * D2 * d2 + e12.y);
-            dp2 += D0 * d0 * d0 + D1 * d1 * d1 + D2 * d2 * d2;
+            double tc0 = 0.0, tc1 = 0.0, Dc = 1.0;
+            if (on) {
+                const int os = sStart[lq], oe = sStart[lq + 1];
+                int o = os;
+                for (; o + 1 < oe; o += 2) { tc0 += sT[o * 3 + c3]; tc1 += sT[o * 3 + 3 + c3]; }
+                if (o < oe) tc0 += sT[o * 3 + c3];
+                if (cfg.damp_diag) {                                            // PBA: dL and |d|^2 in the metric of diag V_i
+                    Dc = 0.0;
+                    for (o = os; o < oe; ++o) Dc += sD[o * 3 + c3];
+                }
+            }
+            const double tc = tc0 + tc1;
+            const double t0 = dpp_move<0x00>(tc), t1 = dpp_move<0x55>(tc), t2 = dpp_move<0xAA>(tc);   // quad_perm [0,0,0,0], [1,1,1,1], [2,2,2,2]
+            if (on) {
+                const double d = ph - (pv0 * t0 + pv1 * t1 + pv2 * t2);
+                const double Xn = pX + d;
+                const size_t ix = 3 * (size_t)(p0 + lq) + c3;
+                g.pts_new[ix] = Xn;
+                if (g.dB) g.dB[ix] = d;
+                sX[lq * 3 + c3] = Xn;
+                dl += d * (g.mu * Dc * d + pe);
+                dp2 += Dc * d * d;
+            }
         }
         wave_lds_sync();
-        __builtin_amdgcn_s_setprio(0);
         if (active) {
             const double Xn[3] = { sX[lp * 3], sX[lp * 3 + 1], sX[lp * 3 + 2] };
             // project_obs on the compact new record: R = cln[0..8], c = cln[10..12], f = cln[13], k1, k2 = cln[14..15]
@@ -3353,7 +3375,7 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
 #pragma unroll
                 for (int r = 0; r < 3; ++r) q[r] = cln[3 * r] * Xn[0] + cln[3 * r + 1] * Xn[1] + cln[3 * r + 2] * Xn[2] + cln[10 + r];
             }
-            const double iz = 1.0 / q[2], mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
+            const double iz = fast_rcp(q[2]), mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
             const bool md = FULL && cfg.undistort == 2;
             const double gg = cfg.proj_sign * cln[13] * ((!FULL || md) ? 1.0 : 1.0 + cln[14] * r2 + cln[15] * r2 * r2);
             double en0 = xy.x - gg * mx, en1 = xy.y - gg * my;
