@@ -288,3 +288,49 @@ def tri_scene(seed=21, m=24, n=1500, d=6, noise_px=0.3):
         q = np.einsum("kij,j->ki", R[sc.obs_cam[o]], far) + t[sc.obs_cam[o]]
         xy[o] = f[sc.obs_cam[o], None] * q[:, :2] / q[:, 2:3]
     return dict(f=f, R=R.reshape(m, 9), t=t, c=c, pt_ptr=sc.pt_ptr.astype(np.int32), obs_cam=cam.astype(np.int32), xy=xy, X_true=X, m=m, n=n)
+
+
+def c5_scene():
+    """BASELINE config C5: 8 sub-reconstructions of one ring scene (160 cameras, 20 000 points, 6 views), each carrying its own residual
+    Sim(3) misalignment after the pairwise merges (MergeClusters.cpp:894-995 chains such transforms); VSFM frame (+z camera, camera
+    parameters hold t).  Returns the scene (R0 = the clusters' rotations as merged) and the merged parameter vector."""
+    scene = pkg("scene")
+    sc = vsfm_scene(m=160, n=20000, d=6, seed=77, strides=(1, 2, 5), cam_noise=0.0, pt_noise=0.0, f_noise=0.0)
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    rng = np.random.default_rng(5)
+    a = sc.p0[:m * cnp].reshape(m, cnp).copy(); X = sc.p0[m * cnp:].reshape(n, 3).copy()
+    R = sc.R0.reshape(m, 3, 3).copy()
+    cam_cluster = np.arange(m) * 8 // m
+    pt_cluster = cam_cluster[sc.obs_cam[sc.pt_ptr[:-1]]]              # a point belongs to its first camera's cluster
+    for c in range(8):
+        Rc = scene._rodrigues(rng.normal(0, 0.004, 3)); sc_ = 1 + rng.normal(0, 0.004); T = rng.normal(0, 0.02, 3)
+        cams = np.where(cam_cluster == c)[0]
+        for j in cams:                                                  # x = f (R X + t): X' = s Rc X + T
+            Cj = -R[j].T @ a[j, :3]
+            R[j] = R[j] @ Rc.T
+            a[j, :3] = -R[j] @ (sc_ * Rc @ Cj + T)
+        pts = pt_cluster == c
+        X[pts] = sc_ * X[pts] @ Rc.T + T
+    p_init = np.concatenate([a.reshape(-1), X.reshape(-1)])
+    sc.R0 = np.ascontiguousarray(R.reshape(m, 9))
+    return sc, p_init
+
+
+def to_bundler_frame(sc, p):
+    """the same problem in Bundler's frame (-z camera: what sba-1.5 behind run_sfm solves, sfm.c:303-374): R' = F R, t' = F t,
+    y measurements negated, F = diag(1, -1, -1) -- a rotation, so omega' = F omega and the additive damping mu I sees an orthogonal
+    change of variables: the same LM trajectory up to rounding.  Scenes holding t (explicit_centers = 0) with omega = 0 only."""
+    import copy
+    assert sc.proj_sign == 1.0 and sc.explicit_centers == 0
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    F = np.diag([1.0, -1.0, -1.0])
+    a = p[:m * cnp].reshape(m, cnp).copy()
+    assert np.all(a[:, 3:6] == 0)
+    a[:, :3] = a[:, :3] @ F
+    sb = copy.copy(sc)
+    sb.proj_sign = -1.0
+    sb.R0 = np.ascontiguousarray(np.einsum("ij,mjk->mik", F, sc.R0.reshape(m, 3, 3)).reshape(m, 9))
+    sb.x = np.ascontiguousarray(sc.x * np.array([1.0, -1.0]))
+    pb = np.concatenate([a.reshape(-1), p[m * cnp:]])
+    sb.p0 = pb
+    return sb, pb
