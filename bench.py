@@ -37,10 +37,21 @@ def cpu_baseline(scene_mod, gpu_value, config, full_c3=False):
     Cholesky), so by default two iterations of C2 (the same generator, 1/10 of the observations) are timed here and scaled to C3
     by the ratio of the reference's own seconds per iteration on the two configurations as measured in the build container
     (tests/golden/ref_C3.npz, ref_C2.npz) -- flagged as extrapolated.  --cpu-baseline-c3 times one real C3 iteration instead."""
+    # sba-1.5 itself is single-threaded; the LAPACK it calls (MKL here: dpotrf / dpotrs of the reduced system, dsytrf / dsytri per point)
+    # is pinned to ONE thread too, before MKL is loaded, so that "cores" is a fact and not a label
+    os.environ["MKL_NUM_THREADS"] = "1"
+    os.environ["OMP_NUM_THREADS"] = "1"
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle, Reference
     golden = os.path.join(ROOT, "tests", "golden")
-    out = {"unit": "LM iterations/s", "cores": 1, "host_cores": os.cpu_count()}
+    out = {"unit": "LM iterations/s", "cores": 1, "mkl_num_threads": 1, "host_cores": os.cpu_count()}
+    try:                                   # (and through MKL's own call, should the library be initialised already)
+        import ctypes
+        mkl = ctypes.CDLL("/opt/conda/lib/libmkl_rt.so.1")   # the library oracle/_ref/libref_sfm.so is linked with (oracle/Makefile)
+        mkl.MKL_Set_Num_Threads(1)
+        out["mkl_num_threads"] = int(mkl.MKL_Get_Max_Threads())
+    except Exception:
+        pass
     c3 = np.load(os.path.join(golden, "ref_C3.npz")) if os.path.exists(os.path.join(golden, "ref_C3.npz")) else None
     try:
         if Reference.available():
@@ -51,7 +62,7 @@ def cpu_baseline(scene_mod, gpu_value, config, full_c3=False):
                 r = ref.run(sc, itmax=1)
                 dt = time.time() - t0
                 out.update({"value": float(r["info"][9] / dt), "kind": "reference", "config": "C3",
-                            "sample": "config C3 itself: 1 LM iteration of the real sba-1.5 (FD Jacobian, dense Cholesky via MKL), %.1f s" % dt})
+                            "sample": "config C3 itself: 1 LM iteration of the real sba-1.5 (FD Jacobian, dense Cholesky via MKL, MKL_NUM_THREADS=1), %.1f s" % dt})
             else:
                 sc = scene_mod.make_scene("C2")
                 t0 = time.time()
@@ -59,7 +70,7 @@ def cpu_baseline(scene_mod, gpu_value, config, full_c3=False):
                 dt = time.time() - t0
                 out.update({"value": float(r["info"][9] / dt), "kind": "reference", "config": "C2",
                             "sample": "config C2 (200 cams / 100k pts / 1M obs, same generator), 2 LM iterations of the real sba-1.5 (FD Jacobian, "
-                            "dense Cholesky via MKL, MKL_NUM_THREADS unset: sba itself is single-threaded), %.1f s" % dt,
+                            "dense Cholesky via MKL with MKL_NUM_THREADS=1: one core in all), %.1f s" % dt,
                             "rmse_after": float(np.sqrt(r["info"][1] / sc.nobs))})
                 if c3 is not None:
                     c2 = np.load(os.path.join(golden, "ref_C2.npz"))
@@ -146,6 +157,19 @@ def main():
             uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
         eng.comm_init(bytes(uid.cpu().numpy().tobytes()))
+    # what RCCL itself reports about the communicator every rank joined (ncclCommCount / CuDevice / UserRank inside libmi_ba.so), gathered
+    # on rank 0: the line below is refused unless N ranks on N distinct devices were really seen
+    comm = eng.comm_info()
+    comm["hip_device"] = device
+    comm["pid"] = os.getpid()
+    comms = [comm]
+    if dist is not None:
+        comms = [None] * world
+        dist.all_gather_object(comms, comm)
+        if not rehearsal:
+            bad = [c for c in comms if not c["rccl"] or c["nranks"] != world]
+            if bad or len({c["device"] for c in comms}) != world or sorted(c["rank"] for c in comms) != list(range(world)):
+                raise SystemExit("bench.py: the RCCL communicator does not span %d ranks on %d devices: %s" % (world, world, comms))
     eng.set_timing_detail(1)            # HIP events around the build kernels: the roofline figure is measured in the timed steps
     eng.load_scene(sc)
     if args.shared_focal > 0 and not (cfg.est_focal and sc.cnp >= 7):
@@ -235,6 +259,8 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             **({"rehearsal": "ranks share one GPU, host transport: control flow only, not a measurement"} if rehearsal else {}),
+            "rccl": {"transport": "host test transport (rehearsal)" if rehearsal else ("rccl" if world > 1 else "none (one rank: no exchange)"),
+                     "ranks": [{k: c[k] for k in ("rank", "nranks", "device", "hip_device", "pid")} for c in comms]},
             "config": {"workload": f"{args.config}: {sc.m} cams / {sc.n} pts / {sc.nobs} obs, cnp 7 (pose + focal), "
                        "point-sharded Schur + block-Jacobi PCG", "parallelism": f"points/{world}",
                        "pcg_tol": args.pcg_tol, "pcg_maxit": args.pcg_maxit, "deterministic": args.deterministic, "shared_focal_weight": args.shared_focal},

@@ -206,6 +206,10 @@ int mi_ba_set_timing_detail(mi_ba_engine *e, int level);
 #define MI_BA_UNIQUE_ID_BYTES 128
 int mi_ba_comm_unique_id(char id[MI_BA_UNIQUE_ID_BYTES]);                 /* rank 0 */
 int mi_ba_comm_init(mi_ba_engine *e, const char id[MI_BA_UNIQUE_ID_BYTES]); /* every rank, before prepare */
+/* what RCCL itself says about this rank's communicator: out[0] = ncclCommCount, out[1] = ncclCommCuDevice (the HIP device the
+ * communicator is bound to), out[2] = ncclCommUserRank, out[3] = 1 when the exchanges go through RCCL (0: one rank and no
+ * communicator yet, or the host test transport).  Lets a launcher prove that N ranks on N devices were really joined. */
+int mi_ba_comm_info(const mi_ba_engine *e, int out[4]);
 /* test transport: instead of RCCL, every exchange goes device -> host, through `fn` (which must leave the element-wise
  * sum (op 0) or maximum (op 1) over all ranks in buf), and back.  Lets the sharded engine be exercised by several
  * processes that share ONE GPU (tests/test_sharding_gpu.py, gloo underneath); never used by bench.py. */

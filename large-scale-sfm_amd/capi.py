@@ -79,7 +79,7 @@ def lib() -> C.CDLL:
             "mi_ba_get_trace": [vp, dp, i32], "mi_ba_get_params": [vp, dp, dp], "mi_ba_set_params": [vp, dp, dp],
             "mi_ba_get_rotations": [vp, dp], "mi_ba_debug_linearize": [vp, dbl, dp, dp, dp, dp, dp, dp, dp],
             "mi_ba_debug_solve": [vp, dbl, dp, dp, dp], "mi_ba_get_timing": [vp, C.POINTER(Timing)],
-            "mi_ba_comm_init": [vp, C.c_char_p], "mi_ba_comm_unique_id": [C.c_char_p],
+            "mi_ba_comm_init": [vp, C.c_char_p], "mi_ba_comm_unique_id": [C.c_char_p], "mi_ba_comm_info": [vp, C.POINTER(C.c_int)],
             "mi_ba_plan_build": [i32, i32, i64, ip, ip, i32, i32, i32], "mi_ba_plan_build_rows": [i32, i32, i64, ip, ip, i32, i32, i32], "mi_ba_plan_free": [vp],
             "mi_ba_plan_stats": [vp, C.POINTER(i64)], "mi_ba_plan_get": [vp, C.c_char_p, vp, i64],
             "mi_ba_create": [C.POINTER(Config)], "mi_ba_default_config": [C.POINTER(Config)],
@@ -190,6 +190,12 @@ class Engine:
         self._chk(self.L.mi_ba_set_points(self.h, self.n, _d(xyz)), "set_points")
         self._chk(self.L.mi_ba_set_observations(self.h, self.nobs, _d(xy), pt.ctypes.data_as(_ip),
                                                 cam.ctypes.data_as(_ip)), "set_observations")
+
+    def comm_info(self) -> dict:
+        """what RCCL reports about this rank's communicator (mi_ba_comm_info)"""
+        out = (C.c_int * 4)()
+        self._chk(self.L.mi_ba_comm_info(self.h, out), "comm_info")
+        return {"nranks": int(out[0]), "device": int(out[1]), "rank": int(out[2]), "rccl": bool(out[3])}
 
     def comm_init(self, uid: bytes):
         buf = C.create_string_buffer(uid, 128)

@@ -213,6 +213,18 @@ int Engine::set_observations(int64_t nobs, const double *xy, const int *pt_idx, 
     return 0;
 }
 
+// what RCCL reports about the communicator (include/mi_ba.h)
+int Engine::comm_info(int out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!comm_) { out[0] = host_ar_ ? cfg.world : 1; out[1] = cfg.device; out[2] = cfg.rank; return 0; }
+    int n = 0, dev = -1, rk = -1;
+    if (ncclCommCount((ncclComm_t)comm_, &n) != ncclSuccess || ncclCommCuDevice((ncclComm_t)comm_, &dev) != ncclSuccess ||
+        ncclCommUserRank((ncclComm_t)comm_, &rk) != ncclSuccess) { err = "ncclCommCount / CuDevice / UserRank failed"; return MI_BA_ERROR; }
+    out[0] = n; out[1] = dev; out[2] = rk; out[3] = 1;
+    return 0;
+}
+
 int Engine::comm_init(const char *id)
 {
     DeviceGuard on_device(cfg.device);

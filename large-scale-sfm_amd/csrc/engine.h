@@ -65,6 +65,7 @@ public:
     int debug_linearize(double mu, double *S, double *E, double *ea, double *eb, double *V, double *diagU, double *cost);
     int debug_solve(double mu, double *da, double *db, double *cost_new);
     int comm_init(const char *id);
+    int comm_info(int out[4]);
 
     mi_ba_config cfg;
     int cnp = 7;

@@ -143,6 +143,23 @@ def test_two_ranks_on_two_gpus_through_rccl(tmp_path):
     ret, info = eng.run()
     assert abs(int(res[0]["ret"]) - ret) <= 1 and abs(res[0]["info"][1] - info[1]) < 1e-9 * info[1]
     assert np.abs(res[0]["p"] - eng.packed_params()).max() < 1e-6
+    eng.close()
+    # ... and bench.py itself as the driver launches it for N = 2 (torch.distributed.run, one rank per GPU, RCCL): the first multi-GPU
+    # scaling run must not be the first execution of that path.  The line carries what RCCL reported about every rank's communicator.
+    import json
+    import subprocess
+    port = 29900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--config", "C2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "rehearsal" not in d and d["rccl"]["transport"] == "rccl"
+    assert sorted(r["rank"] for r in d["rccl"]["ranks"]) == [0, 1] and all(r["nranks"] == 2 for r in d["rccl"]["ranks"])
+    assert len({r["device"] for r in d["rccl"]["ranks"]}) == 2
+    assert d["kernel_ms_per_step"]["exchange"] > 0 and d["rmse_px"]["after_timed_steps"] < 0.5 * d["rmse_px"]["initial"]
 
 
 def test_bench_with_two_ranks_rehearsed_on_one_gpu(tmp_path):
@@ -163,3 +180,4 @@ def test_bench_with_two_ranks_rehearsed_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and "rehearsal" in d and d["config"]["parallelism"] == "points/2"
     assert d["rmse_px"]["after_timed_steps"] < 0.5 * d["rmse_px"]["initial"] and d["kernel_ms_per_step"]["allreduce_host"] > 0
     assert d["kernel_ms_per_step"]["exchange"] > 0 and d["kernel_ms_per_step"]["replicated"] > 0      # what a scaling run has to explain itself with
+    assert d["rccl"]["transport"].startswith("host") and sorted(r["rank"] for r in d["rccl"]["ranks"]) == [0, 1]    # every rank reported in
