@@ -164,6 +164,10 @@ int mi_ba_get_rotations(mi_ba_engine *e, double *R);
  *   V   n*9 undamped V_i (full symmetric),  diagU m*cnp, returns cost in *cost              */
 int mi_ba_debug_linearize(mi_ba_engine *e, double mu, double *S, double *E, double *ea, double *eb,
                           double *V, double *diagU, double *cost);
+/* after debug_linearize on an engine whose every point takes the row path (mi_ba_config.deterministic = 2, one rank): the full blocks
+ * sba exports through Uout / Wout -- U m*cnp*cnp (row-major U_j, camera-constraint weights on the diagonal), W nobs*cnp*3 (W_ij = A^T B
+ * of observation k in the caller's order).  Either may be NULL. */
+int mi_ba_debug_blocks(mi_ba_engine *e, double *U, double *W);
 /* after debug_linearize: solve S da = E with the PCG, back-substitute; da m*cnp, db n*3,
  * cost at p + dp; returns PCG iterations or MI_BA_ERROR */
 int mi_ba_debug_solve(mi_ba_engine *e, double mu, double *da, double *db, double *cost_new);

@@ -71,6 +71,21 @@ int mi_sba_motstr_levmar(int n, int m, int mcon, const char *vmask, double *p, i
                          const double *R0, const double *f_fixed, int explicit_camera_centers,
                          int itmax, int verbose, const double opts[6], double info[10]);
 
+/* the same with sba's four output hooks (sba.h:95-108 "Vout, Sout, Uout, Wout"; filled by sba_motstr_levmar_x after the solve from a
+ * linearisation at the final estimate WITHOUT damping, sba_levmar.c:1633-2026).  Any of them may be NULL.  Layouts as the reference's:
+ *   Vout  n * 9        V_i = sum_j B_ij^T B_ij (+ point constraints), full symmetric 3 x 3          (:1758-1769)
+ *   Uout  m * cnp^2    U_j = sum_i A_ij^T A_ij (+ camera constraints on the diagonal), row-major   (:1694-1695)
+ *   Wout  (m cnp) x (3 n) dense row-major: Wout[(j cnp + r) 3 n + 3 i + c] = W_ij[r][c] = (A_ij^T B_ij)[r][c], zero where point i is not
+ *         seen by camera j or the camera is fixed (:1829-1842)
+ *   Sout  (m cnp)^2    S = U - W V^-1 W^T (symmetric, so the reference's final transposition is immaterial)  (:1908-2019); with mcon > 0
+ *         the fixed cameras' rows and columns are identity here (the reference compacts them away)
+ * The Jacobian behind them is analytic (the reference's: forward differences): they agree with the reference's to ~1e-5 relative.
+ * Singular V_i at zero damping (a point seen from one direction only) -> MI_BA_ERROR (the reference substitutes 100 I, :1776-1784). */
+int mi_sba_motstr_levmar_blocks(int n, int m, int mcon, const char *vmask, double *p, int cnp, const double *x,
+                                const double *R0, const double *f_fixed, int explicit_camera_centers,
+                                int itmax, int verbose, const double opts[6], double info[10],
+                                double *Vout, double *Sout, double *Uout, double *Wout);
+
 #ifdef __cplusplus
 }
 #endif

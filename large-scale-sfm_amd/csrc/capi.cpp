@@ -111,6 +111,7 @@ int mi_ba_comm_unique_id(char id[MI_BA_UNIQUE_ID_BYTES])
     return 0;
 }
 int mi_ba_comm_init(mi_ba_engine *h, const char id[MI_BA_UNIQUE_ID_BYTES]) { return h ? h->e->comm_init(id) : MI_BA_ERROR; }
+int mi_ba_debug_blocks(mi_ba_engine *h, double *U, double *W) { return h ? h->e->debug_blocks(U, W) : MI_BA_ERROR; }
 int mi_ba_comm_info(const mi_ba_engine *h, int out[4]) { return h && out ? h->e->comm_info(out) : MI_BA_ERROR; }
 
 // ---- planner -------------------------------------------------------------------------------

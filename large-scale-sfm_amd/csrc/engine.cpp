@@ -1135,6 +1135,41 @@ int Engine::get_rotations(double *R)
     return hipok(hipMemcpy(R, tmp.p, sizeof(double) * (size_t)m_ * 9, hipMemcpyDeviceToHost), "download R") ? 0 : MI_BA_ERROR;
 }
 
+// U_j = sum_i A_ij^T A_ij (+ the soft camera constraints' weights on the diagonal) and W_ij = A_ij^T B_ij of the LAST linearisation, from
+// the observation records the row path leaves in HBM (A | B | e | ..., kernels.hip RecL) -- what sba hands out through Uout / Wout
+// (sba_levmar.c:1633-1700, 1812-1850).  Needs every point on the row path (mi_ba_config.deterministic = 2) and one rank.
+//   U  m * cnp * cnp row-major blocks;  W  nobs * cnp * 3, observation k of the caller's order: W[k][r][c]
+int Engine::debug_blocks(double *U, double *W)
+{
+    DeviceGuard on_device(cfg.device);
+    if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
+    if (!prepared_) { err = "debug_blocks: prepare first"; return MI_BA_ERROR; }
+    const Plan &pl = plan_;
+    if (cfg.deterministic != 2 || cfg.world > 1) { err = "debug_blocks: needs deterministic = 2 (every observation leaves a record) and world == 1"; return MI_BA_ERROR; }
+    const int rs = split_ ? kRec9 : kRec, ap = split_ ? 10 : 8;
+    const size_t nrec = (size_t)pl.rec_cam[m_];
+    std::vector<double> rec(nrec * rs);
+    if (nrec && !hipok(hipMemcpy(rec.data(), d_rec_.p, rec.size() * sizeof(double), hipMemcpyDeviceToHost), "download records")) return MI_BA_ERROR;
+    if (U) std::fill(U, U + (size_t)m_ * cnp * cnp, 0.0);
+    const int64_t nol = pl.nobs_local();
+    for (int64_t o = 0; o < nol; ++o) {
+        const int r = pl.obs_rec[o], j = pl.obs_cam[o];
+        if (r < 0) { err = "debug_blocks: an observation without a record"; return MI_BA_ERROR; }
+        const double *q = rec.data() + (size_t)r * rs, *A0 = q, *A1 = q + ap, *B = q + 2 * ap;
+        if (U) {
+            double *u = U + (size_t)j * cnp * cnp;
+            for (int a = 0; a < cnp; ++a) for (int b = 0; b < cnp; ++b) u[a * cnp + b] += A0[a] * A0[b] + A1[a] * A1[b];
+        }
+        if (W) {
+            double *w = W + (size_t)pl.obs_src[o] * cnp * 3;
+            for (int a = 0; a < cnp; ++a) for (int c = 0; c < 3; ++c) w[a * 3 + c] = A0[a] * B[c] + A1[a] * B[3 + c];
+        }
+    }
+    if (U && !h_cam_cw_.empty())
+        for (int j = 0; j < m_; ++j) for (int a = 0; a < cnp; ++a) U[(size_t)j * cnp * cnp + a * cnp + a] += h_cam_cw_[(size_t)j * cnp + a];
+    return 0;
+}
+
 int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double *eb, double *V, double *diagU, double *cost)
 {
     DeviceGuard on_device(cfg.device);
@@ -1143,6 +1178,7 @@ int Engine::debug_linearize(double mu, double *S, double *E, double *ea, double 
     if (cfg.world > 1 && (eb || V)) { err = "debug_linearize: point outputs need world == 1"; return MI_BA_ERROR; }
     spec_ready_ = false;   // whatever was enqueued for the next trial is overwritten here
     if (!linear_phase(mu, true) || !read_scalars()) return MI_BA_ERROR;
+    if (mu == 0.0 && h_scal_[SC_SINGULAR] != 0.0) { err = "debug_linearize: a V_i is singular at zero damping"; return MI_BA_ERROR; }
     const Plan &pl = plan_;
     if (cost) *cost = h_scal_[SC_COST];
     const size_t vec = (size_t)mv_ * kCP;

@@ -66,6 +66,7 @@ public:
     int debug_solve(double mu, double *da, double *db, double *cost_new);
     int comm_init(const char *id);
     int comm_info(int out[4]);
+    int debug_blocks(double *U, double *W);
 
     mi_ba_config cfg;
     int cnp = 7;

@@ -11,11 +11,12 @@
 namespace {
 
 struct Constraints { const double *cam_w = nullptr, *cam_v = nullptr, *pt_w = nullptr, *pt_v = nullptr; };
+struct Blocks { double *V = nullptr, *S = nullptr, *U = nullptr, *W = nullptr; bool any() const { return V || S || U || W; } };
 
 // cnp 6 / 7: pose (+ focal length); undistort: + k1, k2 (cnp 8 / 9), Bundler's projection distortion (sfm.c:360-373, 648-649)
 int solve(int n, int m, int mcon, const char *vmask, double *p, int cnp, const double *x, const double *R0,
           const double *f_fixed, int explicit_centers, int itmax, int verbose, const double opts[6], double info[10], int mode = 0,
-          const Constraints &cons = Constraints(), int undistort = 0)
+          const Constraints &cons = Constraints(), int undistort = 0, const Blocks &out = Blocks())
 {
     const int est_focal = undistort ? cnp == 9 : cnp == 7;
     if (n <= 0 || m <= 0 || !vmask || !p || !x || !R0 || (undistort ? (cnp != 8 && cnp != 9) : (cnp != 6 && cnp != 7))) {
@@ -43,6 +44,32 @@ int solve(int n, int m, int mcon, const char *vmask, double *p, int cnp, const d
     }
     if (ret == MI_BA_ERROR) std::fprintf(stderr, "mi_sba_motstr_levmar: %s\n", mi_ba_last_error(e));
     mi_ba_destroy(e);
+    // sba's output hooks (sba_levmar.c:1633-2026): one more linearisation at the final estimate, without damping, on an engine whose every
+    // observation leaves its A | B record in HBM (deterministic = 2: the block-major row path) -- S and V from the parity hook, U and W
+    // formed on the host from the records
+    if (ret != MI_BA_ERROR && out.any()) {
+        if (mode != 0) { std::fprintf(stderr, "mi_sba_motstr_levmar: Vout / Sout / Uout / Wout exist for the full bundle only (sba_motstr_levmar_x)\n"); return MI_BA_ERROR; }
+        cfg.deterministic = 2;
+        mi_ba_engine *b = mi_ba_create(&cfg);
+        if (!b) { std::fprintf(stderr, "mi_sba_motstr_levmar: %s\n", mi_ba_last_error(nullptr)); return MI_BA_ERROR; }
+        const size_t N = (size_t)m * cnp, nobs = pt.size();
+        std::vector<double> Wc(out.W ? nobs * cnp * 3 : 0);
+        int rc = MI_BA_ERROR;
+        if (mi_ba_set_cameras(b, m, p, R0, f_fixed) == 0 && mi_ba_set_points(b, n, p + N) == 0 &&
+            mi_ba_set_camera_constraints(b, cons.cam_w, cons.cam_v) == 0 && mi_ba_set_point_constraints(b, cons.pt_w, cons.pt_v) == 0 &&
+            mi_ba_set_observations(b, (int64_t)nobs, x, pt.data(), cam.data()) == 0 && mi_ba_prepare(b) == 0 &&
+            mi_ba_debug_linearize(b, 0.0, out.S, nullptr, nullptr, nullptr, out.V, nullptr, nullptr) == 0 &&
+            ((!out.U && !out.W) || mi_ba_debug_blocks(b, out.U, out.W ? Wc.data() : nullptr) == 0)) rc = 0;
+        if (rc != 0) std::fprintf(stderr, "mi_sba_motstr_levmar: output blocks: %s\n", mi_ba_last_error(b));
+        mi_ba_destroy(b);
+        if (rc != 0) return MI_BA_ERROR;
+        if (out.W) {                                   // dense (m cnp) x (3 n), sba_levmar.c:1829-1842
+            std::fill(out.W, out.W + N * 3 * (size_t)n, 0.0);
+            for (size_t k = 0; k < nobs; ++k)
+                for (int r = 0; r < cnp; ++r)
+                    for (int c = 0; c < 3; ++c) out.W[((size_t)cam[k] * cnp + r) * 3 * (size_t)n + 3 * (size_t)pt[k] + c] = Wc[(k * cnp + r) * 3 + c];
+        }
+    }
     return ret;
 }
 
@@ -57,18 +84,29 @@ int mi_sba_motstr_levmar(int n, int m, int mcon, const char *vmask, double *p, i
     return solve(n, m, mcon, vmask, p, cnp, x, R0, f_fixed, explicit_camera_centers, itmax, verbose, opts, info);
 }
 
+int mi_sba_motstr_levmar_blocks(int n, int m, int mcon, const char *vmask, double *p, int cnp, const double *x,
+                                const double *R0, const double *f_fixed, int explicit_camera_centers,
+                                int itmax, int verbose, const double opts[6], double info[10],
+                                double *Vout, double *Sout, double *Uout, double *Wout)
+{
+    Blocks out; out.V = Vout; out.S = Sout; out.U = Uout; out.W = Wout;
+    return solve(n, m, mcon, vmask, p, cnp, x, R0, f_fixed, explicit_camera_centers, itmax, verbose, opts, info, 0, Constraints(), 0, out);
+}
+
 int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *projections,
                int est_focal_length, int const_focal_length, int undistort, int explicit_camera_centers,
                camera_params_t *cams, v3_t *pts, int use_constraints, int use_point_constraints,
                v3_t *pt_constraints, double pt_constraint_weight, int fix_points, int optimize_for_fisheye,
                double eps2, double *Vout, double *Sout, double *Uout, double *Wout, double info_out[10])
 {
-    if (const_focal_length || optimize_for_fisheye || Vout || Sout || Uout || Wout ||
+    if (const_focal_length || optimize_for_fisheye || ((Vout || Sout || Uout || Wout) && fix_points) ||
         (use_point_constraints && (fix_points || !pt_constraints))) {
         std::fprintf(stderr, "[run_sfm] this build supports est_focal_length / undistort / explicit_camera_centers / ncons / fix_points / "
-                             "use_constraints / use_point_constraints (no fisheye, const_focal_length or Vout/Sout/Uout/Wout)\n");
+                             "use_constraints / use_point_constraints / Vout, Sout, Uout, Wout (no fisheye, no const_focal_length; the output "
+                             "blocks with the full bundle only, as in the reference)\n");
         return MI_BA_ERROR;
     }
+    Blocks blocks; blocks.V = Vout; blocks.S = Sout; blocks.U = Uout; blocks.W = Wout;
     const int m = num_cameras, n = num_pts, cnp = (est_focal_length ? 7 : 6) + (undistort ? 2 : 0), kc = est_focal_length ? 7 : 6;
     const double f_scale = 0.001, k_scale = 5.0; // sfm.c:640-641 (TEST_FOCAL)
     std::vector<double> p((size_t)m * cnp + 3 * (size_t)n), R0((size_t)m * 9), ff(m);
@@ -109,7 +147,7 @@ int mi_run_sfm(int num_pts, int num_cameras, int ncons, char *vmask, double *pro
     }
     double info[10] = { 0 };
     const int ret = solve(n, m, ncons, vmask, p.data(), cnp, projections, R0.data(), ff.data(), explicit_camera_centers,
-                          150 /* MAX_ITERS, sfm.c:820 */, 0, opts, info, fix_points ? 1 : 0 /* sba_mot_levmar, sfm.c:845-852 */, cons, undistort);
+                          150 /* MAX_ITERS, sfm.c:820 */, 0, opts, info, fix_points ? 1 : 0 /* sba_mot_levmar, sfm.c:845-852 */, cons, undistort, blocks);
     if (info_out) std::memcpy(info_out, info, sizeof(info));
     if (ret == MI_BA_ERROR) return ret;
     std::printf("[run_sfm] Number of iterations: %d\n", (int)info[5]);

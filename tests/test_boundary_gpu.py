@@ -144,6 +144,57 @@ def test_sba_motstr_levmar_shape():
     assert abs(info[1] - want[1]) < 1e-6 * want[1]
 
 
+def test_sba_output_blocks_in_the_references_layouts():
+    """Vout / Sout / Uout / Wout of sba_motstr_levmar and run_sfm (sba.h:95-108, sfm.h:68-86; filled at sba_levmar.c:1633-2026 from an
+    undamped linearisation at the final estimate): against the blocks the REAL reference exported on the micro scene (ref_micro.npz: S0,
+    U0, V0, W0 -- forward-difference Jacobians there, analytic here: 1e-4), through the C ABI, in the reference's own layouts; and through
+    run_sfm at the end of a whole solve, where the four arrays must satisfy S = U - W V^-1 W^T among themselves."""
+    sc, z = scene_from_golden("micro")
+    L = pkg("capi").lib()
+    m, n, cnp = sc.m, sc.n, sc.cnp
+    N = m * cnp
+    vmask, x = _dense_inputs(sc)
+    p = sc.p0.copy(); info = np.zeros(10)
+    opts = np.array([1e-3, 1e300, 1e-12, 1e-12, 0.0, 4e-2])     # eps1 huge: stop 1 before the first step, as make_golden.py ran the reference
+    V, S, U, W = np.zeros((n, 3, 3)), np.zeros((N, N)), np.zeros((m, cnp, cnp)), np.zeros((N, 3 * n))
+    vp = C.c_void_p
+    L.mi_sba_motstr_levmar_blocks.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]
+    ret = L.mi_sba_motstr_levmar_blocks(n, m, 0, vmask.ctypes.data, p.ctypes.data, cnp, x.ctypes.data, sc.R0.ctypes.data, sc.f_fixed.ctypes.data,
+                                        sc.explicit_centers, 1, 0, opts.ctypes.data, info.ctypes.data, V.ctypes.data, S.ctypes.data, U.ctypes.data, W.ctypes.data)
+    assert ret == 0 and info[6] == 1 and np.array_equal(p, sc.p0)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(U, z["U0"]) < 1e-4 and rel(V, z["V0"]) < 1e-4 and rel(W, z["W0"]) < 1e-4
+    assert np.abs(S - z["S0"]).max() < 1e-4 * np.abs(z["U0"]).max()
+    assert (W != 0).sum() == sc.nobs * cnp * 3 and np.array_equal(W.reshape(m, cnp, n, 3)[:, 0, :, 0] != 0, vmask.T != 0)   # zero where camera j does not see point i
+    # any subset of the four may be asked for
+    S2 = np.zeros((N, N))
+    assert L.mi_sba_motstr_levmar_blocks(n, m, 0, vmask.ctypes.data, p.ctypes.data, cnp, x.ctypes.data, sc.R0.ctypes.data, sc.f_fixed.ctypes.data,
+                                         sc.explicit_centers, 1, 0, opts.ctypes.data, info.ctypes.data, None, S2.ctypes.data, None, None) == 0
+    assert np.array_equal(S2, S)
+    # run_sfm with the four hooks: a whole solve, the blocks at its answer
+    a = sc.p0[:N].reshape(m, cnp)
+    cams = (CameraParams * m)()
+    for j in range(m):
+        cams[j].R[:] = list(sc.R0[j]); cams[j].t[:] = list(a[j, :3]); cams[j].f = a[j, 6] / 0.001
+    pts = np.ascontiguousarray(sc.p0[N:]).copy()
+    L.mi_run_sfm.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_double, C.c_int, C.c_int,
+                             C.c_double, vp, vp, vp, vp, vp]
+    V[:] = 0; S[:] = 0; U[:] = 0; W[:] = 0
+    ret = L.mi_run_sfm(n, m, 0, vmask.ctypes.data, x.ctypes.data, 1, 0, 0, sc.explicit_centers, C.addressof(cams), pts.ctypes.data, 0, 0, None, 0.0, 0, 0, 1e-12,
+                       V.ctypes.data, S.ctypes.data, U.ctypes.data, W.ctypes.data, info.ctypes.data)
+    assert ret == int(z["ret_final"]) and info[6] == z["info_final"][6]
+    Ud = np.zeros((N, N)); Vi = np.zeros((3 * n, 3 * n))
+    for j in range(m):
+        Ud[j * cnp:(j + 1) * cnp, j * cnp:(j + 1) * cnp] = U[j]
+    for i in range(n):
+        Vi[3 * i:3 * i + 3, 3 * i:3 * i + 3] = np.linalg.inv(V[i])
+    assert np.abs(S - (Ud - W @ Vi @ W.T)).max() < 1e-9 * np.abs(U).max() and np.abs(S - S.T).max() < 1e-9 * np.abs(U).max()
+    assert rel(U, z["U0"]) > 1e-3                                    # (at the answer, not at the start)
+    # the truncated bundles have no such hooks in the reference either
+    assert L.mi_run_sfm(n, m, 0, vmask.ctypes.data, x.ctypes.data, 1, 0, 0, sc.explicit_centers, C.addressof(cams), pts.ctypes.data, 0, 0, None, 0.0, 1, 0, 1e-12,
+                        V.ctypes.data, None, None, None, None) == -1
+
+
 def test_optimizer_all_with_only_the_side_files_the_callers_write(tmp_path, oracle):
     """the two TriangulationMultiStep call sites (:1024-1095, :1308-1382) leave NO NVM before system("../bin/optimizer_all ..."):
     the freshly triangulated points exist only in ours_new.txt, the cameras only as R + centre and a focal file.  The binary
