@@ -118,6 +118,7 @@ ModelCfg Engine::model() const
     mc.mcon = cfg.mcon; mc.points_fixed = cfg.mode == 1; mc.proj_sign = cfg.proj_sign; mc.f_scale = cfg.f_scale; mc.k_scale = cfg.k_scale;
     mc.inv_f_scale = 1.0 / cfg.f_scale; mc.inv_k_scale = 1.0 / cfg.k_scale;
     mc.nk = cfg.undistort == 1 ? cfg.nk : 1; mc.split = split_ ? 1 : 0;
+    mc.pba_update = lm_variant_cfg_ >= 1 ? 1 : 0;   // PBA's controller comes with PBA's UpdateCamera (f clamp, R <- exp(d omega) R)
     mc.damp_diag = cfg.lm_variant == 1;         // (2: PBA's controller with identity damping, __lm_use_diagonal_damp off)
     return mc;
 }
@@ -376,7 +377,7 @@ int Engine::prepare()
             }
         }
     }
-    UP(d_R0_, h_R0_); UP(d_ff_, h_ff_);
+    UP(d_R0_[0], h_R0_); UP(d_R0_[1], h_R0_); UP(d_R0_init_, h_R0_); UP(d_ff_, h_ff_);
     {   // soft constraints: camera side always present (zeros = none), point side only when set
         if (!h_pt_cw_.empty() && cfg.mode != 0) { err = "prepare: point constraints need the full bundle (mode 0)"; return MI_BA_ERROR; }
         if (!h_cam_cw_.empty() && cfg.mode == 2) { err = "prepare: camera constraints make no sense in a structure-only bundle"; return MI_BA_ERROR; }
@@ -564,6 +565,7 @@ int Engine::set_params(const double *a, const double *xyz)
         for (int r = 0; r < 3; ++r) { double v = xyz[3 * (size_t)pl.perm[t] + r]; pl2_inactive_ += v * v; }
     if (xyz != h_xyz_.data()) h_xyz_.assign(xyz, xyz + (size_t)n_ * 3);
     cur_ = 0; cam_lin_valid_ = false;
+    if (!hipok(hipMemcpy(d_R0_[0].p, d_R0_init_.p, d_R0_init_.n * sizeof(double), hipMemcpyDeviceToDevice), "restore R0")) return MI_BA_ERROR;   // (PBA's update moves it)
     if (!hipok(hipMemcpy(d_cam_a_[0].p, ap.data(), ap.size() * sizeof(double), hipMemcpyHostToDevice), "upload cam_a")) return MI_BA_ERROR;
     if (npl && !hipok(hipMemcpy(d_pts_[0].p, pp.data(), pp.size() * sizeof(double), hipMemcpyHostToDevice), "upload pts")) return MI_BA_ERROR;
     // a device-resident copy of the starting point, for restart()
@@ -581,6 +583,7 @@ int Engine::restart()
     if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_ || !d_cam_a_init_.p) { err = "restart: prepare first"; return MI_BA_ERROR; }
     cur_ = 0; cam_lin_valid_ = false;
+    if (!hipok(hipMemcpyAsync(d_R0_[0].p, d_R0_init_.p, d_R0_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore R0")) return MI_BA_ERROR;
     if (!hipok(hipMemcpyAsync(d_cam_a_[0].p, d_cam_a_init_.p, d_cam_a_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore cam_a")) return MI_BA_ERROR;
     if (d_pts_init_.n && !hipok(hipMemcpyAsync(d_pts_[0].p, d_pts_init_.p, d_pts_init_.n * sizeof(double), hipMemcpyDeviceToDevice, st_), "restore pts")) return MI_BA_ERROR;
     return begin();
@@ -646,7 +649,12 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     const ModelCfg mc = model();
     if (!hipok(hipMemsetAsync(d_acc_.p, 0, d_acc_.n * sizeof(double), st_), "memset acc")) return false;
     // the camera records of the current estimate: after an accepted trial they are the ones k_cam_update wrote for the trial point
-    if (!cam_lin_valid_) { launch_cam_prep(st_, m_, cnp, mc, d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p); cam_lin_valid_ = true; }
+    if (!cam_lin_valid_) {
+        launch_cam_prep(st_, m_, cnp, mc, d_cam_a_[cur_].p, d_R0_[cur_].p, d_ff_.p, d_cam_lin_[cur_].p);
+        // PBA's parametrisation: whatever omega the caller passed is folded into the rotation the camera is linearised about
+        if (mc.pba_update) launch_cam_rebase(st_, m_, split_ ? 2 * kCP : kCP, d_cam_a_[cur_].p, d_cam_lin_[cur_].p, d_R0_[cur_].p);
+        cam_lin_valid_ = true;
+    }
     BuildArgs a{};
     a.tile_batch = d_tile_batch_.p; a.tile_slot = d_tile_slot_.p; a.tile_cslot = d_tile_cslot_.p;
     a.tile_mode = d_tile_mode_.p; a.has_table = pl.ntile_table > 0; a.has_mfma = pl.ntile_mfma > 0; a.has_uni = pl.ntile_uni > 0; a.has_reg = pl.ntile_lds - pl.ntile_table - pl.ntile_mfma - pl.ntile_uni > 0;
@@ -847,8 +855,8 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
 {
     const Plan &pl = plan_;
     const ModelCfg mc = model();
-    launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, upd_p_, d_dA_.p, camvec_(), d_R0_.p, d_ff_.p, links_,
-                      d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part2_.p);
+    launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, upd_p_, d_dA_.p, camvec_(), d_R0_[cur_].p, d_ff_.p, links_,
+                      d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part2_.p, mc.pba_update ? d_R0_[cur_ ^ 1].p : nullptr);
     BacksubArgs b{};
     b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_real_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
@@ -1097,6 +1105,25 @@ int Engine::get_params(double *a, double *xyz)
         if (!hipok(hipMemcpy(ap.data(), d_cam_a_[cur_].p, ap.size() * sizeof(double), hipMemcpyDeviceToHost), "download cam_a")) return MI_BA_ERROR;
         for (int j = 0; j < m_; ++j)
             for (int r = 0; r < cnp; ++r) a[(size_t)j * cnp + r] = ap[slot_(j, r)];
+        if (lm_variant_cfg_ >= 1) {
+            // PBA's update keeps the whole rotation in the (moving) R0 and omega at 0; the interface's omega is relative to the rotation the
+            // caller passed: omega = log(R R0^T)
+            std::vector<double> Rc((size_t)m_ * 9);
+            if (!hipok(hipMemcpy(Rc.data(), d_R0_[cur_].p, Rc.size() * sizeof(double), hipMemcpyDeviceToHost), "download R")) return MI_BA_ERROR;
+            for (int j = 0; j < m_; ++j) {
+                const double *R = &Rc[(size_t)j * 9], *Q = &h_R0_[(size_t)j * 9];
+                double w[3] = { ap[slot_(j, 3)], ap[slot_(j, 4)], ap[slot_(j, 5)] };
+                if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0) {          // (before the first linearisation of a solve omega is still the caller's)
+                    double D[9];
+                    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) D[3 * r + c] = R[3 * r] * Q[3 * c] + R[3 * r + 1] * Q[3 * c + 1] + R[3 * r + 2] * Q[3 * c + 2];
+                    const double cs = std::min(1.0, std::max(-1.0, 0.5 * (D[0] + D[4] + D[8] - 1.0))), th = std::acos(cs);
+                    const double v[3] = { D[7] - D[5], D[2] - D[6], D[3] - D[1] }, sn = std::sin(th);
+                    const double k = sn < 1e-12 ? 0.5 : th / (2.0 * sn);
+                    for (int r = 0; r < 3; ++r) w[r] = k * v[r];
+                }
+                for (int r = 0; r < 3; ++r) a[(size_t)j * cnp + 3 + r] = w[r];
+            }
+        }
     }
     if (xyz) {
         const size_t npl = (size_t)pl.npts_local();
@@ -1127,7 +1154,7 @@ int Engine::get_rotations(double *R)
     DeviceGuard on_device(cfg.device);
     if (!hipok(on_device.status, "hipSetDevice")) return MI_BA_ERROR;
     if (!prepared_) { err = "get_rotations: prepare first"; return MI_BA_ERROR; }
-    launch_cam_prep(st_, m_, cnp, model(), d_cam_a_[cur_].p, d_R0_.p, d_ff_.p, d_cam_lin_[cur_].p);
+    launch_cam_prep(st_, m_, cnp, model(), d_cam_a_[cur_].p, d_R0_[cur_].p, d_ff_.p, d_cam_lin_[cur_].p);
     DevBuf<double> tmp;
     if (!hipok(tmp.alloc((size_t)m_ * 9), "alloc R")) return MI_BA_ERROR;
     launch_rotations(st_, m_, d_cam_lin_[cur_].p, tmp.p);

@@ -168,7 +168,7 @@ private:
     LongArgs long_args(double mu, double *dB_dev, int part_row0);
     DevBuf<double2> d_obs_xy_;
     // device: state
-    DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_S_pcg_, d_Linv_, d_E_, d_dA_, d_dB_,
+    DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_[2] /* [cur_]: the rotation omega is relative to; moves with the camera under PBA's update */, d_R0_init_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_S_pcg_, d_Linv_, d_E_, d_dA_, d_dB_,
         d_pcg_, d_rzpq_, d_full_pts_, d_part_, d_stage_, d_spec_;
     int cur_ = 0; // index of the current estimate in the [2] buffers
     bool cam_lin_valid_ = false; // d_cam_lin_[cur_] holds the records of d_cam_a_[cur_]

@@ -29,6 +29,8 @@ struct ModelCfg {
     int nk;             // radial coefficients that are parameters with undistort == 1: 1 (k1) or 2 (k1, k2: Bundler, sfm.c:648-649)
     int split;          // 9 camera parameters: camera j is rows 2j (parameters 0-7) and 2j + 1 (parameter 8) of every camera-side array
     int points_fixed;   // motion-only bundle: B_ij := 0 (sba_mot_levmar_x has no structure block)
+    int pba_update;     // PBA's UpdateCamera (SparseBundleCPU.cpp:1073-1105): f = max(f + d, 1e-10) and R <- exp(d omega) R with omega back at 0 after every
+                        // step -- the rotation the camera is linearised about moves with it (R0 is double-buffered like the parameters)
     int damp_diag;      // PBA's damping: U* = U + mu diag(U), V* = V + mu diag(V) (SparseBundleCPU.cpp:1813-1814) instead of sba's + mu I
     double proj_sign, f_scale, k_scale;
     double inv_f_scale, inv_k_scale;   // 1 / f_scale, 1 / k_scale (the per-observation kernels multiply; a division by a uniform is 13 instructions there)
@@ -211,7 +213,9 @@ void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, dou
  // out8[c] = max over the ranks' slots, which are zeroed
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const PcgArgs &pa,
                        double *dA, const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
-                       double *cam_lin_new, double *cam_part);   // ends the scaled solve (da = Linv^T x~, + k_pcg_tail's work with pa.tail), then a + da
+                       double *cam_lin_new, double *cam_part, double *R0_new /* cfg.pba_update: the trial's rotations, or nullptr */);
+// cfg.pba_update, at the start of a solve: R0 <- exp([omega]x) R0, omega <- 0, J_l <- I (idempotent)
+void launch_cam_rebase(hipStream_t st, int m, int row_stride /* doubles between cameras in cam_a */, double *cam_a, double *cam_lin, double *R0);   // ends the scaled solve (da = Linv^T x~, + k_pcg_tail's work with pa.tail), then a + da
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a);
 void launch_long_build(hipStream_t st, int cnp, const LongArgs &a);   // k_long_reduce
 void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a); // after every record of this linearisation has been written

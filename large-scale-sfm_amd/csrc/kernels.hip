@@ -3189,7 +3189,7 @@ __device__ __forceinline__ double scaled_back(const PcgArgs &pa, int k, int r)
 __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *__restrict__ fixed, double mu, const double *__restrict__ cam_a,
                              const PcgArgs pa, double *__restrict__ dA, const double *__restrict__ camvec,
                              const double *__restrict__ R0, const double *__restrict__ f_fixed, const CamLinks lk,
-                             double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ part)
+                             double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ part, double *__restrict__ R0_new)
 {
     // one thread per REAL camera; its parameters sit in row j of the camera-side arrays, or -- nine parameters, cfg.split -- in
     // rows 2j (parameters 0-7) and 2j + 1 (parameter 8, the rest of that row is padding held at zero)
@@ -3208,7 +3208,9 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
                 dA[v * kCP + r] = dj;
                 const bool live = (row == 0 ? r < cnp : r == 0) && !fixed[v];
                 const double d = live ? dj : 0.0;
-                const double a_new = cam_a[v * kCP + r] + d;
+                double a_new = cam_a[v * kCP + r] + d;
+                // PBA's UpdateCamera keeps the focal length positive: f = max(f + d, 1e-10) (SparseBundleCPU.cpp:1082), in its own units
+                if (cfg.pba_update && cfg.est_focal && row == 0 && r == 6 && live) a_new = fmax(a_new, 1e-10 * cfg.f_scale);
                 cam_a_new[v * kCP + r] = a_new;
                 const double D = cfg.damp_diag ? camvec[(2 * (size_t)(cfg.split ? 2 * m : m) + v) * kCP + r] : 1.0;   // PBA: dL = d'(mu D d + g), |d|^2 in D's metric
                 dl += d * (mu * D * d + camvec[v * kCP + r]);
@@ -3217,6 +3219,14 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
             }
         }
         cam_record(cfg, cnp, an, R0 + (size_t)j * 9, f_fixed ? f_fixed[j] : 1.0, cam_lin_new + (size_t)j * kCamLin);
+        if (cfg.pba_update && R0_new) {
+            // PBA's update of the rotation, R <- exp([d omega]x) R (:1089-1098): the trial's rotation becomes the rotation the camera is
+            // linearised about, omega goes back to 0 and with it J_l(omega) = I -- the next Jacobian is PBA's JacobianOne (:1332-1455)
+            double *cl = cam_lin_new + (size_t)j * kCamLin;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { R0_new[(size_t)j * 9 + i] = cl[i]; cl[9 + i] = (i % 4 == 0) ? 1.0 : 0.0; }
+            cam_a_new[vb * kCP + 3] = 0.0; cam_a_new[vb * kCP + 4] = 0.0; cam_a_new[vb * kCP + 5] = 0.0;
+        }
         if (lk.row)                                            // link penalty at the trial point (links couple parameters 0-7: row vb)
             for (int q = lk.row[vb]; q < lk.row[vb + 1]; ++q) {
                 const int k = lk.other[q];
@@ -3391,6 +3401,17 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
         double *pr = g.part + (size_t)blockIdx.x * kPartW;
         pr[0] = cn; pr[1] = dl; pr[2] = dp2; pr[3] = 0.0; pr[4] = pct; pr[5] = 0.0; pr[6] = 0.0; pr[7] = 0.0;
     }
+}
+
+// PBA's parametrisation at the start of a solve: the caller's (R0, omega) folded into R0 <- exp([omega]x) R0 (cam_lin holds it), omega <- 0
+__global__ void k_cam_rebase(int m, int row_stride, double *__restrict__ cam_a, double *__restrict__ cam_lin, double *__restrict__ R0)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    double *cl = cam_lin + (size_t)j * kCamLin;
+    for (int i = 0; i < 9; ++i) { R0[(size_t)j * 9 + i] = cl[i]; cl[9 + i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    double *a = cam_a + (size_t)j * row_stride;
+    a[3] = 0.0; a[4] = 0.0; a[5] = 0.0;
 }
 
 __global__ void k_rotations(int m, const double *__restrict__ cam_lin, double *__restrict__ R)
@@ -3576,10 +3597,15 @@ void launch_reduce_partials(hipStream_t st, int nrows, const double *part, doubl
 
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const PcgArgs &pa,
                        double *dA, const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
-                       double *cam_lin_new, double *cam_part)
+                       double *cam_lin_new, double *cam_part, double *R0_new)
 {
     hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, pa, dA, camvec, R0, f_fixed,
-                       links, cam_a_new, cam_lin_new, cam_part);
+                       links, cam_a_new, cam_lin_new, cam_part, R0_new);
+}
+
+void launch_cam_rebase(hipStream_t st, int m, int row_stride, double *cam_a, double *cam_lin, double *R0)
+{
+    hipLaunchKernelGGL(k_cam_rebase, dim3((m + 63) / 64), dim3(64), 0, st, m, row_stride, cam_a, cam_lin, R0);
 }
 
 // last stage of the back-substitution's reduction (its first stage first when there are many rows) + the camera-side sums + peek
