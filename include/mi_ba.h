@@ -194,9 +194,9 @@ typedef struct {
     double pcg_persistent;                 /* reduced solves done by the one persistent launch (k_pcg_persist) instead of a launch per iteration */
     double reserved[10];                   /* the struct stays 32 doubles from here on: new figures come out of this tail */
 } mi_ba_timing;
-/* ABI note: the struct grew twice before it got its tail (17 doubles in round 1, 21 in round 2, 32 now).  A caller compiled
- * against an older header passes a smaller struct: it must use mi_ba_get_timing_n with ITS sizeof (at most that many bytes are
- * written); mi_ba_get_timing writes sizeof(mi_ba_timing) of THIS header. */
+/* ABI note: the struct grew twice before it got its tail (17 doubles in round 1, 21 in round 2, 32 now).  mi_ba_get_timing is the
+ * symbol every one of those headers declares, so it only ever writes the 17 doubles they all share (build_ms .. build_index_bytes);
+ * the whole block comes through mi_ba_get_timing_n with the CALLER's sizeof (at most that many bytes are written). */
 int mi_ba_get_timing(const mi_ba_engine *e, mi_ba_timing *t);
 int mi_ba_get_timing_n(const mi_ba_engine *e, void *t, size_t bytes);
 int mi_ba_reset_timing(mi_ba_engine *e);

@@ -78,7 +78,7 @@ def lib() -> C.CDLL:
             "mi_ba_set_point_constraints": [vp, dp, dp], "mi_ba_set_fixed_cameras": [vp, C.c_void_p], "mi_ba_set_fixed_params": [vp, C.c_void_p], "mi_ba_run": [vp, dp], "mi_ba_get_info": [vp, dp],
             "mi_ba_get_trace": [vp, dp, i32], "mi_ba_get_params": [vp, dp, dp], "mi_ba_set_params": [vp, dp, dp],
             "mi_ba_get_rotations": [vp, dp], "mi_ba_debug_linearize": [vp, dbl, dp, dp, dp, dp, dp, dp, dp],
-            "mi_ba_debug_solve": [vp, dbl, dp, dp, dp], "mi_ba_get_timing": [vp, C.POINTER(Timing)],
+            "mi_ba_debug_solve": [vp, dbl, dp, dp, dp], "mi_ba_get_timing": [vp, C.POINTER(Timing)], "mi_ba_get_timing_n": [vp, C.POINTER(Timing), C.c_size_t],
             "mi_ba_comm_init": [vp, C.c_char_p], "mi_ba_comm_unique_id": [C.c_char_p], "mi_ba_comm_info": [vp, C.POINTER(C.c_int)],
             "mi_ba_plan_build": [i32, i32, i64, ip, ip, i32, i32, i32], "mi_ba_plan_build_rows": [i32, i32, i64, ip, ip, i32, i32, i32], "mi_ba_plan_free": [vp],
             "mi_ba_plan_stats": [vp, C.POINTER(i64)], "mi_ba_plan_get": [vp, C.c_char_p, vp, i64],
@@ -259,7 +259,7 @@ class Engine:
 
     def timing(self) -> dict:
         t = Timing()
-        self.L.mi_ba_get_timing(self.h, C.byref(t))
+        self.L.mi_ba_get_timing_n(self.h, C.byref(t), C.sizeof(Timing))
         return t.as_dict()
 
     def reset_timing(self):

@@ -83,7 +83,9 @@ int mi_ba_debug_linearize(mi_ba_engine *h, double mu, double *S, double *E, doub
 { return h ? h->e->debug_linearize(mu, S, E, ea, eb, V, diagU, cost) : MI_BA_ERROR; }
 int mi_ba_debug_solve(mi_ba_engine *h, double mu, double *da, double *db, double *cost_new)
 { return h ? h->e->debug_solve(mu, da, db, cost_new) : MI_BA_ERROR; }
-int mi_ba_get_timing(const mi_ba_engine *h, mi_ba_timing *t) { if (!h || !t) return MI_BA_ERROR; *t = h->e->timing; return 0; }
+// (the symbol the oldest clients bind: they pass the 17-double struct of round 1, so this one never writes more than that -- the
+// fields every version of the header shares; the whole block goes through mi_ba_get_timing_n with the caller's own sizeof)
+int mi_ba_get_timing(const mi_ba_engine *h, mi_ba_timing *t) { if (!h || !t) return MI_BA_ERROR; std::memcpy(t, &h->e->timing, 17 * sizeof(double)); return 0; }
 static_assert(sizeof(mi_ba_timing) == 32 * sizeof(double), "mi_ba_timing keeps its size: take new fields out of reserved[]");
 int mi_ba_get_timing_n(const mi_ba_engine *h, void *t, size_t bytes)
 {

@@ -538,7 +538,10 @@ void Engine::setup_persist()
         if (cap <= 0 || nwg > cap - cap / 8) continue;             // a margin of an eighth of the chip
         const int group = std::max(8, (nwg + kBarMaxGroups - 1) / kBarMaxGroups);
         if (!hipok(d_bar_.alloc(kBarWords), "alloc barrier words") || !hipok(hipMemset(d_bar_.p, 0, kBarWords * sizeof(unsigned long long)), "memset barrier words") ||
-            !hipok(d_win_ptr_.upload(win_ptr), "upload windows") || !hipok(d_win_col_.upload(win_col), "upload windows") || !hipok(d_blk_loc_.upload(blk_loc), "upload windows")) return;
+            !hipok(d_win_ptr_.upload(win_ptr), "upload windows") || !hipok(d_win_col_.upload(win_col), "upload windows") || !hipok(d_blk_loc_.upload(blk_loc), "upload windows")) {
+            err.clear();               // (an opt-in that could not be set up is simply off: prepare() goes on with the launched iteration)
+            return;
+        }
         persist_rows_ = rows; persist_nwg_ = nwg; persist_lds_ = lds; persist_group_ = group;
         persist_ok_ = true;
         if (cfg.verbose && cfg.rank == 0)
@@ -636,7 +639,7 @@ LongArgs Engine::long_args(double mu, double *dB_dev, int part_row0)
     a.cam_lin = d_cam_lin_[cur_].p; a.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; a.pts = d_pts_[cur_].p; a.dA = d_dA_.p;
     a.pt_cw = d_pt_cw_.p; a.pt_cv = d_pt_cv_.p;
     a.rec = d_rec_.p; a.ptout = d_ptout_.p; a.part = d_part_.p;
-    a.pts_new = d_pts_[cur_ ^ 1].p; a.dB = dB_dev; a.mu = mu; a.eps5 = cfg.opts[5];
+    a.pts_new = d_pts_[cur_ ^ 1].p; a.dB = dB_dev; a.mu = mu; a.eps5 = cfg.lm_variant >= 1 ? 0.0 : cfg.opts[5];
     a.nlong = (int)plan_.long_pts.size(); a.m = m_; a.part_row0 = part_row0; a.cfg = model();
     a.scal = scal_();
     return a;
@@ -715,6 +718,11 @@ PeekArgs Engine::peek_args(double mu) const
     k.eps2_sq = cfg.opts[2] * cfg.opts[2]; k.eps3_sq = cfg.opts[3] * cfg.opts[3]; k.eps4_sq = cfg.opts[4] * cfg.opts[4]; k.eps5 = cfg.opts[5];
     k.pl2_inactive = pl2_inactive_; k.itno = itno_; k.mode = cfg.mode; k.stops = cfg.disable_stops ? 0 : 1;
     k.last = itno_ + 1 >= cfg.itmax ? 1 : 0;
+    k.variant = cfg.lm_variant;
+    if (cfg.lm_variant >= 1) {     // PBA's controller: opts[] mean other things there (mi_ba.h), and its cap counts trials
+        k.mu_min = cfg.opts[3]; k.mu_max = cfg.opts[4]; k.d_thr = cfg.opts[2];
+        k.last = trials_ + 1 >= cfg.itmax ? 1 : 0;
+    }
     return k;
 }
 
@@ -861,7 +869,7 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_real_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
-    b.mu = mu; b.eps5 = cfg.opts[5]; b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, backsub_grid()); b.cfg = mc; b.scal = scal_();
+    b.mu = mu; b.eps5 = cfg.lm_variant >= 1 ? 0.0 : cfg.opts[5];   /* (Bundler's rule; under PBA's controller opts[5] is the auto-switch threshold) */ b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, backsub_grid()); b.cfg = mc; b.scal = scal_();
     if (timing_detail >= 2) (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, dB_dev, b.ngrid));
@@ -1013,7 +1021,8 @@ int Engine::step()
             ret = 0;
         } while (false);
         timing.step_ms += now_ms() - t0; timing.steps += 1;
-        return ret;
+        if (stop_) cfg.lm_variant = lm_variant_cfg_;   // (the auto-switch to identity damping belongs to the solve it happened in: the parity hooks
+        return ret;                                    //  and model() read the configured variant again once the solve is over)
     }
     do {
         if (eab_inf_ <= eps1 && stops) { dp_L2_ = 0.0; stop_ = 1; ret = 2; break; }          // :1117-1121

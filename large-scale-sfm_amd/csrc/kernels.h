@@ -205,6 +205,8 @@ struct PeekArgs {
     double c_lag, mu;                                  // the controller's state the scalars do not hold
     double eps2_sq, eps3_sq, eps4_sq, eps5, pl2_inactive;
     int itno, mode, stops, last;                       // last: the iteration cap ends the solve with this trial
+    int variant;                                       // 0: sba's controller; 1, 2: PBA's (accept on any decrease, its damping bounds, its step stop)
+    double mu_min, mu_max, d_thr;                      // PBA: opts[3], opts[4] (0 or variant 2: no upper bound), opts[2]
 };
 void launch_lm_peek(hipStream_t st, double *scal, const PeekArgs &pk, double *spec);
 void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,

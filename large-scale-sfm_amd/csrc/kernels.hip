@@ -3156,6 +3156,10 @@ __global__ __launch_bounds__(256) void k_pcg_persist(const PersistArgs g)
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (live[k] && c == 0) a.x[jr[k] * 8 + r] = x_own[k];
+        // one more round: a workgroup whose bounded spin gave up in the LAST iteration's barrier (just before the generation word
+        // landed) left without storing its rows -- it does not arrive here, the round times out for everybody and the solve is
+        // reported unusable (status 3) instead of workgroup 0 declaring a partly stale x~ final
+        alive = persist_barrier(g.bar, g.group, ++round);
     }
     if (b == 0 && threadIdx.x == 0) {
         a.scal[SC_PCG_ITERS] = (double)iters;
@@ -3555,7 +3559,19 @@ __device__ __forceinline__ void lm_peek(double *__restrict__ s, const PeekArgs &
     const double dL = s[SC_DL_CAMS] + s[SC_DL_PTS], dF = p_eL2 - pdp_eL2;
     const bool solved = s[SC_PCG_FINAL] != 0.0 && s[SC_PCG_STATUS] == 0.0 && s[SC_NOT_PD] == 0.0 && s[SC_SINGULAR] == 0.0;
     double go = 0.0, mu_next = mu;
-    if (solved && isfinite(pdp_eL2) && dL > 0.0 && dF > 0.0) {
+    if (k.variant >= 1) {
+        // PBA's controller (engine.cpp step(), SparseBundleCPU.cpp:3892-3948): accept on any decrease, the damping update with its bounds --
+        // the same arithmetic as the host's, so that the host finds ITS next damping in spec[1] and adopts the work enqueued ahead
+        if (solved && isfinite(pdp_eL2) && dF > 0.0) {
+            const double dl = dL > 0.0 ? dL : 0.001 * dF;
+            double tmp = 2.0 * dF / dl - 1.0;
+            tmp = 1.0 - tmp * tmp * tmp;
+            mu_next = mu * ((tmp >= 0.3333333334) ? tmp : 0.3333333334);
+            if (mu_next < k.mu_min) mu_next = k.mu_min; else if (k.variant == 1 && k.mu_max > 0.0 && mu_next > k.mu_max) mu_next = k.mu_max;
+            go = k.last ? 0.0 : 1.0;
+            if (k.stops && sqrt(s[SC_DP2_CAMS] + s[SC_DP2_PTS]) <= k.d_thr) go = 0.0;      // "quit on too small change"
+        }
+    } else if (solved && isfinite(pdp_eL2) && dL > 0.0 && dF > 0.0) {
         double tmp = 2.0 * dF / dL - 1.0;
         tmp = 1.0 - tmp * tmp * tmp;
         mu_next = mu * ((tmp >= 0.3333333334) ? tmp : 0.3333333334);
