@@ -8,7 +8,7 @@ cur = db.cursor()
 names = dict(cur.execute("select id, kernel_name from rocpd_info_kernel_symbol").fetchall())
 rows = sorted(cur.execute("select start, end, kernel_id from rocpd_kernel_dispatch").fetchall())
 short = lambda n: n.split("(")[0].replace("miba::", "")[:60]
-starts = [i for i, (s, e, k) in enumerate(rows) if "k_build" in names.get(k, "") and "ELb1E" in names.get(k, "")]
+starts = [i for i, (s, e, k) in enumerate(rows) if "k_build" in names.get(k, "")]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 a, b = starts[which], starts[which + 1]
 t0 = rows[a][0]
