@@ -160,6 +160,7 @@ int64_t mi_ba_plan_get(const mi_ba_plan *p, const char *name, void *out, int64_t
     I32("tile_batch", tile_batch); I32("tile_slot", tile_slot); I32("slot_gblk", slot_gblk); I32("tile_cslot", tile_cslot);
     I32("cslot_cam", cslot_cam); I32("up_row", up_row); I32("up_col", up_col); I32("bsr_row", bsr_row); I32("bsr_col", bsr_col);
     I32("bsr_src", bsr_src); I32("pt_obs", pt_obs); I32("long_pts", long_pts);
+    I32("bs_batch_obs", bs_batch_obs); I32("bs_batch_pt", bs_batch_pt); I32("bs_batch_obs_end", bs_batch_obs_end); I32("bs_batch_pt_end", bs_batch_pt_end);
     I32("obs_rec", obs_rec); I32("rec_cam", rec_cam); I32("wk_blk", wk_blk); I32("wk_diag_cam", wk_diag_cam); I32("wk_diag_blk", wk_diag_blk);
 #undef I32
     if (k == "obs_src") return copy_out(pl.obs_src, (int64_t *)out, cap);

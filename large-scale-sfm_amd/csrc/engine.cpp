@@ -310,7 +310,7 @@ int Engine::prepare()
     UP(d_tile_batch_, pl.tile_batch); UP(d_tile_slot_, pl.tile_slot); UP(d_tile_cslot_, pl.tile_cslot); UP(d_tile_mode_, pl.tile_mode);
     UP(d_slot_gblk_, pl.slot_gblk); UP(d_cslot_cam_, pl.cslot_cam);
     UP(d_batch_obs_, pl.batch_obs); UP(d_batch_pt_, pl.batch_pt); UP(d_pt_obs_, pl.pt_obs);
-    UP(d_bs_batch_obs_, pl.bs_batch_obs); UP(d_bs_batch_pt_, pl.bs_batch_pt);
+    UP(d_bs_batch_obs_, pl.bs_batch_obs); UP(d_bs_batch_pt_, pl.bs_batch_pt); UP(d_bs_batch_obs_end_, pl.bs_batch_obs_end); UP(d_bs_batch_pt_end_, pl.bs_batch_pt_end);
     UP(d_obs_cslot_, pl.obs_cslot);                              // (obs_cam, obs_pt, obs_xy: the early upload above)
     UP(d_pair_, pl.pair);
     UP(d_obs_rec_, pl.obs_rec); UP(d_rec_cam_, pl.rec_cam); UP(d_wk_blk_, pl.wk_blk); UP(d_rpair_, pl.rpair);
@@ -468,7 +468,7 @@ int Engine::prepare()
         !hipok(d_E_.alloc((size_t)mv_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)mv_ * kCP), "alloc dA") ||
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)mv_ * kCP * 8), "alloc pcg") ||
         !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)mv_), "alloc rz/pq") ||
-        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGridMax) + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
+        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGridMax) + pl.ntile() + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
         !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage") ||
         !hipok(d_cam_part_.alloc((size_t)((mv_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
         !hipok(d_cam_part2_.alloc((size_t)((m_ + 63) / 64 + 1) * kPartW), "alloc camera partials"))
@@ -866,15 +866,20 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     launch_cam_update(st_, m_, cnp, mc, d_fixed_.p, mu, d_cam_a_[cur_].p, upd_p_, d_dA_.p, camvec_(), d_R0_[cur_].p, d_ff_.p, links_,
                       d_cam_a_[cur_ ^ 1].p, d_cam_lin_[cur_ ^ 1].p, d_cam_part2_.p, mc.pba_update ? d_R0_[cur_ ^ 1].p : nullptr);
     BacksubArgs b{};
-    b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
+    b.batch_obs = d_bs_batch_obs_.p; b.batch_pt = d_bs_batch_pt_.p; b.batch_obs_end = d_bs_batch_obs_end_.p; b.batch_pt_end = d_bs_batch_pt_end_.p;
+    b.tile_mode = d_tile_mode_.p; b.tile_batch = d_tile_batch_.p; b.tile_cslot = d_tile_cslot_.p; b.cslot_cam = d_cslot_cam_.p;
+    b.bld_batch_obs = d_batch_obs_.p; b.bld_batch_pt = d_batch_pt_.p;
+    b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_real_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
-    b.mu = mu; b.eps5 = cfg.lm_variant >= 1 ? 0.0 : cfg.opts[5];   /* (Bundler's rule; under PBA's controller opts[5] is the auto-switch threshold) */ b.nbatch = (int)pl.bs_batch_obs.size() - 1; b.ngrid = std::min(b.nbatch, backsub_grid()); b.cfg = mc; b.scal = scal_();
+    b.mu = mu; b.eps5 = cfg.lm_variant >= 1 ? 0.0 : cfg.opts[5];   /* (Bundler's rule; under PBA's controller opts[5] is the auto-switch threshold) */ b.nbatch = (int)pl.bs_batch_obs.size(); b.ngrid = std::min(b.nbatch, backsub_grid()); b.cfg = mc; b.scal = scal_();
+    const int nlong = (int)pl.long_pts.size();
+    b.uni_ntile = pl.bs_uni ? pl.ntile_lds : 0; b.uni_row0 = b.ngrid + nlong;     // partial rows: k_backsub's | the long tracks' | the uniform tiles'
     if (timing_detail >= 2) (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, dB_dev, b.ngrid));
     if (timing_detail >= 2) (void)hipEventRecord(ev_[5], st_);
-    launch_reduce_final(st_, b.ngrid + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
+    launch_reduce_final(st_, b.ngrid + nlong + b.uni_ntile, d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
                         cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT,
                         m_, mv_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, peek_args(mu));
     if (!allreduce2()) return false;

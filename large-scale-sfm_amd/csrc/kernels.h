@@ -95,6 +95,7 @@ struct BuildArgs {
 
 struct BacksubArgs {
     const int *batch_obs, *batch_pt, *pt_obs, *obs_cam, *obs_pt;
+    const int *batch_obs_end, *batch_pt_end;   // batch b = observations [batch_obs[b], batch_obs_end[b]), points [batch_pt[b], batch_pt_end[b]): runs of consecutive points with gaps between batches (plan.h bs_uni)
     const unsigned char *cam_fixed;
     const double2 *obs_xy;
     const double *cam_lin, *cam_lin_new, *pts, *ptout, *dA;
@@ -103,6 +104,10 @@ struct BacksubArgs {
     int nbatch, ngrid;
     ModelCfg cfg;
     const double *scal;                     // SC_PCG_FINAL == 0: the reduced solve has not finished, nothing to do yet
+    // k_backsub_uni: the tiles of one camera set (plan.h mode 4) -- the build's tile tables; their points are not in batch_obs / batch_pt above
+    const unsigned char *tile_mode;
+    const int *tile_batch, *tile_cslot, *cslot_cam, *bld_batch_obs, *bld_batch_pt;
+    int uni_ntile, uni_row0;                // workgroups (= LDS tiles of the plan; 0: no uniform tile), first partial row of theirs
 };
 
 // long tracks (> 64 views): one workgroup per point; the records go where the row tiles' go

@@ -83,6 +83,28 @@ __device__ __forceinline__ void ladd(double *p, double v)                       
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// LDS-DMA (global_load_lds_*): a wave instruction that moves 16 (or 4) bytes per active lane from the lane's global address straight
+// into LDS at lds_dst + lane * 16 (or 4) -- no destination registers, counted in vmcnt.  lds_dst is wave-uniform.  Through inline asm:
+// with the builtin the compiler drains the transfers (s_waitcnt vmcnt(0)) in front of the next LDS read of ANY array, which exposes
+// the HBM latency a prefetch is there to hide; the kernels wait for their transfers themselves.  (M0 is the compiler's: saved, put back.)
+__device__ __forceinline__ void glds_b128(const void *src, const void *lds_dst)
+{
+    const unsigned m0v = (unsigned)(size_t)lds_dst;       // LDS byte address: the low 32 bits of the generic pointer
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+}
+__device__ __forceinline__ void glds_b32(const void *src, const void *lds_dst)
+{
+    const unsigned m0v = (unsigned)(size_t)lds_dst;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
+}
+__device__ __forceinline__ void wait_lds_dma()            // every transfer (and store) this wave has issued has landed
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ------------------------------------------------------------------------------------------
 // camera model: projection (sfm.c:303-374) and its analytic Jacobian (the reference uses forward
 // differences, sba_levmar_wrap.c:163-259; the analytic form agrees to ~1e-6 relative, see
@@ -1316,18 +1338,10 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
     auto stream_batch = [&](int kk) {
         int lv = lane; asm volatile("" : "+v"(lv));       // (opaque: the address arithmetic is redone at every call, not kept in registers through the loop)
         const int p1 = tp0 + kk * PB, np1 = min(PB, tp1 - p1);
-        // (inline asm: through the builtin the compiler drains the transfers -- s_waitcnt vmcnt(0) -- in front of the next LDS read of
-        // any array, i.e. at the top of the pair phase, and the HBM latency is exposed; the kernel waits for them itself, in phase 1)
-        auto glds = [&](const void *src, const void *lds_dst, bool wide) {
-            const unsigned m0v = (unsigned)(size_t)lds_dst;   // LDS byte address: the low 32 bits of the generic pointer
-            unsigned keep;                                    // (M0 is the compiler's: saved and put back)
-            if (wide) asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
-            else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(m0v) : "memory");
-        };
         const unsigned *src = reinterpret_cast<const unsigned *>(g.pts + 3 * (size_t)p1);
-        if (lv < np1 * D) glds(g.obs_xy + (to0 + kk * PB * D + lv), sXY, true);
-        if (lv < 6 * np1) glds(src + lv, sX, false);
-        if (lv + kWave < 6 * np1) glds(src + kWave + lv, reinterpret_cast<unsigned *>(sX) + kWave, false);
+        if (lv < np1 * D) glds_b128(g.obs_xy + (to0 + kk * PB * D + lv), sXY);
+        if (lv < 6 * np1) glds_b32(src + lv, sX);
+        if (lv + kWave < 6 * np1) glds_b32(src + kWave + lv, reinterpret_cast<unsigned *>(sX) + kWave);
     };
     double ea[CNP], Ev[CNP];                                // this lane's share of its camera's e_a and E, summed over the tile's batches
 #pragma unroll
@@ -1345,8 +1359,7 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
         double pcw = 0.0, pcd[3] = { 0.0, 0.0, 0.0 };
         double *const row = sR + lane * SR;
         // ---- phase 1: residual and Jacobian of the lane's observation
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the batch's streams have landed (issued a pair phase ago)
-        __builtin_amdgcn_wave_barrier();
+        wait_lds_dma();                                    // the batch's streams have landed (issued a pair phase ago)
         const double2 xy = active ? sXY[lane] : make_double2(0.0, 0.0);
         double X[3] = { 0.0, 0.0, 0.0 };
         if (active) { X[0] = sX[3 * lp]; X[1] = sX[3 * lp + 1]; X[2] = sX[3 * lp + 2]; }
@@ -3279,8 +3292,8 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
     int n_o0 = 0, n_nob = 0, n_p0 = 0, n_npt = 0, n_j = 0, n_ip = 0;
     double2 n_xy = make_double2(0.0, 0.0);
     auto load_stream = [&](int b) {
-        n_o0 = g.batch_obs[b]; n_nob = g.batch_obs[b + 1] - n_o0;
-        n_p0 = g.batch_pt[b]; n_npt = g.batch_pt[b + 1] - n_p0;
+        n_o0 = g.batch_obs[b]; n_nob = g.batch_obs_end[b] - n_o0;
+        n_p0 = g.batch_pt[b]; n_npt = g.batch_pt_end[b] - n_p0;
         n_j = 0; n_ip = n_p0; n_xy = make_double2(0.0, 0.0);
         if (lane < n_nob) { const int o = n_o0 + lane; n_j = g.obs_cam[o]; n_ip = g.obs_pt[o]; n_xy = g.obs_xy[o]; }
     };
@@ -3405,6 +3418,181 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
         double *pr = g.part + (size_t)blockIdx.x * kPartW;
         pr[0] = cn; pr[1] = dl; pr[2] = dp2; pr[3] = 0.0; pr[4] = pct; pr[5] = 0.0; pr[6] = 0.0; pr[7] = 0.0;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_backsub_uni: the back-substitution of a tile of ONE camera set (plan.h tile mode 4; the planner keeps those points out of
+// k_backsub's batches).  Same arithmetic as k_backsub; what the uniform shape buys here is OCCUPANCY: k_backsub keeps a lane's camera --
+// its record at p, its record at p + dp and its update, 33 doubles -- in registers across batches (144-160 VGPRs, three wavefronts per
+// SIMD), and its batches are chains of dependent latency (LDS round trips, two reciprocal chains: ~5 600 cycles for ~1 100 of issue)
+// that three wavefronts do not cover.  Here the tile's <= 10 cameras sit in an LDS table, built once per tile; a lane's state is its
+// lane arithmetic and four accumulators, and five wavefronts fit a SIMD.  The measurement and point streams come by LDS-DMA one
+// batch ahead (k_build_uni's), the ptout rows straight into the registers of the (point, component) lanes at the batch's top.
+// ------------------------------------------------------------------------------------------
+template <int CNP, bool FULL, bool DAMP>
+__global__ __launch_bounds__(64, 4) void k_backsub_uni   /* (five: 96 VGPRs with two spilled -- scratch reloads among the transfers -- 0.154 ms against 0.116) */(const BacksubArgs g)
+{
+    const int tile = blockIdx.x;
+    double *const prow = g.part + (size_t)(g.uni_row0 + tile) * kPartW;
+    if (g.scal[SC_PCG_FINAL] == 0.0) return;   // launched ahead of the host's look at the reduced solve (engine.cpp solve_phase)
+    const int lane = threadIdx.x;
+    if (g.tile_mode[tile] != 4) {               // not a uniform tile: its points are k_backsub's; a row of zeros for the reduction
+        if (lane < kPartW) prow[lane] = 0.0;
+        return;
+    }
+    constexpr int kMaxD = kMaxViewsLds, kMaxPts = kWave / kUniMinViews;
+    constexpr int SCL = 18;                      // a compact camera record: R (9) - c (3) f k1 k2 at 10..15; 18 doubles apart (distinct banks)
+    constexpr int SCD = 10;                      // the camera's update (CamDelta, 9 doubles)
+    __shared__ __attribute__((aligned(16))) double sCl[kMaxD * SCL], sCln[kMaxD * SCL], sCd[kMaxD * SCD];
+    __shared__ __attribute__((aligned(16))) double2 sXY[2][kWave];
+    __shared__ __attribute__((aligned(16))) double sPX[2][kMaxPts * 3];
+    __shared__ double sT[kWave * 3], sXn[kMaxPts * 3];
+    __shared__ double sD[DAMP ? kWave * 3 : 1];
+    __shared__ int sFix[kMaxD];
+    const ModelCfg cfg = g.cfg;
+    const int D = g.tile_cslot[tile + 1] - g.tile_cslot[tile];
+    const int PB = kWave / D;
+    const int lp = lane / D, cs = lane - lp * D;
+    // ---- the tile's camera table: lane c prepares camera c (record at p, record at p + dp, the update's per-camera vectors)
+    if (lane < D) {
+        const int j = g.cslot_cam[g.tile_cslot[tile] + lane];
+        const double *cl = g.cam_lin + (size_t)j * kCamLin, *cn = g.cam_lin_new + (size_t)j * kCamLin;
+        double rec[kCamLin], da[9];
+#pragma unroll
+        for (int k = 0; k < kCamLin; ++k) rec[k] = cl[k];
+        const double *dj = g.dA + (size_t)(cfg.split ? 2 * j : j) * kCP;
+#pragma unroll
+        for (int k = 0; k < kCP; ++k) da[k] = dj[k];
+        da[8] = (CNP > kCP && cfg.split) ? g.dA[(size_t)(2 * j + 1) * kCP] : 0.0;
+        const bool fx = g.cam_fixed[j] != 0;
+        const CamDelta cd = cam_delta(cfg, rec, da, fx, FULL);
+        double *o = sCl + lane * SCL, *on = sCln + lane * SCL, *od = sCd + lane * SCD;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { o[k] = rec[k]; on[k] = cn[k]; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { o[10 + k] = rec[18 + k]; on[10 + k] = cn[18 + k]; }
+        od[0] = cd.v0[0]; od[1] = cd.v0[1]; od[2] = cd.v0[2]; od[3] = cd.u[0]; od[4] = cd.u[1]; od[5] = cd.u[2]; od[6] = cd.df; od[7] = cd.dk; od[8] = cd.dk2;
+        sFix[lane] = fx;
+    }
+    const int b_begin = g.tile_batch[tile], b_end = g.tile_batch[tile + 1];
+    const int tp0 = g.bld_batch_pt[b_begin], tp1 = g.bld_batch_pt[b_end], to0 = g.bld_batch_obs[b_begin];
+    const int nbatch = b_end - b_begin;
+    auto stream_batch = [&](int kk, int buf) {
+        int lv = lane; asm volatile("" : "+v"(lv));
+        const int p1 = tp0 + kk * PB, np1 = min(PB, tp1 - p1);
+        const unsigned *src = reinterpret_cast<const unsigned *>(g.pts + 3 * (size_t)p1);
+        if (lv < np1 * D) glds_b128(g.obs_xy + (to0 + kk * PB * D + lv), sXY[buf]);
+        if (lv < 6 * np1) glds_b32(src + lv, sPX[buf]);
+        if (lv + kWave < 6 * np1) glds_b32(src + kWave + lv, reinterpret_cast<unsigned *>(sPX[buf]) + kWave);
+    };
+    double cn = 0.0, pct = 0.0, dl = 0.0, dp2 = 0.0;
+    // the lane as (point, component) of the point phase: four lanes per point
+    const int qp = lane >> 2, qc = lane & 3;
+    const int c3 = qc < 3 ? qc : 0;
+    const int vi0 = c3 == 0 ? 0 : c3, vi1 = c3 == 0 ? 1 : (c3 == 1 ? 3 : 4), vi2 = c3 == 0 ? 2 : (c3 == 1 ? 4 : 5);   // row c of the packed inverse (00 01 02 11 12 22)
+    // Memory waits in the loop: ONE full drain at a batch's top (the streams issued in the middle of the batch before have landed), and the
+    // compiler's own wait for the five ptout loads of the point lanes, which are ordinary loads issued at the top and consumed behind the
+    // first hand-off -- at a moment when no transfer is in flight, because the next batch's are issued only AFTER the point phase.
+    // (LDS-DMA transfers and ordinary loads are not retired in their common issue order, so a counted s_waitcnt cannot separate them: a
+    // version that waited vmcnt(5) for "the transfers, but not the five loads behind them" read stale LDS; and loads prefetched into
+    // registers by inline asm were copied by the compiler BEFORE the hand-written wait.)
+    stream_batch(0, 0);
+    wave_lds_sync();   // the camera table is in place
+    for (int k = 0; k < nbatch; ++k) {
+        const int buf = k & 1;
+        const int p0 = tp0 + k * PB, npt = min(PB, tp1 - p0);
+        const bool active = lp < npt;
+        const bool on = qp < npt && qc < 3;
+        wait_lds_dma();
+        double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0, ph = 0.0, pe = 0.0;
+        if (on) {
+            const double *po = g.ptout + (size_t)(p0 + qp) * kPtOut;
+            pv0 = po[vi0]; pv1 = po[vi1]; pv2 = po[vi2]; ph = po[6 + c3]; pe = po[9 + c3];
+        }
+        double2 xy = make_double2(0.0, 0.0);
+        double e[2] = { 0.0, 0.0 };
+        if (active) {
+            xy = sXY[buf][lane];
+            const double X[3] = { sPX[buf][3 * lp], sPX[buf][3 * lp + 1], sPX[buf][3 * lp + 2] };
+            // backsub_obs wants the record in cam_lin's layout: R at 0..8, c f k1 k2 at 18..23 -- the compact one is read through a shim
+            double cl[kCamLin];
+            const double *o = sCl + cs * SCL;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) cl[i] = o[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) cl[18 + i] = o[10 + i];
+            CamDelta cd;
+            const double *od = sCd + cs * SCD;
+            cd.v0[0] = od[0]; cd.v0[1] = od[1]; cd.v0[2] = od[2]; cd.u[0] = od[3]; cd.u[1] = od[4]; cd.u[2] = od[5]; cd.df = od[6]; cd.dk = od[7]; cd.dk2 = od[8];
+            double t[3], bd[3];
+            backsub_obs<CNP, FULL>(cfg, cl, cd, X, xy, e, t, bd);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sT[lane * 3 + c] = t[c];
+            if constexpr (DAMP) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sD[lane * 3 + c] = bd[c];
+            }
+        }
+        wave_lds_sync();
+        // ---- the point's update on lanes (point, component): the point's D observations are lanes qp D .. qp D + D - 1
+        {
+            double tc0 = 0.0, tc1 = 0.0, Dc = 1.0, pX = 0.0;
+            if (on) {
+                const double *pt = sT + qp * D * 3 + c3;
+#pragma unroll
+                for (int v = 0; v < kMaxViewsLds; v += 2) {
+                    if (v < D) tc0 += pt[v * 3];
+                    if (v + 1 < D) tc1 += pt[v * 3 + 3];
+                }
+                if constexpr (DAMP) {
+                    Dc = 0.0;
+                    const double *pd = sD + qp * D * 3 + c3;
+                    for (int v = 0; v < D; ++v) Dc += pd[v * 3];
+                }
+                pX = sPX[buf][3 * qp + c3];
+            }
+            const double tc = tc0 + tc1;
+            const double t0 = dpp_move<0x00>(tc), t1 = dpp_move<0x55>(tc), t2 = dpp_move<0xAA>(tc);   // quad_perm [0,0,0,0], [1,1,1,1], [2,2,2,2]
+            if (on) {
+                const double d = ph - (pv0 * t0 + pv1 * t1 + pv2 * t2);
+                const double Xn = pX + d;
+                const size_t ix = 3 * (size_t)(p0 + qp) + c3;
+                g.pts_new[ix] = Xn;
+                if (g.dB) g.dB[ix] = d;
+                sXn[qp * 3 + c3] = Xn;
+                dl += d * (g.mu * Dc * d + pe);
+                dp2 += Dc * d * d;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < nbatch) stream_batch(k + 1, buf ^ 1);   // (behind the ptout loads' wait: see above)
+        __builtin_amdgcn_sched_barrier(0);
+        wave_lds_sync();
+        if (active) {
+            const double Xn[3] = { sXn[lp * 3], sXn[lp * 3 + 1], sXn[lp * 3 + 2] };
+            const double *cln = sCln + cs * SCL;
+            double q[3];
+            if (cfg.explicit_centers) {
+                const double d0 = Xn[0] - cln[10], d1 = Xn[1] - cln[11], d2 = Xn[2] - cln[12];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) q[r] = cln[3 * r] * d0 + cln[3 * r + 1] * d1 + cln[3 * r + 2] * d2;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) q[r] = cln[3 * r] * Xn[0] + cln[3 * r + 1] * Xn[1] + cln[3 * r + 2] * Xn[2] + cln[10 + r];
+            }
+            const double iz = fast_rcp(q[2]), mx = q[0] * iz, my = q[1] * iz, r2 = mx * mx + my * my;
+            const bool md = FULL && cfg.undistort == 2;
+            const double gg = cfg.proj_sign * cln[13] * ((!FULL || md) ? 1.0 : 1.0 + cln[14] * r2 + cln[15] * r2 * r2);
+            double en0 = xy.x - gg * mx, en1 = xy.y - gg * my;
+            if (md) { const double kk = cln[14] * (xy.x * xy.x + xy.y * xy.y); en0 = fma(kk, xy.x, en0); en1 = fma(kk, xy.y, en1); }
+            cn += en0 * en0 + en1 * en1;
+            pct = fmax(pct, fmax(pct_change_flag(e[0], en0, g.eps5), pct_change_flag(e[1], en1, g.eps5)));
+        }
+        wave_lds_sync();
+    }
+    wait_lds_dma();
+    cn = wave_sum(cn); dl = wave_sum(dl); dp2 = wave_sum(dp2); pct = wave_max(pct);
+    if (lane == 0) { prow[0] = cn; prow[1] = dl; prow[2] = dp2; prow[3] = 0.0; prow[4] = pct; prow[5] = 0.0; prow[6] = 0.0; prow[7] = 0.0; }
 }
 
 // PBA's parametrisation at the start of a solve: the caller's (R0, omega) folded into R0 <- exp([omega]x) R0 (cam_lin holds it), omega <- 0
@@ -3641,10 +3829,22 @@ void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, dou
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, st, a);
 }
 
+template <int CNP, bool FULL>
+static void launch_backsub_uni_t(hipStream_t st, const BacksubArgs &a)
+{
+    if (a.cfg.damp_diag) hipLaunchKernelGGL((k_backsub_uni<CNP, FULL, true>), dim3(a.uni_ntile), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_backsub_uni<CNP, FULL, false>), dim3(a.uni_ntile), dim3(64), 0, st, a);
+}
+
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
 {
-    if (a.nbatch <= 0) return;
     const bool full = a.cfg.undistort != 0;
+    if (a.uni_ntile > 0 && cnp <= 8) {       // the tiles of one camera set (plan.h mode 4): their own kernel, their own partial rows
+        if (cnp == 8) { if (full) launch_backsub_uni_t<8, true>(st, a); else launch_backsub_uni_t<8, false>(st, a); }
+        else if (cnp == 7) { if (full) launch_backsub_uni_t<7, true>(st, a); else launch_backsub_uni_t<7, false>(st, a); }
+        else { if (full) launch_backsub_uni_t<6, true>(st, a); else launch_backsub_uni_t<6, false>(st, a); }
+    }
+    if (a.nbatch <= 0) return;
     if (cnp == 9) { hipLaunchKernelGGL((k_backsub<9, true>), dim3(a.ngrid), dim3(64), 0, st, a); return; }
     if (cnp == 8) { if (full) hipLaunchKernelGGL((k_backsub<8, true>), dim3(a.ngrid), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_backsub<8, false>), dim3(a.ngrid), dim3(64), 0, st, a); }
     else if (cnp == 7) { if (full) hipLaunchKernelGGL((k_backsub<7, true>), dim3(a.ngrid), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_backsub<7, false>), dim3(a.ngrid), dim3(64), 0, st, a); }

@@ -619,15 +619,33 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     // build look like (a tile boundary closes a build batch; on scenes with ever-changing camera sets that leaves one
     // point per batch, and k_backsub has no use for tiles)
     {
-        pl.bs_batch_obs.assign(1, 0); pl.bs_batch_pt.assign(1, 0);
+        // The points of uniform tiles (mode 4) are k_backsub_uni's, tile by tile: k_backsub's batches leave them out.  A batch is a run of
+        // CONSECUTIVE points, so a skipped range closes the batch being filled.  (MI_BA_UNI_BS=0: every point to k_backsub -- probes.)
+        const char *ub = std::getenv("MI_BA_UNI_BS");
+        pl.bs_uni = pl.ntile_uni > 0 && !(ub && ub[0] == '0');
+        std::vector<uint8_t> in_uni(npl, 0);
+        if (pl.bs_uni)
+            for (int tl = 0; tl < pl.ntile_lds; ++tl)
+                if (pl.tile_mode[tl] == 4)
+                    for (int q = pl.batch_pt[pl.tile_batch[tl]]; q < pl.batch_pt[pl.tile_batch[tl + 1]]; ++q) in_uni[q] = 1;
+        pl.bs_batch_obs.clear(); pl.bs_batch_pt.clear();
+        pl.bs_batch_obs_end.clear(); pl.bs_batch_pt_end.clear();
         const int nshort = npl - (int)pl.long_pts.size();      // long points come last and have their own kernels
-        int cur = 0, pts = 0;
+        int cur = 0, pts = 0, first = -1;
+        auto close = [&](int t_end) {
+            if (first < 0) return;
+            pl.bs_batch_obs.push_back(pl.pt_obs[first]); pl.bs_batch_pt.push_back(first);
+            pl.bs_batch_obs_end.push_back(pl.pt_obs[t_end]); pl.bs_batch_pt_end.push_back(t_end);
+            first = -1; cur = 0; pts = 0;
+        };
         for (int t2 = 0; t2 < nshort; ++t2) {
+            if (in_uni[t2]) { close(t2); continue; }
             const int d = pl.pt_obs[t2 + 1] - pl.pt_obs[t2];
-            if (cur + d > kWave || pts >= kMaxPtsBatch) { pl.bs_batch_obs.push_back(pl.pt_obs[t2]); pl.bs_batch_pt.push_back(t2); cur = 0; pts = 0; }
+            if (cur + d > kWave || pts >= kMaxPtsBatch) close(t2);
+            if (first < 0) first = t2;
             cur += d; ++pts;
         }
-        if (cur) { pl.bs_batch_obs.push_back(pl.pt_obs[nshort]); pl.bs_batch_pt.push_back(nshort); }
+        close(nshort);
     }
     stage("back-substitution batches");
     // ---- row path: records camera-major (points ascending inside a camera), and for every block of S the list of its

@@ -89,7 +89,9 @@ struct Plan {
     uvector<int64_t> obs_src;                        // original observation index
     uvector<uint8_t> obs_cslot;                      // tile-local camera slot (LDS tiles)
     std::vector<int> batch_obs, batch_pt;            // nbatch+1
-    std::vector<int> bs_batch_obs, bs_batch_pt;      // batches of k_backsub (same points, packed regardless of tiles)
+    std::vector<int> bs_batch_obs, bs_batch_pt;      // batches of k_backsub: first observation / first point of batch b (the short points that are not in a
+    std::vector<int> bs_batch_obs_end, bs_batch_pt_end; // uniform tile, packed regardless of the build's tiles), and one past its last
+    bool bs_uni = false;                             // the uniform tiles' points go to k_backsub_uni instead (tile by tile)
     std::vector<int64_t> batch_pair;                 // nbatch+1: first pair entry of the batch | rounds << 48 (batches of one camera set share entries)
     std::vector<int> tile_batch, tile_slot, tile_cslot; // ntile+1
     std::vector<uint8_t> tile_mode;                  // 1 register-accumulated blocks, 2 blocks summed in an LDS table, 3 one camera set: blocks on the

@@ -443,6 +443,38 @@ def test_plan_tables_with_uniform_tiles(monkeypatch):
     assert not (pkg("capi").Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam).get("tile_mode") == 4).any()
 
 
+def test_back_substitution_batches_and_uniform_tiles_partition_the_points(monkeypatch):
+    """k_backsub walks the plan's bs batches (runs of consecutive points, <= 64 observations, <= 32 points), k_backsub_uni the tiles of one
+    camera set (mode 4): together they cover every short point exactly once; MI_BA_UNI_BS=0 hands every point to k_backsub"""
+    scene = pkg("scene")
+    rng = np.random.default_rng(5)
+    L = np.minimum(2 + rng.geometric(0.3, 3000), 12)
+    cases = [scene.make_scene("x", m=24, n=2400, d=7, seed=107, strides=(1,)), scene.make_scene("C1"),
+             scene.make_scene("x", m=40, n=3000, d=12, seed=9, strides=(1, 2), track_len=L)]
+    for sc in cases:
+        for env in (None, "0"):
+            if env is None:
+                monkeypatch.delenv("MI_BA_UNI_BS", raising=False)
+            else:
+                monkeypatch.setenv("MI_BA_UNI_BS", env)
+            pl = pkg("capi").Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam)
+            st = pl.stats()
+            b0, b1, o0, o1 = (pl.get(k) for k in ("bs_batch_pt", "bs_batch_pt_end", "bs_batch_obs", "bs_batch_obs_end"))
+            pt_obs, tm, tb, bp = pl.get("pt_obs"), pl.get("tile_mode"), pl.get("tile_batch"), pl.get("batch_pt")
+            nshort = st["npts_local"] - st["nlong"]
+            seen = np.zeros(st["npts_local"], int)
+            for k in range(len(b0)):
+                assert 0 < b1[k] - b0[k] <= 32 and 0 < o1[k] - o0[k] <= 64 and o0[k] == pt_obs[b0[k]] and o1[k] == pt_obs[b1[k]]
+                seen[b0[k]:b1[k]] += 1
+            nuni = 0
+            if env is None:
+                for t in np.where(tm == 4)[0]:
+                    seen[bp[tb[t]]:bp[tb[t + 1]]] += 1
+                    nuni += 1
+            assert np.all(seen[:nshort] == 1) and np.all(seen[nshort:] == 0)
+            assert (nuni > 0) == (env is None and (tm == 4).any())
+
+
 def test_plan_tables_ragged_scene():
     """track lengths 1..20 (register tiles and row tiles), tiny tile budget"""
     scene = pkg("scene")
