@@ -650,7 +650,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
 {
     const Plan &pl = plan_;
     const ModelCfg mc = model();
-    if (!hipok(hipMemsetAsync(d_acc_.p, 0, d_acc_.n * sizeof(double), st_), "memset acc")) return false;
+    launch_zero(st_, d_acc_.p, d_acc_.n);
     // the camera records of the current estimate: after an accepted trial they are the ones k_cam_update wrote for the trial point
     if (!cam_lin_valid_) {
         launch_cam_prep(st_, m_, cnp, mc, d_cam_a_[cur_].p, d_R0_[cur_].p, d_ff_.p, d_cam_lin_[cur_].p);

@@ -185,6 +185,7 @@ struct PersistArgs {
 int pcg_persist_capacity(size_t lds_bytes);                                    // co-resident workgroups at that much dynamic LDS, 0 = cannot run
 bool launch_pcg_persist(hipStream_t st, const PersistArgs &g, int nwg, size_t lds_bytes);   // false: the cooperative launch was refused
 
+void launch_zero(hipStream_t st, double *p, size_t n);   // n doubles to zero (p 16-byte aligned)
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
                      const double *f_fixed, double *cam_lin);
 void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const BuildArgs &a);

@@ -9,6 +9,7 @@
 // accumulation is by f64 atomics into zero-initialised HBM buffers only.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace miba {
@@ -3615,6 +3616,22 @@ __global__ void k_rotations(int m, const double *__restrict__ cam_lin, double *_
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
+// the accumulation buffer [S_up | camvec | scal] back to zero before a linearisation: an ordinary launch in the engine's stream
+// (hipMemsetAsync's fill kernel came with ~6 us of idle GPU in front of it in every trial: profiles/r04_trial_timeline_C3.txt)
+__global__ __launch_bounds__(256) void k_zero(double2 *__restrict__ p, size_t n2, double *__restrict__ tail, int ntail)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = i; q < n2; q += stride) p[q] = make_double2(0.0, 0.0);
+    if (i < (size_t)ntail) tail[i] = 0.0;
+}
+void launch_zero(hipStream_t st, double *p, size_t n)
+{
+    if (n == 0) return;
+    const size_t n2 = n / 2;
+    const int grid = (int)std::min<size_t>((n2 + 255) / 256 + 1, 4096);
+    hipLaunchKernelGGL(k_zero, dim3(grid), dim3(256), 0, st, reinterpret_cast<double2 *>(p), n2, p + 2 * n2, (int)(n - 2 * n2));
+}
+
 void launch_cam_prep(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const double *cam_a, const double *R0,
                      const double *f_fixed, double *cam_lin)
 {
