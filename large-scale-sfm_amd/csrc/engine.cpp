@@ -308,6 +308,9 @@ int Engine::prepare()
     const Plan &pl = plan_;
 #define UP(buf, vec) if (!hipok((buf).upload(vec), "upload " #vec)) return MI_BA_ERROR
     UP(d_tile_batch_, pl.tile_batch); UP(d_tile_slot_, pl.tile_slot); UP(d_tile_cslot_, pl.tile_cslot); UP(d_tile_mode_, pl.tile_mode);
+    uni_fixed_ = uni_other_ = false;      // which instantiations of k_build_uni have tiles: counted from the tables the kernels read
+    for (int t = 0; t < pl.ntile_lds; ++t)
+        if (pl.tile_mode[t] == 4) { if (pl.tile_cslot[t + 1] - pl.tile_cslot[t] == kUniFixedViews) uni_fixed_ = true; else uni_other_ = true; }
     UP(d_slot_gblk_, pl.slot_gblk); UP(d_cslot_cam_, pl.cslot_cam);
     UP(d_batch_obs_, pl.batch_obs); UP(d_batch_pt_, pl.batch_pt); UP(d_pt_obs_, pl.pt_obs);
     UP(d_bs_batch_obs_, pl.bs_batch_obs); UP(d_bs_batch_pt_, pl.bs_batch_pt); UP(d_bs_batch_obs_end_, pl.bs_batch_obs_end); UP(d_bs_batch_pt_end_, pl.bs_batch_pt_end);
@@ -660,7 +663,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     }
     BuildArgs a{};
     a.tile_batch = d_tile_batch_.p; a.tile_slot = d_tile_slot_.p; a.tile_cslot = d_tile_cslot_.p;
-    a.tile_mode = d_tile_mode_.p; a.has_table = pl.ntile_table > 0; a.has_mfma = pl.ntile_mfma > 0; a.has_uni = pl.ntile_uni > 0; a.has_reg = pl.ntile_lds - pl.ntile_table - pl.ntile_mfma - pl.ntile_uni > 0;
+    a.tile_mode = d_tile_mode_.p; a.has_table = pl.ntile_table > 0; a.has_mfma = pl.ntile_mfma > 0; a.has_uni = uni_other_; a.has_uni_fixed = uni_fixed_; a.has_reg = pl.ntile_lds - pl.ntile_table - pl.ntile_mfma - pl.ntile_uni > 0;
     a.slot_gblk = d_slot_gblk_.p; a.cslot_cam = d_cslot_cam_.p;
     a.batch_obs = d_batch_obs_.p; a.batch_pt = d_batch_pt_.p; a.batch_pair = d_batch_pair_.p; a.pt_obs = d_pt_obs_.p;
     a.obs_cam = d_obs_cam_.p; a.obs_pt = d_obs_pt_.p; a.obs_cslot = d_obs_cslot_.p; a.obs_xy = d_obs_xy_.p; a.cam_fixed = d_fixed_real_.p;

@@ -162,6 +162,7 @@ private:
     DevBuf<double> d_cam_cw_, d_cam_cv_, d_pt_cw_, d_pt_cv_;
     DevBuf<int> d_link_row_, d_link_other_, d_link_blk_;
     DevBuf<unsigned char> d_tile_mode_;
+    bool uni_fixed_ = false, uni_other_ = false;   // uniform tiles (plan.h mode 4) with kUniFixedViews views / with another view count
     DevBuf<int> d_bs_batch_obs_, d_bs_batch_pt_, d_bs_batch_obs_end_, d_bs_batch_pt_end_;
     DevBuf<double> d_cam_a_init_, d_pts_init_;
     DevBuf<double> d_link_w_, d_link_pair_w_, d_cam_part_, d_cam_part2_;   // partial rows of k_finalize_vec / of k_cam_update

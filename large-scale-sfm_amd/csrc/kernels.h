@@ -71,7 +71,8 @@ struct CamLinks {
 
 struct BuildArgs {
     const unsigned char *tile_mode; // per tile: 1 register-accumulated blocks, 2 LDS block table, 3 one camera set on the matrix pipe, 4 one camera set on the vector pipe (k_build_uni), 0 row tiles
-    int has_table, has_reg, has_mfma, has_uni; // some tile of this launch range has mode 2 / 1 / 3 / 4
+    int has_table, has_reg, has_mfma, has_uni; // some tile of this launch range has mode 2 / 1 / 3 / 4 (has_uni: with a view count other than kUniFixedViews)
+    int has_uni_fixed;                        // ... mode 4 with kUniFixedViews views: k_build_uni's instantiation with the view count as a constant
     const int *tile_batch, *tile_slot, *tile_cslot, *slot_gblk, *cslot_cam;
     const int *batch_obs, *batch_pt;
     const long long *batch_pair;

@@ -1274,10 +1274,16 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_mfma(const Build
 //     stay in registers, one LDS round trip and one wave synchronisation less per batch.
 // The blocks leave their registers once, when the tile ends (staged through the rows' LDS, dead by then).
 // ------------------------------------------------------------------------------------------
-template <int CNP, bool FULL>
+// DC: the tile's view count D as a compile-time constant (the instantiation for ten views: every tile of C2 / C3), or 0 = whatever the tile has
+// (a launch of each walks the tile range; a workgroup whose tile belongs to the other leaves at once)
+template <int CNP, bool FULL, int DC>
 __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildArgs g)
 {
     if (g.tile_mode[g.tile0 + blockIdx.x] != 4) return;
+    {
+        const int t_ = g.tile0 + blockIdx.x, d_ = g.tile_cslot[t_ + 1] - g.tile_cslot[t_];
+        if (DC > 0 ? d_ != DC : (g.has_uni_fixed && d_ == kUniFixedViews)) return;
+    }
     if (g.spec && g.spec[0] == 0.0) return;
     const double mu_lin = g.spec ? g.spec[1] : g.mu;
 #ifdef MIBA_STAMPS
@@ -1305,8 +1311,8 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_build_uni(const BuildA
     const int lane = threadIdx.x;
     const int tile = g.tile0 + blockIdx.x;
     const ModelCfg cfg = g.cfg;
-    const int D = g.tile_cslot[tile + 1] - g.tile_cslot[tile];           // views per point = cameras of the tile
-    const int NB = g.tile_slot[tile + 1] - g.tile_slot[tile];            // = D (D + 1) / 2, slot of (a, b) = its rank in the a <= b enumeration
+    const int D = DC > 0 ? DC : g.tile_cslot[tile + 1] - g.tile_cslot[tile];   // views per point = cameras of the tile
+    const int NB = DC > 0 ? DC * (DC + 1) / 2 : g.tile_slot[tile + 1] - g.tile_slot[tile];   // = D (D + 1) / 2, slot of (a, b) = its rank in the a <= b enumeration
     const int PB = kWave / D, PPR = kWave / NB;                            // points per batch, points per pair round
     for (int i = lane; i < D * SC; i += kWave) sC[i] = 0.0;
     for (int i = lane; i < D * (kCamLin / 2); i += kWave) {
@@ -3644,7 +3650,8 @@ static void launch_build_t(hipStream_t st, bool lds_mode, int ntiles, const Buil
     if (lds_mode) {
         // both variants walk the same tile range; a workgroup whose tile belongs to the other variant leaves at once
         if (a.has_mfma) hipLaunchKernelGGL((k_build_mfma<CNP, FULL>), dim3(ntiles), dim3(64), 0, st, a);
-        if (a.has_uni) hipLaunchKernelGGL((k_build_uni<CNP, FULL>), dim3(ntiles), dim3(64), 0, st, a);
+        if (a.has_uni_fixed) hipLaunchKernelGGL((k_build_uni<CNP, FULL, kUniFixedViews>), dim3(ntiles), dim3(64), 0, st, a);
+        if (a.has_uni) hipLaunchKernelGGL((k_build_uni<CNP, FULL, 0>), dim3(ntiles), dim3(64), 0, st, a);
         if (a.has_reg) hipLaunchKernelGGL((k_build<CNP, true, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);
         if (a.has_table) hipLaunchKernelGGL((k_build<CNP, true, FULL, true>), dim3(ntiles), dim3(64), 0, st, a);
     } else hipLaunchKernelGGL((k_build<CNP, false, FULL, false>), dim3(ntiles), dim3(64), 0, st, a);

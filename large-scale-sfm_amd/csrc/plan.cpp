@@ -386,7 +386,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
     const int *sig_cams = nullptr; int sig_d = -1;
     int cur_obs = 0, batches_in_tile = 0, sig_runs_in_tile = 0;
     t = 0;
-    pl.ntile_table = 0; pl.ntile_mfma = 0; pl.ntile_uni = 0;
+    pl.ntile_table = 0; pl.ntile_mfma = 0; pl.ntile_uni = 0; pl.ntile_uni_fixed = 0;
 
     std::vector<uint32_t> round_buf;  // pair entries of the round being filled (LDS tiles)
     bool rounds_mode = true;
@@ -468,7 +468,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         pl.tile_mode.push_back(m2);
         if (m2 == 2) pl.ntile_table++;
         if (m2 == 3) pl.ntile_mfma++;
-        if (m2 == 4) pl.ntile_uni++;
+        if (m2 == 4) { pl.ntile_uni++; if (sig_d == kUniFixedViews) pl.ntile_uni_fixed++; }
         sig_runs_in_tile = 0;
         if (mode == 1) tile_log.emplace_back(batches_in_tile, batches_in_tile >= tile_max_batches);
         pl.max_slots = std::max(pl.max_slots, (int)smap.size());

@@ -59,6 +59,7 @@ constexpr int kMfmaMinViews = 4;        // a tile of ONE camera set with this ma
 constexpr int kMfmaMinBatches = 3;      // ... and a tile that holds one such camera set for this many batches ends where the set changes
 constexpr int kUniMinViews = 4;         // a tile of ONE camera set with this many views or more per point is a UNIFORM tile (tile mode 4, k_build_uni: lane =
                                         // point x views + camera, the lane's pair and block constant for the whole tile; MI_BA_UNI=0: the general kernel instead)
+constexpr int kUniFixedViews = 10;       // the view count k_build_uni also exists for as a compile-time constant (= kMaxViewsLds: every tile of the benchmark scenes)
 constexpr int kUniMinBatches = 3;       // ... and a tile that holds one such camera set for this many batches ends where the set changes
 constexpr int kTableRuns = 4;           // a tile whose points change camera set more often than this sums its blocks in an LDS table
 constexpr int kMinRunPts = 12;          // a camera set shared by fewer consecutive points than this goes to the row path: a register-resident block is
@@ -97,6 +98,7 @@ struct Plan {
     std::vector<uint8_t> tile_mode;                  // 1 register-accumulated blocks, 2 blocks summed in an LDS table, 3 one camera set: blocks on the
                                                      // matrix pipe (k_build_mfma, opt-in), 4 one camera set on the vector pipe (k_build_uni), 0 row tiles (records to HBM)
     int ntile_table = 0, ntile_mfma = 0, ntile_uni = 0; // tiles of mode 2, of mode 3, of mode 4
+    int ntile_uni_fixed = 0;                         // ... of mode 4 with kUniFixedViews views
     std::vector<int> slot_gblk, cslot_cam;
     std::vector<uint32_t> pair;                      // la | lb<<6 | slot<<12 (6 bits) | local point<<18 (LDS tiles only)
     int64_t npair_lds = 0;                           // = pair.size()
