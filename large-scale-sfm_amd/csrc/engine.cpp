@@ -877,7 +877,7 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
     b.mu = mu; b.eps5 = cfg.lm_variant >= 1 ? 0.0 : cfg.opts[5];   /* (Bundler's rule; under PBA's controller opts[5] is the auto-switch threshold) */ b.nbatch = (int)pl.bs_batch_obs.size(); b.ngrid = std::min(b.nbatch, backsub_grid()); b.cfg = mc; b.scal = scal_();
     const int nlong = (int)pl.long_pts.size();
-    b.uni_ntile = pl.bs_uni ? pl.ntile_lds : 0; b.uni_row0 = b.ngrid + nlong;     // partial rows: k_backsub's | the long tracks' | the uniform tiles'
+    b.uni_ntile = pl.bs_uni ? pl.ntile_lds : 0; b.uni_row0 = b.ngrid + nlong; b.uni_fixed = uni_fixed_; b.uni_other = uni_other_;     // partial rows: k_backsub's | the long tracks' | the uniform tiles'
     if (timing_detail >= 2) (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
     launch_long_backsub(st_, cnp, long_args(mu, dB_dev, b.ngrid));

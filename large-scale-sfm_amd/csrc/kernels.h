@@ -109,6 +109,7 @@ struct BacksubArgs {
     const unsigned char *tile_mode;
     const int *tile_batch, *tile_cslot, *cslot_cam, *bld_batch_obs, *bld_batch_pt;
     int uni_ntile, uni_row0;                // workgroups (= LDS tiles of the plan; 0: no uniform tile), first partial row of theirs
+    int uni_fixed, uni_other;               // some uniform tile has kUniFixedViews views (the instantiation with that constant) / another view count
 };
 
 // long tracks (> 64 views): one workgroup per point; the records go where the row tiles' go

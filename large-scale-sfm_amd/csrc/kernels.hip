@@ -3436,7 +3436,7 @@ __global__ __launch_bounds__(64, FULL ? 2 : MIBA_BS_WAVES) void k_backsub(const 
 // lane arithmetic and four accumulators, and five wavefronts fit a SIMD.  The measurement and point streams come by LDS-DMA one
 // batch ahead (k_build_uni's), the ptout rows straight into the registers of the (point, component) lanes at the batch's top.
 // ------------------------------------------------------------------------------------------
-template <int CNP, bool FULL, bool DAMP>
+template <int CNP, bool FULL, bool DAMP, int DC /* the tile's view count as a constant, or 0: k_build_uni */>
 __global__ __launch_bounds__(64, 4) void k_backsub_uni   /* (five: 96 VGPRs with two spilled -- scratch reloads among the transfers -- 0.154 ms against 0.116) */(const BacksubArgs g)
 {
     const int tile = blockIdx.x;
@@ -3444,8 +3444,12 @@ __global__ __launch_bounds__(64, 4) void k_backsub_uni   /* (five: 96 VGPRs with
     if (g.scal[SC_PCG_FINAL] == 0.0) return;   // launched ahead of the host's look at the reduced solve (engine.cpp solve_phase)
     const int lane = threadIdx.x;
     if (g.tile_mode[tile] != 4) {               // not a uniform tile: its points are k_backsub's; a row of zeros for the reduction
-        if (lane < kPartW) prow[lane] = 0.0;
+        if (lane < kPartW && (DC > 0 || !g.uni_fixed)) prow[lane] = 0.0;     // (written by one of the two instantiations)
         return;
+    }
+    {
+        const int d_ = g.tile_cslot[tile + 1] - g.tile_cslot[tile];
+        if (DC > 0 ? d_ != DC : (g.uni_fixed && d_ == kUniFixedViews)) return;      // the other instantiation's tile
     }
     constexpr int kMaxD = kMaxViewsLds, kMaxPts = kWave / kUniMinViews;
     constexpr int SCL = 18;                      // a compact camera record: R (9) - c (3) f k1 k2 at 10..15; 18 doubles apart (distinct banks)
@@ -3457,7 +3461,7 @@ __global__ __launch_bounds__(64, 4) void k_backsub_uni   /* (five: 96 VGPRs with
     __shared__ double sD[DAMP ? kWave * 3 : 1];
     __shared__ int sFix[kMaxD];
     const ModelCfg cfg = g.cfg;
-    const int D = g.tile_cslot[tile + 1] - g.tile_cslot[tile];
+    const int D = DC > 0 ? DC : g.tile_cslot[tile + 1] - g.tile_cslot[tile];
     const int PB = kWave / D;
     const int lp = lane / D, cs = lane - lp * D;
     // ---- the tile's camera table: lane c prepares camera c (record at p, record at p + dp, the update's per-camera vectors)
@@ -3856,8 +3860,14 @@ void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, dou
 template <int CNP, bool FULL>
 static void launch_backsub_uni_t(hipStream_t st, const BacksubArgs &a)
 {
-    if (a.cfg.damp_diag) hipLaunchKernelGGL((k_backsub_uni<CNP, FULL, true>), dim3(a.uni_ntile), dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_backsub_uni<CNP, FULL, false>), dim3(a.uni_ntile), dim3(64), 0, st, a);
+    if (a.uni_fixed) {
+        if (a.cfg.damp_diag) hipLaunchKernelGGL((k_backsub_uni<CNP, FULL, true, kUniFixedViews>), dim3(a.uni_ntile), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_backsub_uni<CNP, FULL, false, kUniFixedViews>), dim3(a.uni_ntile), dim3(64), 0, st, a);
+    }
+    if (a.uni_other || !a.uni_fixed) {
+        if (a.cfg.damp_diag) hipLaunchKernelGGL((k_backsub_uni<CNP, FULL, true, 0>), dim3(a.uni_ntile), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_backsub_uni<CNP, FULL, false, 0>), dim3(a.uni_ntile), dim3(64), 0, st, a);
+    }
 }
 
 void launch_backsub(hipStream_t st, int cnp, const BacksubArgs &a)
