@@ -263,7 +263,8 @@ def main():
                      "ranks": [{k: c[k] for k in ("rank", "nranks", "device", "hip_device", "pid")} for c in comms]},
             "config": {"workload": f"{args.config}: {sc.m} cams / {sc.n} pts / {sc.nobs} obs, cnp 7 (pose + focal), "
                        "point-sharded Schur + block-Jacobi PCG", "parallelism": f"points/{world}",
-                       "pcg_tol": args.pcg_tol, "pcg_maxit": args.pcg_maxit, "deterministic": args.deterministic, "shared_focal_weight": args.shared_focal},
+                       "pcg_tol": args.pcg_tol, "pcg_maxit": args.pcg_maxit,
+                       "pcg_matrix": "f32 storage of the scaled matrix (> 64 MB: streamed every iteration), f64 vectors and sums" if tm.get("pcg_matrix_f32") else "f64", "deterministic": args.deterministic, "shared_focal_weight": args.shared_focal},
             "rmse_px": {"initial": rmse0, "after_timed_steps": rmse_after, "final_of_last_completed_solve": done["rmse"]},
             "accepted_steps": int(done["accepted"]), "completed_solves": done["solves"], "lm_iterations_of_last_completed_solve": done["iters"],
             "pcg_iters_per_step": tm["pcg_iters"] / max(tm["pcg_solves"], 1), "pcg_resumes": int(tm["pcg_resumes"]),

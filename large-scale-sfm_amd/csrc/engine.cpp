@@ -19,6 +19,7 @@ namespace {
 constexpr double kEpsilonSq = 1E-12 * 1E-12; // SBA_EPSILON_SQ, sba_levmar.c:37-38
 constexpr double kOneThird = 0.3333333334;   // SBA_ONE_THIRD, sba_levmar.c:40
 constexpr int kBuildTimedEvery = 4;          // mi_ba_set_timing_detail(1): every fourth build is bracketed by HIP events (both buffers of the double-buffered pair in turn)
+constexpr size_t kPcgF32FromBytes = 64u << 20;   // the scaled matrix goes single precision above this size (pcg_f32_)
 constexpr int kPcgChunk = 8;                 // PCG iterations launched between two host checks
 constexpr int kPcgRowPerWorkgroupMax = 512; // up to this many cameras a block row of S~ gets a whole workgroup (4 wavefronts), above: a wavefront
 constexpr int kPcgTotalsFrom = 1024;          // workgroups of the CG product from which the dot products are summed by a launch of their own (k_pcg_totals)
@@ -484,6 +485,11 @@ int Engine::prepare()
         if (!hipok(d_dbg_.alloc(8), "alloc dbg") || !hipok(hipMemset(d_dbg_.p, 0, 64), "memset dbg")) return MI_BA_ERROR;
     }
     setup_persist();
+    {   // the single-precision matrix of the reduced solve (pcg_f32_): MI_BA_PCG_F32 = 0 / 1 forces, MI_BA_PCG_F32_FROM_MB moves the size threshold (probes, tests)
+        const char *f = std::getenv("MI_BA_PCG_F32"), *mb = std::getenv("MI_BA_PCG_F32_FROM_MB");
+        pcg_f32_force_ = f ? std::atoi(f) : -1;
+        pcg_f32_from_ = mb ? (size_t)std::atoll(mb) << 20 : kPcgF32FromBytes;
+    }
     stage("parameters, buffers");
     prepared_ = true;
     if (set_params(h_a0_.data(), h_xyz_.data()) != 0) return MI_BA_ERROR;
@@ -729,10 +735,22 @@ PeekArgs Engine::peek_args(double mu) const
     return k;
 }
 
+// The scaled matrix of the reduced solve in single precision (vectors, dot products and recurrences stay f64): for systems whose matrix
+// is streamed from HBM / the Infinity Cache every iteration (> kPcgF32FromBytes; C4: 208 MB at 4.9 TB/s = 43 us per iteration) and a
+// tolerance the rounding of the matrix (6e-8 relative) is far below.  Small systems (C1-C3, C5: L2 / cache resident, launch-bound) keep
+// f64 -- nothing changes for them.  Not with the coarse space or the persistent solve (their kernels read f64).  MI_BA_PCG_F32=0 / 1 forces.
+bool Engine::pcg_f32_() const
+{
+    if (co_.ng || persist_ok_) return false;
+    if (pcg_f32_force_ >= 0) return pcg_f32_force_ != 0;
+    return (size_t)plan_.nb_full() * 64 * sizeof(double) > pcg_f32_from_ && cfg.pcg_tol >= 1e-6;
+}
+
 PcgStart Engine::pcg_start()
 {
     const PcgArgs p = pcg_args();
-    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr };
+    timing.pcg_matrix_f32 = pcg_f32_() ? 1.0 : 0.0;
+    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr, pcg_f32_() ? 1 : 0 };
 }
 
 PcgArgs Engine::pcg_args()
@@ -740,6 +758,7 @@ PcgArgs Engine::pcg_args()
     const size_t vec = (size_t)mv_ * kCP;
     PcgArgs p{};
     p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_pcg_.p; p.Linv = d_Linv_.p; p.E = d_E_.p;
+    p.S32 = pcg_f32_() ? reinterpret_cast<const float *>(d_S_pcg_.p) : nullptr;
     double *v = d_pcg_.p;
     p.da = d_dA_.p; p.x = v; p.p = v + vec; p.r0 = v + 2 * vec; p.r1 = v + 3 * vec; p.w0 = v + 4 * vec; p.w1 = v + 5 * vec;
     p.s0 = v + 6 * vec; p.s1 = v + 7 * vec;

@@ -66,6 +66,8 @@ public:
     int debug_solve(double mu, double *da, double *db, double *cost_new);
     int comm_init(const char *id);
     int comm_info(int out[4]);
+    bool pcg_f32_() const;
+    int pcg_f32_force_ = -1; size_t pcg_f32_from_ = (size_t)64 << 20;   // read from the environment by prepare()
     int debug_blocks(double *U, double *W);
 
     mi_ba_config cfg;

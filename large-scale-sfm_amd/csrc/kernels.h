@@ -141,7 +141,7 @@ struct SchurArgs {
 };
 
 // where the CG starts: written by k_block_inv, which holds L^-1 of every camera's diagonal block anyway
-struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
+struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; int f32 /* the scaled matrix goes to S_pcg in single precision (PcgArgs.S32) */; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
 // grid-barrier words of the persistent reduced solve (u64, 64-byte apart): root counter, generation, abort, one counter per group
 constexpr int kBarRoot = 0, kBarGen = 8, kBarAbort = 16, kBarGroup0 = 32, kBarMaxGroups = 32, kBarWords = kBarGroup0 + 8 * kBarMaxGroups;
 
@@ -162,6 +162,7 @@ struct CoarseArgs {
 struct PcgArgs {
     const int *bsr_row, *bsr_col;
     const double *S, *Linv, *E;                        // S = the scaled matrix S~ (k_scale_blocks)
+    const float *S32;                                  // ... or, non-null, S~ in single precision in the same buffer (large systems: the product streams half the bytes)
     double *x, *da, *p, *r0, *r1, *w0, *w1, *s0, *s1;  // r, w, s alternate by iteration parity (read by the neighbours' rows)
     double *gp, *dp, *rz_hist, *alpha_hist, *scal;     // gp, dp [2][nwg]: partials of r.r and w.r per workgroup; histories [maxit+2]
     double tol;

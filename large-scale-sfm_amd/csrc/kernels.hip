@@ -2321,7 +2321,8 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
 }
 
 // S~_jk = Linv_j S_jk Linv_k^T, one wavefront per block, lane (r,c); the block and the two factors go through LDS
-__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg)
+// f32out: the scaled matrix is stored in single precision instead (PcgArgs.S32: the CG then streams half the bytes; engine.cpp pcg_f32_)
+__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg, int f32out)
 {
     __shared__ double sh[4][4][64];   // per wavefront: S, T = Linv_j S, Linv_j, Linv_k
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
@@ -2341,7 +2342,10 @@ __global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs
     double o = 0.0;                                   // T Linv_k^T
 #pragma unroll
     for (int a = 0; a < 8; ++a) o = fma(sh[wv][1][r * 8 + a], sh[wv][3][c * 8 + a], o);
-    if (live) S_pcg[(size_t)b * 64 + lane] = (j == k) ? (r == c ? 1.0 : 0.0) : o;   // the diagonal blocks are the identity by construction
+    const double val = (j == k) ? (r == c ? 1.0 : 0.0) : o;   // the diagonal blocks are the identity by construction
+    // (single precision: element (r, c) at ((r & 3) * 4 + (c >> 1)) * 4 + (r >> 2) * 2 + (c & 1) -- a lane of the product then finds rows r and r + 4,
+    // columns c, c + 1 in ONE 16-byte load and needs one 16-byte piece of the vector for them: row_products)
+    if (live) { if (f32out) reinterpret_cast<float *>(S_pcg)[(size_t)b * 64 + (((r & 3) * 4 + (c >> 1)) * 4 + (r >> 2) * 2 + (c & 1))] = (float)val; else S_pcg[(size_t)b * 64 + lane] = val; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2417,11 +2421,66 @@ __device__ __forceinline__ void publish_partials(const PcgArgs &a, int slot, dou
 template <int NV>
 __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, int stride, int lane, const double *const (&vec)[NV], double (&out)[NV])
 {
-    const int half = lane >> 5, c2 = (lane & 3) * 2, el = ((lane & 31) >> 2) * 8 + c2;
-    const double *__restrict__ Sv = a.S;
     double acc[NV][2];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = 0.0;
+    if (a.S32) {
+        // The matrix in single precision (large systems: vectors, sums and the recurrences stay f64).  One wave load = 16 B per lane = FOUR
+        // 8 x 8 blocks: the quarter-wave lane >> 4 takes every fourth block of the row; lane (r', column pair) of a quarter holds elements
+        // (r', c), (r', c + 1), (r' + 4, c), (r' + 4, c + 1) (k_scale_blocks' layout) and multiplies them with ONE 16-byte piece of the vector --
+        // the same vector traffic per block as the f64 form, half the matrix bytes.
+        const float *__restrict__ Sf = a.S32;
+        const int quarter = lane >> 4, li = lane & 15, c2f = (li & 3) * 2;
+        const int st4 = 4 * stride;
+        int q = qb + quarter * stride;
+        double hi[NV][2];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) hi[v][0] = hi[v][1] = 0.0;
+        for (; q + 7 * st4 < qe; q += 8 * st4) {
+            int k[8];
+            float4 sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                k[u] = a.bsr_col[q + u * st4] * 8 + c2f;
+                sv[u] = *reinterpret_cast<const float4 *>(Sf + (size_t)(q + u * st4) * 64 + li * 4);
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                double2 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const double2 *>(vec[v] + k[u]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc[v][u & 1] = fma((double)sv[u].y, x[u].y, fma((double)sv[u].x, x[u].x, acc[v][u & 1]));
+                    hi[v][u & 1] = fma((double)sv[u].w, x[u].y, fma((double)sv[u].z, x[u].x, hi[v][u & 1]));
+                }
+            }
+        }
+        for (; q < qe; q += st4) {
+            const int k = a.bsr_col[q] * 8 + c2f;
+            const float4 sv = *reinterpret_cast<const float4 *>(Sf + (size_t)q * 64 + li * 4);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double2 x = *reinterpret_cast<const double2 *>(vec[v] + k);
+                acc[v][0] = fma((double)sv.y, x.y, fma((double)sv.x, x.x, acc[v][0]));
+                hi[v][0] = fma((double)sv.w, x.y, fma((double)sv.z, x.x, hi[v][0]));
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double tl = acc[v][0] + acc[v][1], th = hi[v][0] + hi[v][1];
+            tl += dpp_move<0xB1>(tl); tl += dpp_move<0x4E>(tl);        // the 4 lanes of a row pair (quad permutes)
+            th += dpp_move<0xB1>(th); th += dpp_move<0x4E>(th);
+            tl += __shfl_xor(tl, 16); tl += __shfl_xor(tl, 32);       // the four quarters' blocks
+            th += __shfl_xor(th, 16); th += __shfl_xor(th, 32);
+            const int rr = lane >> 3;                                 // row r: rows 0..3 from tl of quad r, rows 4..7 from th of quad r - 4
+            const double a_lo = __shfl(tl, (rr & 3) * 4), a_hi = __shfl(th, (rr & 3) * 4);
+            out[v] = rr < 4 ? a_lo : a_hi;
+        }
+        return;
+    }
+    const int half = lane >> 5, c2 = (lane & 3) * 2, el = ((lane & 31) >> 2) * 8 + c2;
+    const double *__restrict__ Sv = a.S;
     int q = qb + half * stride;                       // this half's first block; then every second block of the row
     const int st2 = 2 * stride;
     for (; q + 7 * st2 < qe; q += 8 * st2) {          // (the halves may leave the loop one trip apart: nothing wave-wide inside)
@@ -3697,7 +3756,7 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
     hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
-    hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg);
+    hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg, ps.f32 ? 1 : 0);
     if (co.ng) {   // the coarse space of this trial's system: Z'SZ, its inverse, S~Z~
         static_assert(kBcSlots == 4, "k_coarse_bc: one wavefront per slot");
         hipLaunchKernelGGL(k_coarse_bc, dim3(m), dim3(256), 0, st, m, bsr_row, bsr_col, (const double *)S_pcg, co);

@@ -1022,3 +1022,32 @@ def test_config_c4_pinned_to_the_reference_at_full_size(oracle):
     print("C4: focal lengths differ by at most %.3g px" % (np.abs(cams[:, 6] - cw[:, 6]).max() / 0.001))
     assert np.abs(cams[:, 6] - cw[:, 6]).max() / 0.001 < 0.5
     eng.close()
+
+
+def test_reduced_solve_with_the_scaled_matrix_in_single_precision(oracle, monkeypatch):
+    """Systems whose scaled matrix exceeds 64 MB (BASELINE config C4: 208 MB) stream it in single precision through the CG -- vectors, dot
+    products and recurrences stay f64 (engine.cpp pcg_f32_, kernels.hip row_products).  Here the threshold is moved to zero on scenes the
+    oracle solves: the same LM iterations, stop reason and final cost as the all-f64 solve and as the oracle (the matrix' rounding, 6e-8
+    relative, is far below the default 1e-3 tolerance of the CG); a tight tolerance (< 1e-6) keeps f64 whatever the size."""
+    for name in ("C1", "C1t"):
+        sc, z = scene_from_golden(name)
+        res = {}
+        for mode in ("f64", "f32"):
+            if mode == "f32":
+                monkeypatch.setenv("MI_BA_PCG_F32_FROM_MB", "0")
+            else:
+                monkeypatch.delenv("MI_BA_PCG_F32_FROM_MB", raising=False)
+            eng = make_engine(sc)
+            ret, info = eng.run()
+            res[mode] = (ret, np.array(info), eng.timing()["pcg_matrix_f32"], eng.trace().copy())
+            eng.close()
+        assert res["f64"][2] == 0.0 and res["f32"][2] == 1.0
+        assert res["f32"][0] == res["f64"][0] == int(z["ret_final"]) and res["f32"][1][6] == res["f64"][1][6] == z["info_final"][6]
+        assert abs(res["f32"][1][1] - res["f64"][1][1]) < 1e-9 * res["f64"][1][1]
+        k = min(len(res["f32"][3]), len(res["f64"][3]))
+        assert np.allclose(res["f32"][3][:k, 3], res["f64"][3][:k, 3], rtol=1e-7)       # trial costs
+    monkeypatch.setenv("MI_BA_PCG_F32_FROM_MB", "0")
+    eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+    eng.run()
+    assert eng.timing()["pcg_matrix_f32"] == 0.0
+    eng.close()
