@@ -2436,13 +2436,22 @@ __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, i
         double hi[NV][2];
 #pragma unroll
         for (int v = 0; v < NV; ++v) hi[v][0] = hi[v][1] = 0.0;
+        int kn[8];                                     // column indices, one chunk ahead (see the f64 form below)
+        if (q + 7 * st4 < qe) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kn[u] = a.bsr_col[q + u * st4];
+        }
         for (; q + 7 * st4 < qe; q += 8 * st4) {
             int k[8];
             float4 sv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                k[u] = a.bsr_col[q + u * st4] * 8 + c2f;
+                k[u] = kn[u] * 8 + c2f;
                 sv[u] = *reinterpret_cast<const float4 *>(Sf + (size_t)(q + u * st4) * 64 + li * 4);
+            }
+            if (q + 15 * st4 < qe) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kn[u] = a.bsr_col[q + (8 + u) * st4];
             }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -2483,13 +2492,24 @@ __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, i
     const double *__restrict__ Sv = a.S;
     int q = qb + half * stride;                       // this half's first block; then every second block of the row
     const int st2 = 2 * stride;
+    // the column indices of a chunk are requested one chunk ahead: the vector loads depend on them, and a row's chunks are otherwise two
+    // dependent round trips each (long rows -- C4: 239 blocks -- are chains of such round trips, not a stream)
+    int kn[8];
+    if (q + 7 * st2 < qe) {                           // (short rows never enter the chunked loop: nothing to request ahead)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) kn[u] = a.bsr_col[q + u * st2];
+    }
     for (; q + 7 * st2 < qe; q += 8 * st2) {          // (the halves may leave the loop one trip apart: nothing wave-wide inside)
         int k[8];
         double2 sv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            k[u] = a.bsr_col[q + u * st2] * 8 + c2;
+            k[u] = kn[u] * 8 + c2;
             sv[u] = *reinterpret_cast<const double2 *>(Sv + (size_t)(q + u * st2) * 64 + el);
+        }
+        if (q + 15 * st2 < qe) {                      // (uniform per half) the next trip's indices
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kn[u] = a.bsr_col[q + (8 + u) * st2];
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
