@@ -194,7 +194,8 @@ typedef struct {
     double pcg_persistent;                 /* reduced solves done by the one persistent launch (k_pcg_persist) instead of a launch per iteration */
     double pcg_matrix_f32;                 /* 1: the reduced solve streams its scaled matrix in single precision (systems whose matrix exceeds 64 MB at the
                                             * default tolerance; vectors, dot products and recurrences f64) -- engine.cpp pcg_f32_ */
-    double reserved[9];                    /* the struct stays 32 doubles from here on: new figures come out of this tail */
+    double pcg_push;                       /* 1: the reduced solve reads its neighbours' vectors from per-block mailboxes (opt-in MI_BA_PCG_PUSH=1) */
+    double reserved[8];                    /* the struct stays 32 doubles from here on: new figures come out of this tail */
 } mi_ba_timing;
 /* ABI note: the struct grew twice before it got its tail (17 doubles in round 1, 21 in round 2, 32 now).  mi_ba_get_timing is the
  * symbol every one of those headers declares, so it only ever writes the 17 doubles they all share (build_ms .. build_index_bytes);

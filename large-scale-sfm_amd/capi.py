@@ -35,7 +35,7 @@ class Config(C.Structure):
 class Timing(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("build_ms", "build_launches", "pcg_ms", "pcg_solves", "pcg_iters", "backsub_ms", "backsub_launches",
-                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes", "pcg_resumes", "build_flops", "pcg_timed", "spec_adopted", "build_index_bytes", "exchange_ms", "exchanges_timed", "replicated_ms", "replicated_timed", "pcg_persistent", "pcg_matrix_f32")] + [("reserved", C.c_double * 9)]
+                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes", "pcg_resumes", "build_flops", "pcg_timed", "spec_adopted", "build_index_bytes", "exchange_ms", "exchanges_timed", "replicated_ms", "replicated_timed", "pcg_persistent", "pcg_matrix_f32", "pcg_push")] + [("reserved", C.c_double * 8)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -280,7 +280,7 @@ def comm_unique_id() -> bytes:
 class Plan:
     """host-only shard plan (usable without a GPU)."""
 
-    _dtypes = dict(obs_src=np.int64, batch_pair=np.int64, pair=np.uint32, rpair=np.uint32, wk_q=np.int64, obs_cslot=np.uint8,
+    _dtypes = dict(obs_src=np.int64, batch_pair=np.int64, pair=np.uint32, rpair=np.uint32, wk_q=np.int64, sb_q=np.int64, obs_cslot=np.uint8,
                    tile_mode=np.uint8, bsr_trans=np.uint8)
 
     def __init__(self, n, m, pt_idx, cam_idx, rank=0, world=1, tile_max_batches=0, all_rows=False):

@@ -143,7 +143,7 @@ int mi_ba_plan_stats(const mi_ba_plan *p, int64_t s[MI_BA_PLAN_NSTATS])
     s[MI_BA_PLAN_NPTS_LOCAL] = pl.npts_local(); s[MI_BA_PLAN_NOBS_LOCAL] = pl.nobs_local();
     s[MI_BA_PLAN_NBATCH] = pl.nbatch(); s[MI_BA_PLAN_NTILE] = pl.ntile(); s[MI_BA_PLAN_NPAIR] = (int64_t)pl.pair.size();
     s[MI_BA_PLAN_NB_UPPER] = pl.nb_up(); s[MI_BA_PLAN_NB_FULL] = pl.nb_full(); s[MI_BA_PLAN_NSLOT_TOTAL] = (int64_t)pl.slot_gblk.size();
-    s[MI_BA_PLAN_NBATCH_ROWS] = pl.nbatch() - pl.nbatch_lds; s[MI_BA_PLAN_NPAIR_ROWS] = (int64_t)pl.rpair.size() / 2;
+    s[MI_BA_PLAN_NBATCH_ROWS] = pl.nbatch() - pl.nbatch_lds; s[MI_BA_PLAN_NPAIR_ROWS] = (int64_t)pl.rpair.size() / 2 + pl.nsuper_pairs;
     s[MI_BA_PLAN_NREC] = pl.rec_cam.empty() ? 0 : pl.rec_cam.back(); s[MI_BA_PLAN_NROW_PTS] = pl.nrow_pts;
     s[MI_BA_PLAN_NLONG] = (int64_t)pl.long_pts.size(); s[MI_BA_PLAN_PT_BEGIN] = pl.pt_begin; s[MI_BA_PLAN_PT_END] = pl.pt_end;
     s[MI_BA_PLAN_MAX_SLOTS] = pl.max_slots;
@@ -161,13 +161,14 @@ int64_t mi_ba_plan_get(const mi_ba_plan *p, const char *name, void *out, int64_t
     I32("cslot_cam", cslot_cam); I32("up_row", up_row); I32("up_col", up_col); I32("bsr_row", bsr_row); I32("bsr_col", bsr_col);
     I32("bsr_src", bsr_src); I32("pt_obs", pt_obs); I32("long_pts", long_pts);
     I32("bs_batch_obs", bs_batch_obs); I32("bs_batch_pt", bs_batch_pt); I32("bs_batch_obs_end", bs_batch_obs_end); I32("bs_batch_pt_end", bs_batch_pt_end);
-    I32("obs_rec", obs_rec); I32("rec_cam", rec_cam); I32("wk_blk", wk_blk); I32("wk_diag_cam", wk_diag_cam); I32("wk_diag_blk", wk_diag_blk);
+    I32("obs_rec", obs_rec); I32("rec_cam", rec_cam); I32("wk_blk", wk_blk); I32("wk_diag_cam", wk_diag_cam); I32("wk_diag_blk", wk_diag_blk); I32("sb_blk", sb_blk); I32("sb_ent", sb_ent);
 #undef I32
     if (k == "obs_src") return copy_out(pl.obs_src, (int64_t *)out, cap);
     if (k == "batch_pair") return copy_out(pl.batch_pair, (int64_t *)out, cap);
     if (k == "pair") return copy_out(pl.pair, (uint32_t *)out, cap);
     if (k == "rpair") return copy_out(pl.rpair, (uint32_t *)out, cap);
     if (k == "wk_q") return copy_out(pl.wk_q, (int64_t *)out, cap);
+    if (k == "sb_q") return copy_out(pl.sb_q, (int64_t *)out, cap);
     if (k == "obs_cslot") return copy_out(pl.obs_cslot, (uint8_t *)out, cap);
     if (k == "tile_mode") return copy_out(pl.tile_mode, (uint8_t *)out, cap);
     if (k == "bsr_trans") return copy_out(pl.bsr_trans, (uint8_t *)out, cap);

@@ -105,6 +105,22 @@ Engine::~Engine()
                          h[0] / tot, h[1] / tot, h[2] / tot, h[3] / tot, h[4] / tot, h[5] / tot, h[6] / tot, h[7] / tot, tot);
         }
     }
+    if (d_pstamps_.p) { // diagnostic build: where the launches of the last reduced solve spent their time (100 MHz wall clock: 10 ns ticks)
+        std::vector<unsigned long long> h(d_pstamps_.n);
+        if (hipMemcpy(h.data(), d_pstamps_.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int w = 0; w < 2; ++w) {
+                double seg[5] = { 0, 0, 0, 0, 0 }; int cnt = 0;
+                for (int it = 2; it + 1 < cfg.pcg_maxit && h[(size_t)(it + 1) * 16 + 8 * w + 4]; ++it) {
+                    const unsigned long long *t = &h[(size_t)it * 16 + 8 * w], *tn = &h[(size_t)(it + 1) * 16 + 8 * w];
+                    if (!t[4] || tn[0] < t[4]) break;
+                    for (int i = 0; i < 4; ++i) seg[i] += (double)(t[i + 1] - t[i]);
+                    seg[4] += (double)(tn[0] - t[4]); ++cnt;
+                }
+                if (cnt) std::fprintf(stderr, "[mi_ba stamps] k_pcg_iter %s workgroup, %d launches, us: flags %.2f | product %.2f | scalars+update %.2f | publish %.2f | exit -> next entry %.2f\n",
+                                      w ? "last" : "first", cnt, seg[0] / cnt / 100, seg[1] / cnt / 100, seg[2] / cnt / 100, seg[3] / cnt / 100, seg[4] / cnt / 100);
+            }
+        }
+    }
     if (comm_) ncclCommDestroy((ncclComm_t)comm_);
     if (h_scal_) (void)hipHostFree(h_scal_);
     for (auto &ev : ev_) if (ev) (void)hipEventDestroy(ev);
@@ -325,10 +341,28 @@ int Engine::prepare()
     {
         std::vector<long long> bp(pl.batch_pair.begin(), pl.batch_pair.end()), wq(pl.wk_q.begin(), pl.wk_q.end());
         UP(d_batch_pair_, bp); UP(d_wk_q_, wq);
+        std::vector<long long> sq(pl.sb_q.begin(), pl.sb_q.end());
+        UP(d_sb_q_, sq); UP(d_sb_blk_, pl.sb_blk); UP(d_sb_ent_, pl.sb_ent);
         std::vector<int> rowidx(pl.nb_full()), diag(mv_, -1);
         for (int j = 0; j < mv_; ++j)
             for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) { rowidx[q] = j; if (pl.bsr_col[q] == j) diag[j] = q; }
         UP(d_bsr_rowidx_, rowidx); UP(d_bsr_diag_, diag);
+        // where every block's transpose sits (the pattern is symmetric): the mailbox a block row pushes its vectors to (kernels.hip push_row)
+        std::vector<int> tq(pl.nb_full(), -1);
+        bool sym = true;
+        for (int j = 0; j < mv_ && sym; ++j)
+            for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) {
+                const int k = pl.bsr_col[q];
+                const int *b = pl.bsr_col.data() + pl.bsr_row[k], *e = pl.bsr_col.data() + pl.bsr_row[k + 1];
+                const int *f = std::lower_bound(b, e, j);
+                if (f == e || *f != j) f = std::find(b, e, j);          // (columns not ascending: look through the row)
+                if (f == e) { sym = false; break; }
+                tq[q] = (int)(f - pl.bsr_col.data());
+            }
+        // (opt-in, MI_BA_PCG_PUSH=1: measured SLOWER than the gather by column index -- C3 0.38 against 0.26 ms per solve, C2 0.208 / 0.202, C1 0.066 / 0.056:
+        //  the mailboxes are 37 x the vectors' bytes, written and read across the XCDs every iteration)
+        pcg_push_ok_ = sym && (size_t)pl.nb_full() * 64 * sizeof(double) <= kPcgF32FromBytes && std::getenv("MI_BA_PCG_PUSH") && std::atoi(std::getenv("MI_BA_PCG_PUSH")) != 0;
+        if (pcg_push_ok_) UP(d_bsr_tq_, tq);
     }
     stage("plan + index uploads");
     if (cfg.deterministic == 1 && pl.ntile_lds > 0) {   // ordered hand-over: who contributes to every block of S and to every camera, in tile order
@@ -479,8 +513,12 @@ int Engine::prepare()
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (!hipok(hipMemset(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double)), "memset rz/pq")) return MI_BA_ERROR;
+    if (pcg_push_ok_ && (!hipok(d_mb_.alloc(2 * (size_t)pl.nb_full() * 24), "alloc CG mailboxes") || !hipok(hipMemset(d_mb_.p, 0, d_mb_.n * sizeof(double)), "memset CG mailboxes"))) return MI_BA_ERROR;
     if (!hipok(d_spec_.alloc(2), "alloc spec") || !hipok(hipMemset(d_spec_.p, 0, 2 * sizeof(double)), "memset spec")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
+    if (std::getenv("MI_BA_PCG_STAMPS")) {
+        if (!hipok(d_pstamps_.alloc((size_t)(cfg.pcg_maxit + 4) * 16), "alloc pcg stamps") || !hipok(hipMemset(d_pstamps_.p, 0, d_pstamps_.n * 8), "memset pcg stamps")) return MI_BA_ERROR;
+    }
     if (std::getenv("MI_BA_STAMPS")) {
         if (!hipok(d_dbg_.alloc(8), "alloc dbg") || !hipok(hipMemset(d_dbg_.p, 0, 64), "memset dbg")) return MI_BA_ERROR;
     }
@@ -498,7 +536,7 @@ int Engine::prepare()
     // camera its 192-B record, every upper block of S once (512 B).  The engine's own index tables (pair entries, batch and
     // tile descriptors) and the row path's observation records are NOT problem data: they are reported beside it.
     timing.build_bytes = 24.0 * (double)pl.nobs_local() + 96.0 * (double)npl + 192.0 * m_ + 512.0 * pl.nb_up();
-    timing.build_index_bytes = 1.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 8.0 * (double)(pl.rpair.size() / 2) +
+    timing.build_index_bytes = 1.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 8.0 * (double)(pl.rpair.size() / 2) + 4.0 * (double)pl.sb_ent.size() +
                                2.0 * 8.0 * kRec * (double)pl.rec_cam[m_];
     {   // arithmetic of the same launch (for the f64 vector roofline beside the HBM one)
         double pairs = 0.0;
@@ -506,9 +544,9 @@ int Engine::prepare()
         timing.build_flops = 400.0 * (double)pl.nobs_local() + 276.0 * pairs + 120.0 * (double)npl;
     }
     if (cfg.verbose)
-        std::fprintf(stderr, "[mi_ba] rank %d/%d: %lld pts %lld obs, %d batches, %d tiles (%d LDS), %zu pair entries; row path: %lld pts, %d records, %zu pairs in %zu + %zu blocks; S: %d upper / %d full blocks\n",
+        std::fprintf(stderr, "[mi_ba] rank %d/%d: %lld pts %lld obs, %d batches, %d tiles (%d LDS), %zu pair entries; row path: %lld pts, %d records, %zu pairs in %zu + %zu blocks, %lld pairs in %zu super-block entries; S: %d upper / %d full blocks\n",
                      cfg.rank, cfg.world, (long long)npl, (long long)pl.nobs_local(), pl.nbatch(), pl.ntile(), pl.ntile_lds,
-                     pl.pair.size(), (long long)pl.nrow_pts, pl.rec_cam[m_], pl.rpair.size() / 2, pl.wk_blk.size(), pl.wk_diag_cam.size(), pl.nb_up(), pl.nb_full());
+                     pl.pair.size(), (long long)pl.nrow_pts, pl.rec_cam[m_], pl.rpair.size() / 2, pl.wk_blk.size(), pl.wk_diag_cam.size(), (long long)pl.nsuper_pairs, pl.sb_ent.size() / 8, pl.nb_up(), pl.nb_full());
     return 0;
 }
 
@@ -702,6 +740,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
         sa.diag_cam = d_wk_diag_cam_.p; sa.diag_blk = d_wk_diag_blk_.p; sa.rec_cam = d_rec_cam_.p;
         sa.nwork = (int)pl.wk_blk.size(); sa.ndiag = (int)pl.wk_diag_cam.size(); sa.m = m_; sa.mv = mv_; sa.want_diag = (want_diag || pba) ? 1 : 0;
         sa.wk_vblk = d_wk_vblk_.p; sa.diag_vblk = d_wk_diag_vblk_.p;
+        sa.sb_blk = d_sb_blk_.p; sa.sb_ent = d_sb_ent_.p; sa.sb_q = d_sb_q_.p; sa.nsuper = (int)pl.sb_q.size() - 1;
         sa.S_up = S_up_(); sa.camvec = camvec_(); sa.spec = spec;
         launch_schur_blocks(st_, cnp, sa);
     }
@@ -746,11 +785,15 @@ bool Engine::pcg_f32_() const
     return (size_t)plan_.nb_full() * 64 * sizeof(double) > pcg_f32_from_ && cfg.pcg_tol >= 1e-6;
 }
 
+// the f64 matrix in the product's column form (kernels.hip row_products): whenever the plain launched iteration is the only reader
+bool Engine::pcg_cm_() const { return !co_.ng && !persist_ok_ && !pcg_f32_(); }
+
 PcgStart Engine::pcg_start()
 {
     const PcgArgs p = pcg_args();
     timing.pcg_matrix_f32 = pcg_f32_() ? 1.0 : 0.0;
-    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr, pcg_f32_() ? 1 : 0 };
+    timing.pcg_push = p.mb0 ? 1.0 : 0.0;
+    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr, pcg_f32_() ? 1 : pcg_cm_() ? 2 : 0 };
 }
 
 PcgArgs Engine::pcg_args()
@@ -759,6 +802,8 @@ PcgArgs Engine::pcg_args()
     PcgArgs p{};
     p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_pcg_.p; p.Linv = d_Linv_.p; p.E = d_E_.p;
     p.S32 = pcg_f32_() ? reinterpret_cast<const float *>(d_S_pcg_.p) : nullptr;
+    p.cm = pcg_cm_() ? 1 : 0;
+    if (p.cm && pcg_push_ok_) { p.mb0 = d_mb_.p; p.mb1 = d_mb_.p + (size_t)plan_.nb_full() * 24; p.bsr_tq = d_bsr_tq_.p; }
     double *v = d_pcg_.p;
     p.da = d_dA_.p; p.x = v; p.p = v + vec; p.r0 = v + 2 * vec; p.r1 = v + 3 * vec; p.w0 = v + 4 * vec; p.w1 = v + 5 * vec;
     p.s0 = v + 6 * vec; p.s1 = v + 7 * vec;
@@ -775,6 +820,7 @@ PcgArgs Engine::pcg_args()
     static const int force_tot = std::getenv("MI_BA_PCG_TOTALS") ? std::atoi(std::getenv("MI_BA_PCG_TOTALS")) : -1;
     if (!row_wg && !co_active_ && (force_tot >= 0 ? force_tot != 0 : p.nwg >= kPcgTotalsFrom)) p.tot = p.dp + 2 * (size_t)p.nwg;   // (room: 4 mv doubles are allocated for the partials)
     if (co_active_) p.co = co_;
+    p.stamps = d_pstamps_.p;
     return p;
 }
 

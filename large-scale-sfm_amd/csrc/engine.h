@@ -67,6 +67,8 @@ public:
     int comm_init(const char *id);
     int comm_info(int out[4]);
     bool pcg_f32_() const;
+    bool pcg_cm_() const;
+    bool pcg_push_ok_ = false;                    // the reduced solve's push halo (opt-in MI_BA_PCG_PUSH=1: mailboxes allocated, symmetric pattern)
     int pcg_f32_force_ = -1; size_t pcg_f32_from_ = (size_t)64 << 20;   // read from the environment by prepare()
     int debug_blocks(double *U, double *W);
 
@@ -143,16 +145,16 @@ private:
 
     // device: plan
     DevBuf<int> d_tile_batch_, d_tile_slot_, d_tile_cslot_, d_slot_gblk_, d_cslot_cam_, d_batch_obs_, d_batch_pt_, d_pt_obs_,
-        d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_;
+        d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_, d_bsr_tq_;
     DevBuf<long long> d_batch_pair_;
     DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_, d_pfix_;   // per ROW of the camera-side arrays: held camera; bit r = parameter r held constant
     DevBuf<unsigned char> d_fixed_real_;                                    // per real camera (the point-side kernels)
     DevBuf<int> d_wk_vblk_, d_wk_diag_vblk_;
     DevBuf<unsigned> d_pair_, d_rpair_;
-    DevBuf<int> d_obs_rec_, d_rec_cam_, d_wk_blk_, d_wk_diag_cam_, d_wk_diag_blk_;   // row path (plan.h)
-    DevBuf<long long> d_wk_q_;
+    DevBuf<int> d_obs_rec_, d_rec_cam_, d_wk_blk_, d_wk_diag_cam_, d_wk_diag_blk_, d_sb_blk_, d_sb_ent_;   // row path (plan.h)
+    DevBuf<long long> d_wk_q_, d_sb_q_;
     DevBuf<double> d_rec_;                                                             // kRec doubles per row-path observation
-    DevBuf<unsigned long long> d_dbg_;
+    DevBuf<unsigned long long> d_dbg_, d_pstamps_;
     // the reduced solve as one persistent cooperative launch (kernels.hip k_pcg_persist) when S~ fits the chip's LDS
     DevBuf<unsigned long long> d_bar_;       // its grid-barrier words
     DevBuf<int> d_win_ptr_, d_win_col_, d_blk_loc_;   // per workgroup: the distinct columns of its rows; per block: where its column sits among them
@@ -172,7 +174,7 @@ private:
     DevBuf<double2> d_obs_xy_;
     // device: state
     DevBuf<double> d_cam_a_[2], d_cam_lin_[2], d_pts_[2], d_R0_[2] /* [cur_]: the rotation omega is relative to; moves with the camera under PBA's update */, d_R0_init_, d_ff_, d_ptout_, d_acc_, d_S_full_, d_S_pcg_, d_Linv_, d_E_, d_dA_, d_dB_,
-        d_pcg_, d_rzpq_, d_full_pts_, d_part_, d_stage_, d_spec_;
+        d_pcg_, d_rzpq_, d_full_pts_, d_part_, d_stage_, d_spec_, d_mb_ /* the CG mailboxes (push halo) */;
     int cur_ = 0; // index of the current estimate in the [2] buffers
     bool cam_lin_valid_ = false; // d_cam_lin_[cur_] holds the records of d_cam_a_[cur_]
     double *h_scal_ = nullptr; // pinned, kScalCount

@@ -136,12 +136,15 @@ struct SchurArgs {
     int nwork, ndiag, m, want_diag;
     int mv;                       // rows of the camera-side arrays (2 m with nine camera parameters: ModelCfg.split)
     const int *wk_vblk, *diag_vblk;   // split: the 4 virtual blocks of every work item (diagonal items: 0, 1 and 3 used)
+    const int *sb_blk, *sb_ent;       // super-blocks (plan.h): 16 blocks per work item; 8 records per entry, -1 = none
+    const long long *sb_q;            // ... work item w: entries [sb_q[w], sb_q[w + 1]), a multiple of four
+    int nsuper;
     double *S_up, *camvec;
     const double *spec;           // as in BuildArgs
 };
 
 // where the CG starts: written by k_block_inv, which holds L^-1 of every camera's diagonal block anyway
-struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; int f32 /* the scaled matrix goes to S_pcg in single precision (PcgArgs.S32) */; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
+struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; int layout /* of the scaled matrix in S_pcg: 0 f64 blocks row-major, 1 single precision (PcgArgs.S32), 2 f64 in the product's column form (PcgArgs.cm) */; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
 // grid-barrier words of the persistent reduced solve (u64, 64-byte apart): root counter, generation, abort, one counter per group
 constexpr int kBarRoot = 0, kBarGen = 8, kBarAbort = 16, kBarGroup0 = 32, kBarMaxGroups = 32, kBarWords = kBarGroup0 + 8 * kBarMaxGroups;
 
@@ -163,6 +166,9 @@ struct PcgArgs {
     const int *bsr_row, *bsr_col;
     const double *S, *Linv, *E;                        // S = the scaled matrix S~ (k_scale_blocks)
     const float *S32;                                  // ... or, non-null, S~ in single precision in the same buffer (large systems: the product streams half the bytes)
+    int cm;                                            // S (f64) holds each block in the product's column form (k_scale_blocks layout 2) instead of row-major
+    double *mb0, *mb1;                                 // push halo (with cm): per block q of the pattern the r | w | s (3 x 8) of block row bsr_col[q], by iteration parity; nullptr: gathered by column index
+    const int *bsr_tq;                                 // ... and where block q's transpose sits: bsr_col[bsr_tq[q]] = row of q
     double *x, *da, *p, *r0, *r1, *w0, *w1, *s0, *s1;  // r, w, s alternate by iteration parity (read by the neighbours' rows)
     double *gp, *dp, *rz_hist, *alpha_hist, *scal;     // gp, dp [2][nwg]: partials of r.r and w.r per workgroup; histories [maxit+2]
     double tol;
@@ -175,6 +181,7 @@ struct PcgArgs {
     double *tot;                                       // [2][2] or nullptr: the two dot products summed once per launch by k_pcg_totals (many workgroups:
                                                        // every workgroup adding up all nwg partials itself is O(nwg^2) loads per iteration)
     CoarseArgs co;                                     // co.ng == 0: plain block-Jacobi
+    unsigned long long *stamps;                        // diagnostic build (make stamp, MI_BA_PCG_STAMPS=1): [it][16] wall-clock stamps of the first and the last workgroup of k_pcg_iter
 };
 
 // the whole reduced solve in one cooperative launch (kernels.hip k_pcg_persist): the scaled matrix in LDS, a grid barrier per iteration

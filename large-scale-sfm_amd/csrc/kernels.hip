@@ -1989,6 +1989,102 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_pairs(const Schu
     }
 }
 
+// The off-diagonal blocks whose two cameras lie in different groups of four consecutive cameras, by SUPER-BLOCK (plan.h sb_*): a work item is a
+// (row group, column group) pair = 4 x 4 blocks of S, its list holds one entry per point both groups see -- the point's records of the four
+// row cameras and of the four column cameras.  A round takes four entries: 32 records fetched once (96 lines) serve 64 pairs, where the pair
+// list above fetches 2 records (6 lines) for every pair -- the kernel above is bound by exactly that traffic (C4: 18.5 GB of record lines per
+// launch).  Lane = (entry of the round, row camera, column camera): one block per lane across the whole list as before; the four entries of a
+// round hold copies of the same block, summed through LDS at the end; a lane whose entry lacks one of its two cameras idles for the round.
+template <int CNP>
+__global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_super(const SchurArgs g)
+{
+    constexpr int BLK = CNP * CNP, ST = BLK | 1;
+    constexpr int SLOT = 26;                                        // doubles per record in the staging buffer: 3 lines (24) + 2 pad = 208 B
+    constexpr int NBUF = (32 * SLOT > 32 * ST) ? 32 * SLOT : 32 * ST;
+    __shared__ __attribute__((aligned(16))) double sBuf[NBUF];
+    if (g.spec && g.spec[0] == 0.0) return;
+    const int lane = threadIdx.x, w = blockIdx.x;                  // (the work items come sorted, the longest first)
+    const long long q0 = g.sb_q[w], q1 = g.sb_q[w + 1];
+    const int rounds = (int)((q1 - q0) >> 2);
+    const int *__restrict__ ent = g.sb_ent + 8 * q0;
+    // as a fetcher: record slot `quad` of each half of the round's 32 (two quads of one 8-lane ds_write_b128 group 8 slots = 32 banks apart), 16-byte piece
+    const int quad = ((lane >> 2) & 1) * 8 + (lane >> 3), piece = lane & 3;
+    const int line2 = (quad & 4) ? 2 : 3;                          // third line of a record: G (row side, slots 0-3 of an entry) or B (column side)
+    // as a pair: entry s of the round, row camera ja, column camera kb
+    const int s = lane >> 4, ja = (lane >> 2) & 3, kb = lane & 3;
+    double acc[BLK];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
+    int nA = ent[quad], nB = ent[16 + quad], nVa = ent[s * 8 + ja], nVb = ent[s * 8 + 4 + kb];
+    for (int r = 0; r < rounds; ++r) {
+        const int iA = nA, iB = nB, iVa = nVa, iVb = nVb;
+        if (r + 1 < rounds) {
+            const int *en = ent + (size_t)(r + 1) * 32;
+            nA = en[quad]; nB = en[16 + quad]; nVa = en[s * 8 + ja]; nVb = en[s * 8 + 4 + kb];
+        }
+        double2 st[6];
+        {
+            const double *ra = g.rec + (size_t)(iA < 0 ? 0 : iA) * kRec + piece * 2, *rb = g.rec + (size_t)(iB < 0 ? 0 : iB) * kRec + piece * 2;
+            st[0] = *reinterpret_cast<const double2 *>(ra); st[1] = *reinterpret_cast<const double2 *>(ra + 8); st[2] = *reinterpret_cast<const double2 *>(ra + line2 * 8);
+            st[3] = *reinterpret_cast<const double2 *>(rb); st[4] = *reinterpret_cast<const double2 *>(rb + 8); st[5] = *reinterpret_cast<const double2 *>(rb + line2 * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            *reinterpret_cast<double2 *>(sBuf + ((k / 3) * 16 + quad) * SLOT + (k % 3) * 8 + piece * 2) = st[k];
+        wave_lds_sync();
+        double Aa[16], Ab[16], G[6], Bb[6];
+        {
+            const double2 *ma = reinterpret_cast<const double2 *>(sBuf + (s * 8 + ja) * SLOT);
+            const double2 *mb = reinterpret_cast<const double2 *>(sBuf + (s * 8 + 4 + kb) * SLOT);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const double2 v = ma[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { const double2 v = ma[8 + t]; G[2 * t] = v.x; G[2 * t + 1] = v.y; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { const double2 v = mb[t]; Ab[2 * t] = v.x; Ab[2 * t + 1] = v.y; }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { const double2 v = mb[8 + t]; Bb[2 * t] = v.x; Bb[2 * t + 1] = v.y; }
+        }
+        wave_lds_sync();                                            // operands are in registers: the buffer is free for the next round
+        if (iVa >= 0 && iVb >= 0) {
+            const double M00 = -fma(G[2], Bb[2], fma(G[1], Bb[1], G[0] * Bb[0])), M01 = -fma(G[2], Bb[5], fma(G[1], Bb[4], G[0] * Bb[3]));
+            const double M10 = -fma(G[5], Bb[2], fma(G[4], Bb[1], G[3] * Bb[0])), M11 = -fma(G[5], Bb[5], fma(G[4], Bb[4], G[3] * Bb[3]));
+            double T0[CNP], T1[CNP];
+#pragma unroll
+            for (int c = 0; c < CNP; ++c) { T0[c] = fma(M01, Ab[8 + c], M00 * Ab[c]); T1[c] = fma(M11, Ab[8 + c], M10 * Ab[c]); }
+#pragma unroll
+            for (int rr = 0; rr < CNP; ++rr)
+#pragma unroll
+                for (int c = 0; c < CNP; ++c) acc[rr * CNP + c] = fma(Aa[8 + rr], T1[c], fma(Aa[rr], T0[c], acc[rr * CNP + c]));
+        }
+    }
+    // the four entries' copies of a block (lanes b, b + 16, b + 32, b + 48) -> one, in a fixed order: (0 + 2) + (1 + 3)
+    if (lane >= 32) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) sBuf[(lane - 32) * ST + i] = acc[i];
+    }
+    wave_lds_sync();
+    if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) acc[i] += sBuf[lane * ST + i];
+    }
+    wave_lds_sync();
+    if (lane >= 16 && lane < 32) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) sBuf[(lane - 16) * ST + i] = acc[i];
+    }
+    wave_lds_sync();
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) sBuf[lane * ST + i] = acc[i] + sBuf[lane * ST + i];
+    }
+    wave_lds_sync();
+    for (int b = 0; b < 16; ++b) {
+        const int gb = g.sb_blk[(size_t)w * 16 + b];
+        if (gb >= 0 && lane < BLK) g.S_up[(size_t)gb * (kCP * kCP) + (lane / CNP) * kCP + (lane % CNP)] += sBuf[b * ST + lane];
+    }
+}
+
 template <int CNP>
 __global__ __launch_bounds__(256) void k_long_backsub(const LongArgs g)
 {
@@ -2321,8 +2417,8 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
 }
 
 // S~_jk = Linv_j S_jk Linv_k^T, one wavefront per block, lane (r,c); the block and the two factors go through LDS
-// f32out: the scaled matrix is stored in single precision instead (PcgArgs.S32: the CG then streams half the bytes; engine.cpp pcg_f32_)
-__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg, int f32out)
+// layout 1: the scaled matrix is stored in single precision instead (PcgArgs.S32: the CG then streams half the bytes; engine.cpp pcg_f32_)
+__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg, int layout)
 {
     __shared__ double sh[4][4][64];   // per wavefront: S, T = Linv_j S, Linv_j, Linv_k
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
@@ -2343,9 +2439,15 @@ __global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs
 #pragma unroll
     for (int a = 0; a < 8; ++a) o = fma(sh[wv][1][r * 8 + a], sh[wv][3][c * 8 + a], o);
     const double val = (j == k) ? (r == c ? 1.0 : 0.0) : o;   // the diagonal blocks are the identity by construction
-    // (single precision: element (r, c) at ((r & 3) * 4 + (c >> 1)) * 4 + (r >> 2) * 2 + (c & 1) -- a lane of the product then finds rows r and r + 4,
-    // columns c, c + 1 in ONE 16-byte load and needs one 16-byte piece of the vector for them: row_products)
-    if (live) { if (f32out) reinterpret_cast<float *>(S_pcg)[(size_t)b * 64 + (((r & 3) * 4 + (c >> 1)) * 4 + (r >> 2) * 2 + (c & 1))] = (float)val; else S_pcg[(size_t)b * 64 + lane] = val; }
+    // The product's column forms (row_products): a lane of the product holds ONE column's elements of a few rows and needs one 8-byte element of
+    // the vector for them -- half the vector-load traffic of a row-major piece (the product is bound by the rate at which a CU takes load
+    // instructions).  f64 (layout 2): element (r, c) at ((r >> 1) * 8 + c) * 2 + (r & 1) -- rows 2h, 2h + 1 of column c in one 16-byte load.
+    // Single precision (layout 1): at ((r >> 2) * 8 + c) * 4 + (r & 3) -- rows 4h .. 4h + 3 of column c in one 16-byte load.
+    if (live) {
+        if (layout == 1) reinterpret_cast<float *>(S_pcg)[(size_t)b * 64 + (((r >> 2) * 8 + c) * 4 + (r & 3))] = (float)val;
+        else if (layout == 2) S_pcg[(size_t)b * 64 + (((r >> 1) * 8 + c) * 2 + (r & 1))] = val;
+        else S_pcg[(size_t)b * 64 + lane] = val;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2419,23 +2521,22 @@ __device__ __forceinline__ void publish_partials(const PcgArgs &a, int slot, dou
 // 208 MB; sixteen loads per wavefront instead of eight: slower, C4 2.70 -> 3.91 ms per solve).  The sum over the four lanes of a row by two DPP moves, the two halves by a cross-half read; the result is left
 // where the callers expect it: row r's value in all lanes 8r .. 8r + 7.
 template <int NV>
-__device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, int stride, int lane, const double *const (&vec)[NV], double (&out)[NV])
+__device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, int stride, int lane, const double *const (&vec)[NV], double (&out)[NV], const double *mbox = nullptr)
 {
     double acc[NV][2];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v][0] = acc[v][1] = 0.0;
     if (a.S32) {
         // The matrix in single precision (large systems: vectors, sums and the recurrences stay f64).  One wave load = 16 B per lane = FOUR
-        // 8 x 8 blocks: the quarter-wave lane >> 4 takes every fourth block of the row; lane (r', column pair) of a quarter holds elements
-        // (r', c), (r', c + 1), (r' + 4, c), (r' + 4, c + 1) (k_scale_blocks' layout) and multiplies them with ONE 16-byte piece of the vector --
-        // the same vector traffic per block as the f64 form, half the matrix bytes.
+        // 8 x 8 blocks: the quarter-wave lane >> 4 takes every fourth block of the row; lane (h, c) of a quarter holds rows 4h .. 4h + 3 of
+        // column c (k_scale_blocks' layout 1) and multiplies them with ONE 8-byte element of the vector.
         const float *__restrict__ Sf = a.S32;
-        const int quarter = lane >> 4, li = lane & 15, c2f = (li & 3) * 2;
+        const int quarter = lane >> 4, li = lane & 15, cf = li & 7;
         const int st4 = 4 * stride;
         int q = qb + quarter * stride;
-        double hi[NV][2];
+        double ac[NV][4];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) hi[v][0] = hi[v][1] = 0.0;
+        for (int v = 0; v < NV; ++v) ac[v][0] = ac[v][1] = ac[v][2] = ac[v][3] = 0.0;
         int kn[8];                                     // column indices, one chunk ahead (see the f64 form below)
         if (q + 7 * st4 < qe) {
 #pragma unroll
@@ -2446,7 +2547,7 @@ __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, i
             float4 sv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                k[u] = kn[u] * 8 + c2f;
+                k[u] = kn[u] * 8 + cf;
                 sv[u] = *reinterpret_cast<const float4 *>(Sf + (size_t)(q + u * st4) * 64 + li * 4);
             }
             if (q + 15 * st4 < qe) {
@@ -2455,36 +2556,133 @@ __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, i
             }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                double2 x[8];
+                double x[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const double2 *>(vec[v] + k[u]);
+                for (int u = 0; u < 8; ++u) x[u] = vec[v][k[u]];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    acc[v][u & 1] = fma((double)sv[u].y, x[u].y, fma((double)sv[u].x, x[u].x, acc[v][u & 1]));
-                    hi[v][u & 1] = fma((double)sv[u].w, x[u].y, fma((double)sv[u].z, x[u].x, hi[v][u & 1]));
+                    ac[v][0] = fma((double)sv[u].x, x[u], ac[v][0]); ac[v][1] = fma((double)sv[u].y, x[u], ac[v][1]);
+                    ac[v][2] = fma((double)sv[u].z, x[u], ac[v][2]); ac[v][3] = fma((double)sv[u].w, x[u], ac[v][3]);
                 }
             }
         }
         for (; q < qe; q += st4) {
-            const int k = a.bsr_col[q] * 8 + c2f;
+            const int k = a.bsr_col[q] * 8 + cf;
             const float4 sv = *reinterpret_cast<const float4 *>(Sf + (size_t)q * 64 + li * 4);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const double2 x = *reinterpret_cast<const double2 *>(vec[v] + k);
-                acc[v][0] = fma((double)sv.y, x.y, fma((double)sv.x, x.x, acc[v][0]));
-                hi[v][0] = fma((double)sv.w, x.y, fma((double)sv.z, x.x, hi[v][0]));
+                const double x = vec[v][k];
+                ac[v][0] = fma((double)sv.x, x, ac[v][0]); ac[v][1] = fma((double)sv.y, x, ac[v][1]);
+                ac[v][2] = fma((double)sv.z, x, ac[v][2]); ac[v][3] = fma((double)sv.w, x, ac[v][3]);
             }
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            double tl = acc[v][0] + acc[v][1], th = hi[v][0] + hi[v][1];
-            tl += dpp_move<0xB1>(tl); tl += dpp_move<0x4E>(tl);        // the 4 lanes of a row pair (quad permutes)
-            th += dpp_move<0xB1>(th); th += dpp_move<0x4E>(th);
-            tl += __shfl_xor(tl, 16); tl += __shfl_xor(tl, 32);       // the four quarters' blocks
-            th += __shfl_xor(th, 16); th += __shfl_xor(th, 32);
-            const int rr = lane >> 3;                                 // row r: rows 0..3 from tl of quad r, rows 4..7 from th of quad r - 4
-            const double a_lo = __shfl(tl, (rr & 3) * 4), a_hi = __shfl(th, (rr & 3) * 4);
-            out[v] = rr < 4 ? a_lo : a_hi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                             // over the eight columns: the lanes h * 8 .. h * 8 + 7
+                double t = ac[v][i];
+                t += dpp_move<0xB1>(t); t += dpp_move<0x4E>(t); t += dpp_move<0x141>(t);
+                ac[v][i] = t;
+            }
+            const int i = cf & 3;                                     // lane (h, c) keeps row 4h + (c & 3)
+            double t = i == 0 ? ac[v][0] : i == 1 ? ac[v][1] : i == 2 ? ac[v][2] : ac[v][3];
+            t += __shfl_xor(t, 16); t += __shfl_xor(t, 32);           // the four quarters' blocks
+            const int rr = lane >> 3;                                 // row r: from lane (r >> 2, r & 3)
+            out[v] = __shfl(t, (rr >> 2) * 8 + (rr & 3));
+        }
+        return;
+    }
+    if (a.cm) {
+        // f64 in the column form (k_scale_blocks' layout 2): the half-wave lane >> 5 takes every second block of the row; lane (h, c) of a half
+        // holds rows 2h, 2h + 1 of column c (one 16-byte load) and needs ONE 8-byte element of the vector for them
+        const double *__restrict__ Sv = a.S;
+        const int half = lane >> 5, l5 = lane & 31, cc = l5 & 7;
+        int q = qb + half * stride;
+        const int st2 = 2 * stride;
+        double ac[NV][2][2];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) ac[v][0][0] = ac[v][0][1] = ac[v][1][0] = ac[v][1][1] = 0.0;
+        if (mbox) {
+            // the neighbours' vectors from this row's MAILBOXES (push_row): block q's 3 x 8 doubles sit at 24 q -- no column index between the
+            // row pointer and the vector loads, which go out together with the matrix loads (one round of latency less per launch)
+            static_assert(NV == 3 || NV == 1, "mailboxes hold r | w | s");
+            for (; q + 7 * st2 < qe; q += 8 * st2) {
+                double2 sv[8];
+                double x[NV][8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    sv[u] = *reinterpret_cast<const double2 *>(Sv + (size_t)(q + u * st2) * 64 + l5 * 2);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) x[v][u] = mbox[(size_t)(q + u * st2) * 24 + v * 8 + cc];
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { ac[v][0][u & 1] = fma(sv[u].x, x[v][u], ac[v][0][u & 1]); ac[v][1][u & 1] = fma(sv[u].y, x[v][u], ac[v][1][u & 1]); }
+            }
+            if (q < qe) {                                             // the rest of the row: up to seven blocks, all requested at once
+                double2 sv[7];
+                double x[NV][7];
+#pragma unroll
+                for (int u = 0; u < 7; ++u) {
+                    const bool on = q + u * st2 < qe;
+                    const int qq = on ? q + u * st2 : q;
+                    sv[u] = *reinterpret_cast<const double2 *>(Sv + (size_t)qq * 64 + l5 * 2);
+                    if (!on) sv[u] = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) x[v][u] = mbox[(size_t)qq * 24 + v * 8 + cc];
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int u = 0; u < 7; ++u) { ac[v][0][u & 1] = fma(sv[u].x, x[v][u], ac[v][0][u & 1]); ac[v][1][u & 1] = fma(sv[u].y, x[v][u], ac[v][1][u & 1]); }
+            }
+        } else {
+        int kn[8];
+        if (q + 7 * st2 < qe) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kn[u] = a.bsr_col[q + u * st2];
+        }
+        for (; q + 7 * st2 < qe; q += 8 * st2) {
+            int k[8];
+            double2 sv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                k[u] = kn[u] * 8 + cc;
+                sv[u] = *reinterpret_cast<const double2 *>(Sv + (size_t)(q + u * st2) * 64 + l5 * 2);
+            }
+            if (q + 15 * st2 < qe) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kn[u] = a.bsr_col[q + (8 + u) * st2];
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = vec[v][k[u]];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { ac[v][0][u & 1] = fma(sv[u].x, x[u], ac[v][0][u & 1]); ac[v][1][u & 1] = fma(sv[u].y, x[u], ac[v][1][u & 1]); }
+            }
+        }
+        for (; q < qe; q += st2) {
+            const int k = a.bsr_col[q] * 8 + cc;
+            const double2 sv = *reinterpret_cast<const double2 *>(Sv + (size_t)q * 64 + l5 * 2);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double x = vec[v][k];
+                ac[v][0][0] = fma(sv.x, x, ac[v][0][0]); ac[v][1][0] = fma(sv.y, x, ac[v][1][0]);
+            }
+        }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double t0 = ac[v][0][0] + ac[v][0][1], t1 = ac[v][1][0] + ac[v][1][1];
+            t0 += dpp_move<0xB1>(t0); t0 += dpp_move<0x4E>(t0); t0 += dpp_move<0x141>(t0);   // over the eight columns: the lanes h * 8 .. h * 8 + 7
+            t1 += dpp_move<0xB1>(t1); t1 += dpp_move<0x4E>(t1); t1 += dpp_move<0x141>(t1);
+            double t = (cc & 1) ? t1 : t0;                            // lane (h, c) keeps row 2h + (c & 1)
+            t += __shfl_xor(t, 32);                                   // even + odd blocks
+            const int rr = lane >> 3;                                 // row r: from lane (r >> 1, r & 1)
+            out[v] = __shfl(t, (rr >> 1) * 8 + (rr & 1));
         }
         return;
     }
@@ -2538,19 +2736,41 @@ __device__ __forceinline__ void row_products(const PcgArgs &a, int qb, int qe, i
     }
 }
 
+// Push halo (PcgArgs.mb0 / mb1): a block row leaves its new r | w | s (3 x 8 doubles) in the mailbox of every block row that multiplies with
+// them -- position bsr_tq[q] of its own blocks q (the pattern is symmetric) -- so that the readers' vector loads need no column index.
+// The row's `nparts` wavefronts take its blocks in turn; lane = (block of eight, element e), the element's value sits in lane 8 e.
+__device__ __forceinline__ void push_row(const PcgArgs &a, double *__restrict__ mb, int q0, int q1, int part, int nparts, int lane, int tq_first, double rv, double wv, double sv)
+{
+    const int e = lane & 7;
+    const double re = __shfl(rv, e * 8), we = __shfl(wv, e * 8), se = __shfl(sv, e * 8);
+    int q = q0 + part * 8 + (lane >> 3), tq = tq_first;
+    while (q < q1) {
+        double *dst = mb + (size_t)tq * 24 + e;
+        dst[0] = re; dst[8] = we; dst[16] = se;
+        q += 8 * nparts;
+        if (q < q1) tq = a.bsr_tq[q];
+    }
+}
+// (the first mailbox position of a lane, requested early: with the row pointers)
+__device__ __forceinline__ int push_first(const PcgArgs &a, int q0, int q1, int part, int lane)
+{
+    const int q = q0 + part * 8 + (lane >> 3);
+    return q < q1 ? a.bsr_tq[q] : 0;
+}
+
 // ROWS = 4: four block rows per workgroup, WPR wavefronts each: 2 while the rows are short (C3, 37 blocks a row: the launch is
 // rounds of latency, and half a row per wavefront shortens the longest one: 0.31 -> 0.25 ms per solve; four: no better), 1 for long
 // rows (C4, 239 blocks a row: bound by the rate the 208 MB stream in; two: 2.68 -> 2.90 ms).  ROWS = 1 (few cameras: fewer block rows than the chip has CUs): the four
 // wavefronts of a workgroup share one row.  Wavefronts that share a row take its blocks in turn and add up through LDS in a
 // fixed order -- the result is in the row's first wavefront.  Returns whether this wavefront holds a row's finished products.
 template <int ROWS, int NV, int WPR = 1>
-__device__ __forceinline__ bool workgroup_row_products(const PcgArgs &a, int q0, int q1, const double *const (&vec)[NV], double (&out)[NV], double (*red)[NV][8])
+__device__ __forceinline__ bool workgroup_row_products(const PcgArgs &a, int q0, int q1, const double *const (&vec)[NV], double (&out)[NV], double (*red)[NV][8], const double *mbox = nullptr)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (ROWS == 4 && WPR == 1) { row_products<NV>(a, q0, q1, 1, lane, vec, out); return true; }
+    if (ROWS == 4 && WPR == 1) { row_products<NV>(a, q0, q1, 1, lane, vec, out, mbox); return true; }
     constexpr int SH = ROWS == 4 ? WPR : 4;         // wavefronts per row
     const int part = wv % SH, first = wv - part;
-    row_products<NV>(a, q0 + part, q1, SH, lane, vec, out);
+    row_products<NV>(a, q0 + part, q1, SH, lane, vec, out, mbox);
     if ((lane & 7) == 0) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) red[wv][v][lane >> 3] = out[v];
@@ -2576,13 +2796,17 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_start(const PcgArgs a)
     const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
     const double *const vec[1] = { a.r0 };
     double w[1];
-    const bool mine = workgroup_row_products<ROWS, 1, WPR>(a, q0, q1, vec, w, red);
+    constexpr int SH = ROWS == 4 ? WPR : 4;
+    const int part = (threadIdx.x >> 6) % SH;
+    const int tq_first = a.mb0 ? push_first(a, q0, q1, part, lane) : 0;
+    const bool mine = workgroup_row_products<ROWS, 1, WPR>(a, q0, q1, vec, w, red);      // (by column index: the mailboxes are filled below)
     double g = 0.0, d = 0.0;
+    const double rr = a.r0[jj * 8 + r];
     if (live && mine && c == 0) {
-        const double rr = a.r0[j * 8 + r];
         a.w0[j * 8 + r] = w[0];
         g = rr * rr; d = w[0] * rr;
     }
+    if (a.mb0 && live) push_row(a, a.mb0, q0, q1, part, SH, lane, tq_first, rr, w[0], 0.0);   // what iteration 0 reads: r_0 | w_0 | s_-1 = 0
     publish_partials<4 * WPR>(a, 0, g, d, sh);
 }
 
@@ -2993,9 +3217,15 @@ __global__ __launch_bounds__(256) void k_pcg_totals(const PcgArgs a, int slot)
     if (threadIdx.x == 0) { a.tot[slot * 2] = sg[0]; a.tot[slot * 2 + 1] = sd[0]; }
 }
 
+#ifdef MIBA_STAMPS
+#define PSTAMP(i) do { if (a.stamps && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) a.stamps[(size_t)a.it * 16 + (blockIdx.x ? 8 : 0) + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define PSTAMP(i)
+#endif
 template <int ROWS, int WPR = 1>
 __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
 {
+    PSTAMP(0);
     __shared__ double sh[4 * WPR][2];
     __shared__ double red[4 * WPR][3][8];
     constexpr bool kOwn = ROWS == 4 && WPR == 1;     // every wavefront works for itself: no barrier, no shared totals
@@ -3017,7 +3247,11 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
     const double g_prev = a.rz_hist[prev], g_zero = a.rz_hist[0], a_prev = a.alpha_hist[prev];
     const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
     const double r_own = rc[idx], w_own = wc[idx], s_own = so[idx], p_own = a.p[idx], x_own = a.x[idx];
+    constexpr int SH = ROWS == 4 ? WPR : 4;
+    const int part = (threadIdx.x >> 6) % SH;
+    const int tq_first = a.mb0 ? push_first(a, q0, q1, part, lane) : 0;
     if (st != 0.0 || dn != 0.0) return;
+    PSTAMP(1);
     // rounds 2 and 3
     const double *const vec[3] = { rc, wc, so };
     double S3[3];
@@ -3025,7 +3259,8 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
         const double gsum = wave_sum(gs), dsum = wave_sum(ds);
         if (lane == 0) { sgd[0] = gsum; sgd[1] = dsum; }
     }
-    const bool mine = workgroup_row_products<ROWS, 3, WPR>(a, q0, q1, vec, S3, red);
+    const bool mine = workgroup_row_products<ROWS, 3, WPR>(a, q0, q1, vec, S3, red, a.mb0 ? (par ? a.mb1 : a.mb0) : nullptr);
+    PSTAMP(2);
     const double gamma = kOwn ? wave_sum(gs) : sgd[0], delta = kOwn ? wave_sum(ds) : sgd[1];
     const bool first = blockIdx.x == 0 && threadIdx.x == 0;
     if (first) a.rz_hist[a.it] = gamma;
@@ -3043,16 +3278,19 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
     const double alpha = gamma / den;
     double *rn = par ? a.r0 : a.r1, *wn = par ? a.w0 : a.w1, *sn = par ? a.s0 : a.s1;
     double g = 0.0, d = 0.0;
+    const double s_new = fma(beta, s_own, w_own), r_new = fma(-alpha, s_new, r_own), w_new = fma(-alpha, fma(beta, S3[2], S3[1]), S3[0]);
     if (live && mine && c == 0) {
-        const double s_new = fma(beta, s_own, w_own), r_new = fma(-alpha, s_new, r_own), p_new = fma(beta, p_own, r_own);
-        const double w_new = fma(-alpha, fma(beta, S3[2], S3[1]), S3[0]);
+        const double p_new = fma(beta, p_own, r_own);
         sn[idx] = s_new; rn[idx] = r_new; wn[idx] = w_new;
         a.p[idx] = p_new;
         a.x[idx] = fma(alpha, p_new, x_own);
         g = r_new * r_new; d = w_new * r_new;
     }
+    if (a.mb0 && live) push_row(a, par ? a.mb0 : a.mb1, q0, q1, part, SH, lane, tq_first, r_new, w_new, s_new);   // (every wavefront of the row holds the sums)
+    PSTAMP(3);
     publish_partials<4 * WPR>(a, par ^ 1, g, d, sh);
     if (first) { a.alpha_hist[a.it] = alpha; a.scal[SC_PCG_ITERS] = (double)(a.it + 1); }
+    PSTAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3776,7 +4014,7 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
     hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
-    hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg, ps.f32 ? 1 : 0);
+    hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg, ps.layout);
     if (co.ng) {   // the coarse space of this trial's system: Z'SZ, its inverse, S~Z~
         static_assert(kBcSlots == 4, "k_coarse_bc: one wavefront per slot");
         hipLaunchKernelGGL(k_coarse_bc, dim3(m), dim3(256), 0, st, m, bsr_row, bsr_col, (const double *)S_pcg, co);
@@ -3982,6 +4220,7 @@ static void launch_schur_blocks_t(hipStream_t st, const SchurArgs &a)
         if (direct) hipLaunchKernelGGL((k_schur_blocks<CNP, false>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_schur_pairs<CNP>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
     }
+    if (a.nsuper > 0) hipLaunchKernelGGL((k_schur_super<CNP>), dim3(a.nsuper), dim3(64), 0, st, a);
 }
 
 void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a)

@@ -665,9 +665,43 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         const int nbu = pl.nb_up();
         const int nrow = npl - t_rows;
         const int nt = nrow < (1 << 14) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-        std::vector<std::vector<int>> cnt(nt, std::vector<int>(nrow ? nbu : 0, 0));
+        // super-blocks: decided on the pair count (every pair of observations of a row point)
+        bool super = false;
+        {
+            int64_t np = 0;
+            for (int tt = t_rows; tt < npl; ++tt) { const int64_t d = pl.pt_obs[tt + 1] - pl.pt_obs[tt]; np += d * (d - 1) / 2; }
+            const char *env = std::getenv("MI_BA_SUPER");
+            super = !cam_split && (env ? std::atoi(env) != 0 : np >= kSuperMinPairs);
+        }
+        constexpr int GS = kSuperCams;
+        const int ngrp = (m + GS - 1) / GS;
+        // the group pairs with a block in the pattern: sup_row / sup_col (CSR over row groups, column groups ascending, the diagonal group pair left out)
+        std::vector<int> sup_row(ngrp + 1, 0), sup_col;
+        if (super) {
+            std::vector<int> mark(ngrp, -1);
+            for (int G = 0; G < ngrp; ++G) {
+                std::vector<int> cols;
+                for (int j = G * GS; j < std::min(m, (G + 1) * GS); ++j)
+                    for (int q = pl.up_row[j]; q < pl.up_row[j + 1]; ++q) {
+                        const int H = pl.up_col[q] / GS;
+                        if (H != G && mark[H] != G) { mark[H] = G; cols.push_back(H); }
+                    }
+                std::sort(cols.begin(), cols.end());
+                sup_col.insert(sup_col.end(), cols.begin(), cols.end());
+                sup_row[G + 1] = (int)sup_col.size();
+            }
+        }
+        const int nsup = (int)sup_col.size();
+        auto sup_of = [&](int G, int H) {
+            const int *b = sup_col.data() + sup_row[G], *e = sup_col.data() + sup_row[G + 1];
+            const int *it = std::lower_bound(b, e, H);
+            return (it == e || *it != H) ? -1 : (int)(it - sup_col.data());
+        };
+        std::vector<std::vector<int>> cnt(nt, std::vector<int>(nrow ? nbu : 0, 0)), scnt(nt, std::vector<int>(nrow ? nsup : 0, 0));
+        std::vector<int64_t> spairs(nt, 0);
+        std::vector<int64_t> sbase;                       // super-block s's entries start at sbase[s] (filled before the second pass)
         std::atomic<bool> missing(false);
-        auto walk = [&](int k, bool fill_pass, std::vector<int64_t> *pos) {
+        auto walk = [&](int k, bool fill_pass, std::vector<int64_t> *pos, std::vector<int64_t> *spos) {
             const int b0 = t_rows + (int)((int64_t)nrow * k / nt), b1 = t_rows + (int)((int64_t)nrow * (k + 1) / nt);
             for (int tt = b0; tt < b1; ++tt) {
                 const int os = pl.pt_obs[tt], d = pl.pt_obs[tt + 1] - os;
@@ -676,6 +710,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                     const int *rb = pl.up_col.data() + pl.up_row[c[a]], *re = pl.up_col.data() + pl.up_row[c[a] + 1];
                     const int *it = rb;
                     for (int b = a + 1; b < d; ++b) {
+                        if (super && c[b] / GS != c[a] / GS) break;          // (cameras ascend: every later one is in another group too) -> the entries below
                         it = std::lower_bound(it, re, c[b]);             // cameras ascend inside a point: the search only moves right
                         if (it == re || *it != c[b]) { missing = true; return; }
                         const int g = (int)(it - pl.up_col.data());
@@ -686,6 +721,26 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                         }
                     }
                 }
+                if (!super) continue;
+                // the point's runs of observations by camera group, and one entry per pair of runs
+                for (int a0 = 0; a0 < d;) {
+                    int a1 = a0 + 1;
+                    while (a1 < d && c[a1] / GS == c[a0] / GS) ++a1;
+                    for (int e0 = a1; e0 < d;) {
+                        int e1 = e0 + 1;
+                        while (e1 < d && c[e1] / GS == c[e0] / GS) ++e1;
+                        const int sidx = sup_of(c[a0] / GS, c[e0] / GS);
+                        if (sidx < 0) { missing = true; return; }
+                        if (!fill_pass) { scnt[k][sidx]++; spairs[k] += (int64_t)(a1 - a0) * (e1 - e0); }
+                        else {
+                            int32_t *ent = pl.sb_ent.data() + 2 * GS * (size_t)(*spos)[sidx]++;
+                            for (int x = a0; x < a1; ++x) ent[c[x] % GS] = pl.obs_rec[os + x];
+                            for (int x = e0; x < e1; ++x) ent[GS + c[x] % GS] = pl.obs_rec[os + x];
+                        }
+                        e0 = e1;
+                    }
+                    a0 = a1;
+                }
             }
         };
         auto run_threads = [&](const std::function<void(int)> &fn) {
@@ -694,18 +749,47 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             for (int k = 0; k < nt; ++k) th.emplace_back(fn, k);
             for (auto &x : th) x.join();
         };
-        if (nrow) run_threads([&](int k) { walk(k, false, nullptr); });
+        if (nrow) run_threads([&](int k) { walk(k, false, nullptr, nullptr); });
         if (missing) return "internal: block missing from pattern";
         // block g's pairs: [base[g], base[g + 1]), thread k's share of them after the shares of the threads before it
         std::vector<int64_t> base(nbu + 1, 0);
-        std::vector<std::vector<int64_t>> pos(nt);
+        std::vector<std::vector<int64_t>> pos(nt), spos(nt);
         if (nrow) {
             for (int g = 0; g < nbu; ++g) { int64_t tot = 0; for (int k = 0; k < nt; ++k) tot += cnt[k][g]; base[g + 1] = base[g] + tot; }
             for (int k = 0; k < nt; ++k) pos[k].resize(nbu);
             for (int g = 0; g < nbu; ++g) { int64_t at = base[g]; for (int k = 0; k < nt; ++k) { pos[k][g] = at; at += cnt[k][g]; } }
         }
+        pl.sb_blk.clear(); pl.sb_q.assign(1, 0); pl.sb_ent.clear(); pl.nsuper_pairs = 0;
+        if (nrow && super) {
+            // work items in the order of falling entry counts (one wavefront each, dealt to the chip in this order: the long ones first)
+            std::vector<int64_t> tot(nsup, 0);
+            for (int s2 = 0; s2 < nsup; ++s2) for (int k = 0; k < nt; ++k) tot[s2] += scnt[k][s2];
+            std::vector<int> order;
+            for (int s2 = 0; s2 < nsup; ++s2) if (tot[s2] > 0) order.push_back(s2);
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return tot[x] > tot[y]; });
+            std::vector<int> grp_of(nsup);
+            for (int G = 0; G < ngrp; ++G) for (int q = sup_row[G]; q < sup_row[G + 1]; ++q) grp_of[q] = G;
+            sbase.assign(nsup, 0);
+            int64_t at = 0;
+            for (int s2 : order) {
+                sbase[s2] = at;
+                at += (tot[s2] + 3) / 4 * 4;
+                pl.sb_q.push_back(at);
+                const int G = grp_of[s2], H = sup_col[s2];
+                for (int ja = 0; ja < GS; ++ja)
+                    for (int kb = 0; kb < GS; ++kb) {
+                        const int j = G * GS + ja, k2 = H * GS + kb;
+                        pl.sb_blk.push_back(j < m && k2 < m ? pl.upper_block(j, k2) : -1);
+                    }
+            }
+            pl.sb_ent.assign((size_t)(2 * GS * at), -1);
+            for (int k = 0; k < nt; ++k) spos[k].assign(nsup, 0);
+            for (int s2 = 0; s2 < nsup; ++s2) { int64_t a2 = sbase[s2]; for (int k = 0; k < nt; ++k) { spos[k][s2] = a2; a2 += scnt[k][s2]; } }
+            for (int k = 0; k < nt; ++k) pl.nsuper_pairs += spairs[k];
+        }
         pl.rpair.assign((size_t)(2 * base[nbu]), 0u);
-        if (nrow) run_threads([&](int k) { walk(k, true, &pos[k]); });
+        if (nrow) run_threads([&](int k) { walk(k, true, &pos[k], &spos[k]); });
+        if (missing) return "internal: block missing from pattern";
         pl.wk_blk.clear(); pl.wk_q.assign(1, 0); pl.wk_diag_cam.clear(); pl.wk_diag_blk.clear();
         for (int g = 0; g < nbu; ++g)
             if (base[g + 1] > base[g]) { pl.wk_blk.push_back(g); pl.wk_q.push_back(base[g + 1]); }

@@ -66,6 +66,8 @@ constexpr int kMinRunPts = 12;          // a camera set shared by fewer consecut
                                         // handed to HBM once per run (49 f64 atomics per block, ~120 G elements/s chip-wide), the row path costs ~2.5x the
                                         // per-point work and no atomics; break-even ~14 points.  MI_BA_MIN_RUN_PTS overrides (probes);
                                         // mi_ba_config.deterministic sends EVERY point down the row path
+constexpr int kSuperCams = 4;             // cameras per side of a super-block (plan.h sb_blk; k_schur_super: lane = (entry of the round, row camera, column camera))
+constexpr int64_t kSuperMinPairs = 1 << 20; // row-path pairs from which the super-blocks are worth their tables
 constexpr int kRec = 32;                // doubles per observation record: A (2 x 8) | B (6) | e (2) | G = B V*^-1 (6) | e - B h (2)
 constexpr int kRec9 = 36;               // the same with nine camera parameters: A (2 x 10)
 constexpr int kCP = 8;           // padded camera block dimension (cnp <= 8)
@@ -109,6 +111,14 @@ struct Plan {
     std::vector<int64_t> wk_q;                       // ... and its pairs rpair[2 wk_q[w] .. 2 wk_q[w+1])
     std::vector<uint32_t> rpair;                     // per pair: record of the row camera's observation, record of the column camera's
     std::vector<int> wk_diag_cam, wk_diag_blk;       // diagonal work items: cameras with records, and their diagonal block
+    // super-blocks (k_schur_super): the pairs whose two cameras lie in DIFFERENT groups of kSuperCams consecutive cameras leave the per-block lists
+    // above; work item w = (row group, column group) owns the kSuperCams^2 blocks sb_blk[16 w ..] (-1: not in the pattern) and, per point that
+    // both groups see, one ENTRY of 2 kSuperCams records (the point's records of the row group's cameras, then of the column group's; -1 =
+    // none) -- a record is fetched once per entry and serves up to four pairs, where a pair list fetches both of its records per pair
+    std::vector<int> sb_blk;
+    std::vector<int64_t> sb_q;                       // work item w's entries sb_ent[8 sb_q[w] .. 8 sb_q[w + 1]): a multiple of four (padded with all -1)
+    std::vector<int32_t> sb_ent;
+    int64_t nsuper_pairs = 0;                        // pairs the entries stand for
     std::vector<int> wk_vblk, wk_diag_vblk;          // cam_split: 4 virtual blocks per work item: (2a,2b) (2a,2b+1) (2a+1,2b) (2a+1,2b+1)
     int64_t nrow_pts = 0;                            // points on the row path (long ones included)
     int ntile_lds = 0, nbatch_lds = 0;

@@ -1051,3 +1051,26 @@ def test_reduced_solve_with_the_scaled_matrix_in_single_precision(oracle, monkey
     eng.run()
     assert eng.timing()["pcg_matrix_f32"] == 0.0
     eng.close()
+
+
+def test_reduced_solve_with_pushed_vectors(monkeypatch):
+    """MI_BA_PCG_PUSH=1 (opt-in: measured slower, engine.cpp prepare): every block row leaves its new r | w | s in a mailbox per neighbouring row
+    (kernels.hip push_row) and the product reads them by block position instead of gathering by column index -- the same sums in the same
+    order, so the same iterates as the default to rounding, on a workgroup-per-row scene (C1) and a wavefront-per-row one (1 000 cameras)"""
+    scenes = [scene_from_golden("C1")[0], pkg("scene").make_scene("x", m=1000, n=20000, d=6, seed=4, strides=(1, 3))]
+    for sc in scenes:
+        res = {}
+        for mode in ("gather", "push"):
+            if mode == "push":
+                monkeypatch.setenv("MI_BA_PCG_PUSH", "1")
+            else:
+                monkeypatch.delenv("MI_BA_PCG_PUSH", raising=False)
+            eng = make_engine(sc, itmax=6)
+            ret, info = eng.run()
+            res[mode] = (ret, np.array(info), eng.trace().copy(), eng.params()[0].copy(), eng.timing()["pcg_push"])
+            eng.close()
+        assert res["push"][4] == 1.0 and res["gather"][4] == 0.0
+        assert res["push"][0] == res["gather"][0] and np.array_equal(res["push"][2][:, 5], res["gather"][2][:, 5])       # CG iterations per trial
+        assert np.allclose(res["push"][2][:, 3], res["gather"][2][:, 3], rtol=1e-12)                                     # trial costs
+        assert np.allclose(res["push"][3], res["gather"][3], rtol=0, atol=1e-10 * np.abs(res["gather"][3]).max())
+
