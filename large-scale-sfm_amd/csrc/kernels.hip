@@ -2015,22 +2015,24 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_super(const Schu
     double acc[BLK];
 #pragma unroll
     for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
-    int nA = ent[quad], nB = ent[16 + quad], nVa = ent[s * 8 + ja], nVb = ent[s * 8 + 4 + kb];
+    // the pipeline: record ids two rounds ahead, the records themselves one round ahead (in flight through the arithmetic of the round before)
+#define MIBA_SUPER_FETCH(iA, iB)                                                                                                             \
+    do {                                                                                                                                     \
+        const double *ra_ = g.rec + (size_t)((iA) < 0 ? 0 : (iA)) * kRec + piece * 2, *rb_ = g.rec + (size_t)((iB) < 0 ? 0 : (iB)) * kRec + piece * 2; \
+        st0 = *reinterpret_cast<const double2 *>(ra_); st1 = *reinterpret_cast<const double2 *>(ra_ + 8); st2 = *reinterpret_cast<const double2 *>(ra_ + line2 * 8); \
+        st3 = *reinterpret_cast<const double2 *>(rb_); st4 = *reinterpret_cast<const double2 *>(rb_ + 8); st5 = *reinterpret_cast<const double2 *>(rb_ + line2 * 8); \
+    } while (0)
+    double2 st0, st1, st2, st3, st4, st5;
+    int vA = ent[s * 8 + ja], vB = ent[s * 8 + 4 + kb];            // this round's pair: both records there?
+    MIBA_SUPER_FETCH(ent[quad], ent[16 + quad]);
+    int nA = 0, nB = 0, nVa = -1, nVb = -1;
+    if (rounds > 1) { nA = ent[32 + quad]; nB = ent[48 + quad]; nVa = ent[32 + s * 8 + ja]; nVb = ent[32 + s * 8 + 4 + kb]; }
     for (int r = 0; r < rounds; ++r) {
-        const int iA = nA, iB = nB, iVa = nVa, iVb = nVb;
-        if (r + 1 < rounds) {
-            const int *en = ent + (size_t)(r + 1) * 32;
-            nA = en[quad]; nB = en[16 + quad]; nVa = en[s * 8 + ja]; nVb = en[s * 8 + 4 + kb];
-        }
-        double2 st[6];
         {
-            const double *ra = g.rec + (size_t)(iA < 0 ? 0 : iA) * kRec + piece * 2, *rb = g.rec + (size_t)(iB < 0 ? 0 : iB) * kRec + piece * 2;
-            st[0] = *reinterpret_cast<const double2 *>(ra); st[1] = *reinterpret_cast<const double2 *>(ra + 8); st[2] = *reinterpret_cast<const double2 *>(ra + line2 * 8);
-            st[3] = *reinterpret_cast<const double2 *>(rb); st[4] = *reinterpret_cast<const double2 *>(rb + 8); st[5] = *reinterpret_cast<const double2 *>(rb + line2 * 8);
+            double *d0 = sBuf + quad * SLOT + piece * 2, *d1 = sBuf + (16 + quad) * SLOT + piece * 2;
+            *reinterpret_cast<double2 *>(d0) = st0; *reinterpret_cast<double2 *>(d0 + 8) = st1; *reinterpret_cast<double2 *>(d0 + 16) = st2;
+            *reinterpret_cast<double2 *>(d1) = st3; *reinterpret_cast<double2 *>(d1 + 8) = st4; *reinterpret_cast<double2 *>(d1 + 16) = st5;
         }
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-            *reinterpret_cast<double2 *>(sBuf + ((k / 3) * 16 + quad) * SLOT + (k % 3) * 8 + piece * 2) = st[k];
         wave_lds_sync();
         double Aa[16], Ab[16], G[6], Bb[6];
         {
@@ -2046,7 +2048,16 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_super(const Schu
             for (int t = 0; t < 3; ++t) { const double2 v = mb[8 + t]; Bb[2 * t] = v.x; Bb[2 * t + 1] = v.y; }
         }
         wave_lds_sync();                                            // operands are in registers: the buffer is free for the next round
-        if (iVa >= 0 && iVb >= 0) {
+        const bool valid = vA >= 0 && vB >= 0;
+        if (r + 1 < rounds) {
+            MIBA_SUPER_FETCH(nA, nB);
+            vA = nVa; vB = nVb;
+            if (r + 2 < rounds) {
+                const int *en = ent + (size_t)(r + 2) * 32;
+                nA = en[quad]; nB = en[16 + quad]; nVa = en[s * 8 + ja]; nVb = en[s * 8 + 4 + kb];
+            }
+        }
+        if (valid) {
             const double M00 = -fma(G[2], Bb[2], fma(G[1], Bb[1], G[0] * Bb[0])), M01 = -fma(G[2], Bb[5], fma(G[1], Bb[4], G[0] * Bb[3]));
             const double M10 = -fma(G[5], Bb[2], fma(G[4], Bb[1], G[3] * Bb[0])), M11 = -fma(G[5], Bb[5], fma(G[4], Bb[4], G[3] * Bb[3]));
             double T0[CNP], T1[CNP];
@@ -2058,6 +2069,7 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_super(const Schu
                 for (int c = 0; c < CNP; ++c) acc[rr * CNP + c] = fma(Aa[8 + rr], T1[c], fma(Aa[rr], T0[c], acc[rr * CNP + c]));
         }
     }
+#undef MIBA_SUPER_FETCH
     // the four entries' copies of a block (lanes b, b + 16, b + 32, b + 48) -> one, in a fixed order: (0 + 2) + (1 + 3)
     if (lane >= 32) {
 #pragma unroll
