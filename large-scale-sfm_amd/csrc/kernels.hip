@@ -2428,37 +2428,63 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
     }
 }
 
-// S~_jk = Linv_j S_jk Linv_k^T, one wavefront per block, lane (r,c); the block and the two factors go through LDS
+// S~_jk = Linv_j S_jk Linv_k^T, a wavefront per block at a time, lane (r,c); the block and the two factors go through LDS.  The wavefronts of the
+// (chip-filling) grid walk the blocks in strides and keep TWO blocks ahead in flight -- the indices of the one after next (wave-uniform: scalar
+// loads), the element and the two factors of the next -- while they multiply the present one: a wavefront per block with nothing ahead was a
+// chain of two memory round trips and three LDS exchanges per block, 4.5 (C3) to 50 (C4) of them one after the other per wavefront slot
+// (C3 19.5 us, C4 184 us for 26 / 260 MB).  Diagonal blocks are the identity by construction: nothing is fetched for them.
 // layout 1: the scaled matrix is stored in single precision instead (PcgArgs.S32: the CG then streams half the bytes; engine.cpp pcg_f32_)
 __global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg, int layout)
 {
     __shared__ double sh[4][4][64];   // per wavefront: S, T = Linv_j S, Linv_j, Linv_k
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
-    const int b = blockIdx.x * 4 + wv;
-    const bool live = b < nb;
-    const int bb = live ? b : 0;
-    const int j = f.rowidx[bb], k = f.col[bb];
-    sh[wv][0][lane] = finalized_element(f, bb, lane);
-    sh[wv][2][lane] = Linv[(size_t)j * 64 + lane];
-    sh[wv][3][lane] = Linv[(size_t)k * 64 + lane];
-    wave_lds_sync();
-    double t = 0.0;                                   // T = Linv_j S
+    const int nw = (int)gridDim.x * 4;
+    int b = (int)blockIdx.x * 4 + wv;                 // (left a per-lane value on purpose: made wave-uniform, every index load is followed by a wait for its v_readfirstlane)
+    if (b >= nb) return;
+    struct Idx { int j, k, src, trans; };
+    struct Dat { double s, lj, lk; int fx, pj, pk; };
+    auto ldidx = [&](int bb) {                        // (past the end: the last block again, never used)
+        const int q = bb < nb ? bb : nb - 1;
+        return Idx{ f.rowidx[q], f.col[q], f.src[q], (int)f.trans[q] };
+    };
+    auto lddat = [&](const Idx &x) {                  // every load unconditional and independent of the others
+        Dat d;
+        d.s = f.S_up[(size_t)x.src * 64 + (x.trans ? c * 8 + r : r * 8 + c)];
+        d.lj = Linv[(size_t)x.j * 64 + lane]; d.lk = Linv[(size_t)x.k * 64 + lane];
+        d.fx = (int)f.fixed[x.j] | (int)f.fixed[x.k]; d.pj = f.pfix[x.j]; d.pk = f.pfix[x.k];
+        return d;
+    };
+    Idx i0 = ldidx(b), i1 = ldidx(b + nw);
+    Dat d0 = lddat(i0);
+    for (; b < nb; b += nw) {
+        const Idx i2 = ldidx(b + 2 * nw);
+        const Dat d1 = lddat(i1);
+        const int j = i0.j, k = i0.k;
+        double o = 0.0;
+        if (j != k) {                                     // (the same for all lanes)
+            double v = d0.s;
+            if (r == c && f.lk.row) { const int pq = f.lk.blk_pair[b]; if (pq >= 0) v -= f.lk.pair_w[(size_t)pq * kCP + r]; }   // shared-intrinsics links: U_jk = -w
+            // fixed cameras, padding rows / columns, constant parameters (finalized_element)
+            if (d0.fx | (r >= f.cnp) | (c >= f.cnp) | ((d0.pj >> r) & 1) | ((d0.pk >> c) & 1)) v = 0.0;
+            sh[wv][0][lane] = v; sh[wv][2][lane] = d0.lj; sh[wv][3][lane] = d0.lk;
+            wave_lds_sync();
+            double t = 0.0;                               // T = Linv_j S
 #pragma unroll
-    for (int a = 0; a < 8; ++a) t = fma(sh[wv][2][r * 8 + a], sh[wv][0][a * 8 + c], t);
-    sh[wv][1][lane] = t;
-    wave_lds_sync();
-    double o = 0.0;                                   // T Linv_k^T
+            for (int a = 0; a < 8; ++a) t = fma(sh[wv][2][r * 8 + a], sh[wv][0][a * 8 + c], t);
+            sh[wv][1][lane] = t;
+            wave_lds_sync();
 #pragma unroll
-    for (int a = 0; a < 8; ++a) o = fma(sh[wv][1][r * 8 + a], sh[wv][3][c * 8 + a], o);
-    const double val = (j == k) ? (r == c ? 1.0 : 0.0) : o;   // the diagonal blocks are the identity by construction
-    // The product's column forms (row_products): a lane of the product holds ONE column's elements of a few rows and needs one 8-byte element of
-    // the vector for them -- half the vector-load traffic of a row-major piece (the product is bound by the rate at which a CU takes load
-    // instructions).  f64 (layout 2): element (r, c) at ((r >> 1) * 8 + c) * 2 + (r & 1) -- rows 2h, 2h + 1 of column c in one 16-byte load.
-    // Single precision (layout 1): at ((r >> 2) * 8 + c) * 4 + (r & 3) -- rows 4h .. 4h + 3 of column c in one 16-byte load.
-    if (live) {
+            for (int a = 0; a < 8; ++a) o = fma(sh[wv][1][r * 8 + a], sh[wv][3][c * 8 + a], o);   // T Linv_k^T
+            wave_lds_sync();                              // (the next block's operands overwrite the buffers)
+        }
+        const double val = (j == k) ? (r == c ? 1.0 : 0.0) : o;   // the diagonal blocks are the identity by construction
+        // The product's column forms (row_products): a lane of the product holds ONE column's elements of a few rows and needs one 8-byte element of
+        // the vector for them.  f64 (layout 2): element (r, c) at ((r >> 1) * 8 + c) * 2 + (r & 1) -- rows 2h, 2h + 1 of column c in one 16-byte load.
+        // Single precision (layout 1): at ((r >> 2) * 8 + c) * 4 + (r & 3) -- rows 4h .. 4h + 3 of column c in one 16-byte load.
         if (layout == 1) reinterpret_cast<float *>(S_pcg)[(size_t)b * 64 + (((r >> 2) * 8 + c) * 4 + (r & 3))] = (float)val;
         else if (layout == 2) S_pcg[(size_t)b * 64 + (((r >> 1) * 8 + c) * 2 + (r & 1))] = val;
         else S_pcg[(size_t)b * 64 + lane] = val;
+        i0 = i1; i1 = i2; d0 = d1;
     }
 }
 
@@ -4010,6 +4036,7 @@ void launch_build(hipStream_t st, int cnp, bool lds_mode, int ntiles, const Buil
 
 // camera-side finish of the linearisation: right-hand side and norms, L^-1 of the diagonal blocks, the scaled matrix; the
 // full unscaled matrix only when S_full != nullptr (parity hooks)
+constexpr int kScaleBlocksGrid = 2048;   // workgroups of k_scale_blocks: eight wavefronts per SIMD, each walks the blocks in strides
 void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char *fixed, const unsigned char *pfix, double mu, const double *spec, const int *bsr_rowidx, const int *bsr_col,
                      const int *bsr_src, const unsigned char *bsr_trans, const int *bsr_diag, const double *S_up, double *S_full,
                      double *camvec, const double *cam_a, const double *cam_cw, const double *cam_cv, const CamLinks &links,
@@ -4026,7 +4053,7 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
     hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
-    hipLaunchKernelGGL(k_scale_blocks, dim3((nb + 3) / 4), dim3(256), 0, st, nb, f, Linv, S_pcg, ps.layout);
+    hipLaunchKernelGGL(k_scale_blocks, dim3(std::min((nb + 3) / 4, kScaleBlocksGrid)), dim3(256), 0, st, nb, f, Linv, S_pcg, ps.layout);
     if (co.ng) {   // the coarse space of this trial's system: Z'SZ, its inverse, S~Z~
         static_assert(kBcSlots == 4, "k_coarse_bc: one wavefront per slot");
         hipLaunchKernelGGL(k_coarse_bc, dim3(m), dim3(256), 0, st, m, bsr_row, bsr_col, (const double *)S_pcg, co);
