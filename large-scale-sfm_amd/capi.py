@@ -280,7 +280,7 @@ def comm_unique_id() -> bytes:
 class Plan:
     """host-only shard plan (usable without a GPU)."""
 
-    _dtypes = dict(obs_src=np.int64, batch_pair=np.int64, pair=np.uint32, rpair=np.uint32, wk_q=np.int64, sb_q=np.int64, obs_cslot=np.uint8,
+    _dtypes = dict(obs_src=np.int64, batch_pair=np.int64, pair=np.uint32, rpair=np.uint32, wk_q=np.int64, sb_q=np.int64, sb8_q=np.int64, obs_cslot=np.uint8,
                    tile_mode=np.uint8, bsr_trans=np.uint8)
 
     def __init__(self, n, m, pt_idx, cam_idx, rank=0, world=1, tile_max_batches=0, all_rows=False):

@@ -161,7 +161,7 @@ int64_t mi_ba_plan_get(const mi_ba_plan *p, const char *name, void *out, int64_t
     I32("cslot_cam", cslot_cam); I32("up_row", up_row); I32("up_col", up_col); I32("bsr_row", bsr_row); I32("bsr_col", bsr_col);
     I32("bsr_src", bsr_src); I32("pt_obs", pt_obs); I32("long_pts", long_pts);
     I32("bs_batch_obs", bs_batch_obs); I32("bs_batch_pt", bs_batch_pt); I32("bs_batch_obs_end", bs_batch_obs_end); I32("bs_batch_pt_end", bs_batch_pt_end);
-    I32("obs_rec", obs_rec); I32("rec_cam", rec_cam); I32("wk_blk", wk_blk); I32("wk_diag_cam", wk_diag_cam); I32("wk_diag_blk", wk_diag_blk); I32("sb_blk", sb_blk); I32("sb_ent", sb_ent);
+    I32("obs_rec", obs_rec); I32("rec_cam", rec_cam); I32("wk_blk", wk_blk); I32("wk_diag_cam", wk_diag_cam); I32("wk_diag_blk", wk_diag_blk); I32("sb_blk", sb_blk); I32("sb_ent", sb_ent); I32("sb8_blk", sb8_blk); I32("sb8_ent", sb8_ent);
 #undef I32
     if (k == "obs_src") return copy_out(pl.obs_src, (int64_t *)out, cap);
     if (k == "batch_pair") return copy_out(pl.batch_pair, (int64_t *)out, cap);
@@ -169,6 +169,7 @@ int64_t mi_ba_plan_get(const mi_ba_plan *p, const char *name, void *out, int64_t
     if (k == "rpair") return copy_out(pl.rpair, (uint32_t *)out, cap);
     if (k == "wk_q") return copy_out(pl.wk_q, (int64_t *)out, cap);
     if (k == "sb_q") return copy_out(pl.sb_q, (int64_t *)out, cap);
+    if (k == "sb8_q") return copy_out(pl.sb8_q, (int64_t *)out, cap);
     if (k == "obs_cslot") return copy_out(pl.obs_cslot, (uint8_t *)out, cap);
     if (k == "tile_mode") return copy_out(pl.tile_mode, (uint8_t *)out, cap);
     if (k == "bsr_trans") return copy_out(pl.bsr_trans, (uint8_t *)out, cap);

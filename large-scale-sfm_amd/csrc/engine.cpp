@@ -343,6 +343,8 @@ int Engine::prepare()
         UP(d_batch_pair_, bp); UP(d_wk_q_, wq);
         std::vector<long long> sq(pl.sb_q.begin(), pl.sb_q.end());
         UP(d_sb_q_, sq); UP(d_sb_blk_, pl.sb_blk); UP(d_sb_ent_, pl.sb_ent);
+        std::vector<long long> sq8(pl.sb8_q.begin(), pl.sb8_q.end());
+        UP(d_sb8_q_, sq8); UP(d_sb8_blk_, pl.sb8_blk); UP(d_sb8_ent_, pl.sb8_ent);
         std::vector<int> rowidx(pl.nb_full()), diag(mv_, -1);
         for (int j = 0; j < mv_; ++j)
             for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) { rowidx[q] = j; if (pl.bsr_col[q] == j) diag[j] = q; }
@@ -536,7 +538,7 @@ int Engine::prepare()
     // camera its 192-B record, every upper block of S once (512 B).  The engine's own index tables (pair entries, batch and
     // tile descriptors) and the row path's observation records are NOT problem data: they are reported beside it.
     timing.build_bytes = 24.0 * (double)pl.nobs_local() + 96.0 * (double)npl + 192.0 * m_ + 512.0 * pl.nb_up();
-    timing.build_index_bytes = 1.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 8.0 * (double)(pl.rpair.size() / 2) + 4.0 * (double)pl.sb_ent.size() +
+    timing.build_index_bytes = 1.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 8.0 * (double)(pl.rpair.size() / 2) + 4.0 * (double)(pl.sb_ent.size() + pl.sb8_ent.size()) +
                                2.0 * 8.0 * kRec * (double)pl.rec_cam[m_];
     {   // arithmetic of the same launch (for the f64 vector roofline beside the HBM one)
         double pairs = 0.0;
@@ -546,7 +548,7 @@ int Engine::prepare()
     if (cfg.verbose)
         std::fprintf(stderr, "[mi_ba] rank %d/%d: %lld pts %lld obs, %d batches, %d tiles (%d LDS), %zu pair entries; row path: %lld pts, %d records, %zu pairs in %zu + %zu blocks, %lld pairs in %zu super-block entries; S: %d upper / %d full blocks\n",
                      cfg.rank, cfg.world, (long long)npl, (long long)pl.nobs_local(), pl.nbatch(), pl.ntile(), pl.ntile_lds,
-                     pl.pair.size(), (long long)pl.nrow_pts, pl.rec_cam[m_], pl.rpair.size() / 2, pl.wk_blk.size(), pl.wk_diag_cam.size(), (long long)pl.nsuper_pairs, pl.sb_ent.size() / 8, pl.nb_up(), pl.nb_full());
+                     pl.pair.size(), (long long)pl.nrow_pts, pl.rec_cam[m_], pl.rpair.size() / 2, pl.wk_blk.size(), pl.wk_diag_cam.size(), (long long)pl.nsuper_pairs, pl.sb_ent.size() / 8 + pl.sb8_ent.size() / 16, pl.nb_up(), pl.nb_full());
     return 0;
 }
 
@@ -741,6 +743,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
         sa.nwork = (int)pl.wk_blk.size(); sa.ndiag = (int)pl.wk_diag_cam.size(); sa.m = m_; sa.mv = mv_; sa.want_diag = (want_diag || pba) ? 1 : 0;
         sa.wk_vblk = d_wk_vblk_.p; sa.diag_vblk = d_wk_diag_vblk_.p;
         sa.sb_blk = d_sb_blk_.p; sa.sb_ent = d_sb_ent_.p; sa.sb_q = d_sb_q_.p; sa.nsuper = (int)pl.sb_q.size() - 1;
+        sa.sb8_blk = d_sb8_blk_.p; sa.sb8_ent = d_sb8_ent_.p; sa.sb8_q = d_sb8_q_.p; sa.nsuper8 = (int)pl.sb8_q.size() - 1;
         sa.S_up = S_up_(); sa.camvec = camvec_(); sa.spec = spec;
         launch_schur_blocks(st_, cnp, sa);
     }

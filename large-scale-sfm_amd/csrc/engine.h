@@ -151,8 +151,8 @@ private:
     DevBuf<unsigned char> d_fixed_real_;                                    // per real camera (the point-side kernels)
     DevBuf<int> d_wk_vblk_, d_wk_diag_vblk_;
     DevBuf<unsigned> d_pair_, d_rpair_;
-    DevBuf<int> d_obs_rec_, d_rec_cam_, d_wk_blk_, d_wk_diag_cam_, d_wk_diag_blk_, d_sb_blk_, d_sb_ent_;   // row path (plan.h)
-    DevBuf<long long> d_wk_q_, d_sb_q_;
+    DevBuf<int> d_obs_rec_, d_rec_cam_, d_wk_blk_, d_wk_diag_cam_, d_wk_diag_blk_, d_sb_blk_, d_sb_ent_, d_sb8_blk_, d_sb8_ent_;   // row path (plan.h)
+    DevBuf<long long> d_wk_q_, d_sb_q_, d_sb8_q_;
     DevBuf<double> d_rec_;                                                             // kRec doubles per row-path observation
     DevBuf<unsigned long long> d_dbg_, d_pstamps_;
     // the reduced solve as one persistent cooperative launch (kernels.hip k_pcg_persist) when S~ fits the chip's LDS

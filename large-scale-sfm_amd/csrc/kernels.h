@@ -139,6 +139,9 @@ struct SchurArgs {
     const int *sb_blk, *sb_ent;       // super-blocks (plan.h): 16 blocks per work item; 8 records per entry, -1 = none
     const long long *sb_q;            // ... work item w: entries [sb_q[w], sb_q[w + 1]), a multiple of four
     int nsuper;
+    const int *sb8_blk, *sb8_ent;     // ... the same with groups of eight cameras: 64 blocks per work item, 16 records per entry
+    const long long *sb8_q;
+    int nsuper8;
     double *S_up, *camvec;
     const double *spec;           // as in BuildArgs
 };

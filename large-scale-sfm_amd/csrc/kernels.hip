@@ -1989,55 +1989,71 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_pairs(const Schu
     }
 }
 
-// The off-diagonal blocks whose two cameras lie in different groups of four consecutive cameras, by SUPER-BLOCK (plan.h sb_*): a work item is a
-// (row group, column group) pair = 4 x 4 blocks of S, its list holds one entry per point both groups see -- the point's records of the four
-// row cameras and of the four column cameras.  A round takes four entries: 32 records fetched once (96 lines) serve 64 pairs, where the pair
-// list above fetches 2 records (6 lines) for every pair -- the kernel above is bound by exactly that traffic (C4: 18.5 GB of record lines per
-// launch).  Lane = (entry of the round, row camera, column camera): one block per lane across the whole list as before; the four entries of a
-// round hold copies of the same block, summed through LDS at the end; a lane whose entry lacks one of its two cameras idles for the round.
-template <int CNP>
+// The off-diagonal blocks whose two cameras lie in different groups of GS (four, eight) consecutive cameras, by SUPER-BLOCK (plan.h sb_*, sb8_*): a
+// work item is a (row group, column group) pair = GS x GS blocks of S, its list holds one entry per point both groups see -- the point's records
+// of the GS row cameras and of the GS column cameras.  A round = 64 / GS^2 entries (four, one): 32 (16) records fetched once serve 64 pairs, where
+// the pair list above fetches 2 records (6 lines) for every pair -- the kernel above is bound by exactly that traffic (C4: 18.5 GB of record
+// lines per launch).  Measured on C4 (859 us, 820 000 rounds of four entries): without the arithmetic 865 us, with the records always the same 32
+// (L2 hits) 549 us, with neither 417 us -- the arithmetic is hidden, the floor is the round's chain ids -> record lines -> LDS -> operands at two
+// wavefronts per SIMD; a register prefetch of the next round and an LDS-DMA ring two rounds ahead were both built and changed nothing, groups of
+// eight (half the lines per pair, a quarter of the work items) were slower (opt-in MI_BA_SUPER=8: 900 + 450 us).  Lane = (entry of the round,
+// row camera, column camera): one block per lane across the whole list as before; with four entries a round the copies of a block are summed
+// through LDS at the end; a lane whose entry lacks one of its two cameras idles for the round.
+template <int CNP, int GS>
 __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_super(const SchurArgs g)
 {
+    static_assert(GS == 4 || GS == 8, "groups of four or eight cameras");
     constexpr int BLK = CNP * CNP, ST = BLK | 1;
+    constexpr int EPR = kWave / (GS * GS), NR = EPR * 2 * GS, NH = NR / 16;   // entries per round, records per round, fetches of 16 records
     constexpr int SLOT = 26;                                        // doubles per record in the staging buffer: 3 lines (24) + 2 pad = 208 B
-    constexpr int NBUF = (32 * SLOT > 32 * ST) ? 32 * SLOT : 32 * ST;
+    constexpr int NBUF = (NR * SLOT > 32 * ST) ? NR * SLOT : 32 * ST;
     __shared__ __attribute__((aligned(16))) double sBuf[NBUF];
+    __shared__ int sGb[32];
     if (g.spec && g.spec[0] == 0.0) return;
     const int lane = threadIdx.x, w = blockIdx.x;                  // (the work items come sorted, the longest first)
-    const long long q0 = g.sb_q[w], q1 = g.sb_q[w + 1];
-    const int rounds = (int)((q1 - q0) >> 2);
-    const int *__restrict__ ent = g.sb_ent + 8 * q0;
-    // as a fetcher: record slot `quad` of each half of the round's 32 (two quads of one 8-lane ds_write_b128 group 8 slots = 32 banks apart), 16-byte piece
+    const long long q0 = (GS == 4 ? g.sb_q : g.sb8_q)[w], q1 = (GS == 4 ? g.sb_q : g.sb8_q)[w + 1];
+    const int rounds = (int)((q1 - q0) / EPR);
+    const int *__restrict__ ent = (GS == 4 ? g.sb_ent : g.sb8_ent) + 2 * GS * q0;
+    const int *__restrict__ blk = (GS == 4 ? g.sb_blk : g.sb8_blk) + (size_t)w * GS * GS;
+    // as a fetcher: record slot `quad` of each sixteen of the round (two quads of one 8-lane ds_write_b128 group 8 slots = 32 banks apart), 16-byte piece
     const int quad = ((lane >> 2) & 1) * 8 + (lane >> 3), piece = lane & 3;
-    const int line2 = (quad & 4) ? 2 : 3;                          // third line of a record: G (row side, slots 0-3 of an entry) or B (column side)
+    const int line2 = (quad & GS) ? 2 : 3;                         // third line of a record: G (row side, the first GS slots of an entry) or B (column side)
     // as a pair: entry s of the round, row camera ja, column camera kb
-    const int s = lane >> 4, ja = (lane >> 2) & 3, kb = lane & 3;
+    const int s = GS == 4 ? lane >> 4 : 0, ja = GS == 4 ? (lane >> 2) & 3 : lane >> 3, kb = lane & (GS - 1);
+    const int aslot = s * 2 * GS + ja, bslot = s * 2 * GS + GS + kb;
     double acc[BLK];
 #pragma unroll
     for (int i = 0; i < BLK; ++i) acc[i] = 0.0;
-    // the pipeline: record ids two rounds ahead, the records themselves one round ahead (in flight through the arithmetic of the round before)
-#define MIBA_SUPER_FETCH(iA, iB)                                                                                                             \
-    do {                                                                                                                                     \
-        const double *ra_ = g.rec + (size_t)((iA) < 0 ? 0 : (iA)) * kRec + piece * 2, *rb_ = g.rec + (size_t)((iB) < 0 ? 0 : (iB)) * kRec + piece * 2; \
-        st0 = *reinterpret_cast<const double2 *>(ra_); st1 = *reinterpret_cast<const double2 *>(ra_ + 8); st2 = *reinterpret_cast<const double2 *>(ra_ + line2 * 8); \
-        st3 = *reinterpret_cast<const double2 *>(rb_); st4 = *reinterpret_cast<const double2 *>(rb_ + 8); st5 = *reinterpret_cast<const double2 *>(rb_ + line2 * 8); \
-    } while (0)
-    double2 st0, st1, st2, st3, st4, st5;
-    int vA = ent[s * 8 + ja], vB = ent[s * 8 + 4 + kb];            // this round's pair: both records there?
-    MIBA_SUPER_FETCH(ent[quad], ent[16 + quad]);
-    int nA = 0, nB = 0, nVa = -1, nVb = -1;
-    if (rounds > 1) { nA = ent[32 + quad]; nB = ent[48 + quad]; nVa = ent[32 + s * 8 + ja]; nVb = ent[32 + s * 8 + 4 + kb]; }
+    int nF[NH], nVa = ent[aslot], nVb = ent[bslot];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) nF[h] = ent[h * 16 + quad];
     for (int r = 0; r < rounds; ++r) {
-        {
-            double *d0 = sBuf + quad * SLOT + piece * 2, *d1 = sBuf + (16 + quad) * SLOT + piece * 2;
-            *reinterpret_cast<double2 *>(d0) = st0; *reinterpret_cast<double2 *>(d0 + 8) = st1; *reinterpret_cast<double2 *>(d0 + 16) = st2;
-            *reinterpret_cast<double2 *>(d1) = st3; *reinterpret_cast<double2 *>(d1 + 8) = st4; *reinterpret_cast<double2 *>(d1 + 16) = st5;
+        int iF[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) iF[h] = nF[h];
+        const int iVa = nVa, iVb = nVb;
+        if (r + 1 < rounds) {
+            const int *en = ent + (size_t)(r + 1) * NR;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) nF[h] = en[h * 16 + quad];
+            nVa = en[aslot]; nVb = en[bslot];
         }
+        double2 st[NH][3];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const double *rp = g.rec + (size_t)(iF[h] < 0 ? 0 : iF[h]) * kRec + piece * 2;
+            st[h][0] = *reinterpret_cast<const double2 *>(rp); st[h][1] = *reinterpret_cast<const double2 *>(rp + 8); st[h][2] = *reinterpret_cast<const double2 *>(rp + line2 * 8);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                *reinterpret_cast<double2 *>(sBuf + (h * 16 + quad) * SLOT + k * 8 + piece * 2) = st[h][k];
         wave_lds_sync();
         double Aa[16], Ab[16], G[6], Bb[6];
         {
-            const double2 *ma = reinterpret_cast<const double2 *>(sBuf + (s * 8 + ja) * SLOT);
-            const double2 *mb = reinterpret_cast<const double2 *>(sBuf + (s * 8 + 4 + kb) * SLOT);
+            const double2 *ma = reinterpret_cast<const double2 *>(sBuf + aslot * SLOT);
+            const double2 *mb = reinterpret_cast<const double2 *>(sBuf + bslot * SLOT);
 #pragma unroll
             for (int t = 0; t < 8; ++t) { const double2 v = ma[t]; Aa[2 * t] = v.x; Aa[2 * t + 1] = v.y; }
 #pragma unroll
@@ -2048,16 +2064,7 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_super(const Schu
             for (int t = 0; t < 3; ++t) { const double2 v = mb[8 + t]; Bb[2 * t] = v.x; Bb[2 * t + 1] = v.y; }
         }
         wave_lds_sync();                                            // operands are in registers: the buffer is free for the next round
-        const bool valid = vA >= 0 && vB >= 0;
-        if (r + 1 < rounds) {
-            MIBA_SUPER_FETCH(nA, nB);
-            vA = nVa; vB = nVb;
-            if (r + 2 < rounds) {
-                const int *en = ent + (size_t)(r + 2) * 32;
-                nA = en[quad]; nB = en[16 + quad]; nVa = en[s * 8 + ja]; nVb = en[s * 8 + 4 + kb];
-            }
-        }
-        if (valid) {
+        if (iVa >= 0 && iVb >= 0) {
             const double M00 = -fma(G[2], Bb[2], fma(G[1], Bb[1], G[0] * Bb[0])), M01 = -fma(G[2], Bb[5], fma(G[1], Bb[4], G[0] * Bb[3]));
             const double M10 = -fma(G[5], Bb[2], fma(G[4], Bb[1], G[3] * Bb[0])), M11 = -fma(G[5], Bb[5], fma(G[4], Bb[4], G[3] * Bb[3]));
             double T0[CNP], T1[CNP];
@@ -2069,31 +2076,61 @@ __global__ __launch_bounds__(64, CNP <= 7 ? 2 : 1) void k_schur_super(const Schu
                 for (int c = 0; c < CNP; ++c) acc[rr * CNP + c] = fma(Aa[8 + rr], T1[c], fma(Aa[rr], T0[c], acc[rr * CNP + c]));
         }
     }
-#undef MIBA_SUPER_FETCH
-    // the four entries' copies of a block (lanes b, b + 16, b + 32, b + 48) -> one, in a fixed order: (0 + 2) + (1 + 3)
-    if (lane >= 32) {
+    // nb blocks (the staging buffer's rows 0 .. nb - 1 = blocks b0 .. of the work item) onto S: element i * 64 + lane of the list, every read
+    // requested before the first is waited for (block after block they were 2 nb dependent round trips at the end of every work item)
+    auto flush = [&](int b0, auto nb_c) {
+        constexpr int nb = decltype(nb_c)::value;
+        if (lane < nb) sGb[lane] = blk[b0 + lane];
+        wave_lds_sync();
+        constexpr int NEL = (nb * BLK + kWave - 1) / kWave;
+        double *dst[NEL];
+        double old[NEL], add[NEL];
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) sBuf[(lane - 32) * ST + i] = acc[i];
-    }
-    wave_lds_sync();
-    if (lane < 32) {
+        for (int i = 0; i < NEL; ++i) {
+            const int idx = i * kWave + lane, b = idx / BLK, e = idx - b * BLK;
+            const int gb = idx < nb * BLK ? sGb[b] : -1;
+            dst[i] = gb >= 0 ? g.S_up + (size_t)gb * (kCP * kCP) + (e / CNP) * kCP + (e % CNP) : nullptr;
+            add[i] = gb >= 0 ? sBuf[b * ST + e] : 0.0;
+        }
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) acc[i] += sBuf[lane * ST + i];
-    }
-    wave_lds_sync();
-    if (lane >= 16 && lane < 32) {
+        for (int i = 0; i < NEL; ++i) old[i] = dst[i] ? *dst[i] : 0.0;
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) sBuf[(lane - 16) * ST + i] = acc[i];
-    }
-    wave_lds_sync();
-    if (lane < 16) {
+        for (int i = 0; i < NEL; ++i) if (dst[i]) *dst[i] = old[i] + add[i];
+        wave_lds_sync();
+    };
+    if constexpr (GS == 4) {
+        // the four entries' copies of a block (lanes b, b + 16, b + 32, b + 48) -> one, in a fixed order: (0 + 2) + (1 + 3)
+        if (lane >= 32) {
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) sBuf[lane * ST + i] = acc[i] + sBuf[lane * ST + i];
-    }
-    wave_lds_sync();
-    for (int b = 0; b < 16; ++b) {
-        const int gb = g.sb_blk[(size_t)w * 16 + b];
-        if (gb >= 0 && lane < BLK) g.S_up[(size_t)gb * (kCP * kCP) + (lane / CNP) * kCP + (lane % CNP)] += sBuf[b * ST + lane];
+            for (int i = 0; i < BLK; ++i) sBuf[(lane - 32) * ST + i] = acc[i];
+        }
+        wave_lds_sync();
+        if (lane < 32) {
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) acc[i] += sBuf[lane * ST + i];
+        }
+        wave_lds_sync();
+        if (lane >= 16 && lane < 32) {
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) sBuf[(lane - 16) * ST + i] = acc[i];
+        }
+        wave_lds_sync();
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < BLK; ++i) sBuf[lane * ST + i] = acc[i] + sBuf[lane * ST + i];
+        }
+        wave_lds_sync();
+        flush(0, std::integral_constant<int, 16>{});
+    } else {
+        // one block per lane: through the buffer in two halves of 32 blocks
+        for (int hh = 0; hh < 2; ++hh) {
+            if ((lane >> 5) == hh) {
+#pragma unroll
+                for (int i = 0; i < BLK; ++i) sBuf[(lane & 31) * ST + i] = acc[i];
+            }
+            wave_lds_sync();
+            flush(hh * 32, std::integral_constant<int, 32>{});
+        }
     }
 }
 
@@ -4259,7 +4296,8 @@ static void launch_schur_blocks_t(hipStream_t st, const SchurArgs &a)
         if (direct) hipLaunchKernelGGL((k_schur_blocks<CNP, false>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_schur_pairs<CNP>), dim3(8 * ((a.nwork + 7) / 8)), dim3(64), 0, st, a);
     }
-    if (a.nsuper > 0) hipLaunchKernelGGL((k_schur_super<CNP>), dim3(a.nsuper), dim3(64), 0, st, a);
+    if (a.nsuper > 0) hipLaunchKernelGGL((k_schur_super<CNP, 4>), dim3(a.nsuper), dim3(64), 0, st, a);
+    if (a.nsuper8 > 0) hipLaunchKernelGGL((k_schur_super<CNP, 8>), dim3(a.nsuper8), dim3(64), 0, st, a);
 }
 
 void launch_schur_blocks(hipStream_t st, int cnp, const SchurArgs &a)

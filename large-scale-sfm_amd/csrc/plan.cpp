@@ -665,44 +665,73 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         const int nbu = pl.nb_up();
         const int nrow = npl - t_rows;
         const int nt = nrow < (1 << 14) ? 1 : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-        // super-blocks: decided on the pair count (every pair of observations of a row point)
-        bool super = false;
+        // super-blocks: decided on the pair count (every pair of observations of a row point).  MI_BA_SUPER: 0 off, 4 (or 1) the groups of four (the default), 8 both levels (measured slower on C4)
+        int levels = 0;
         {
             int64_t np = 0;
             for (int tt = t_rows; tt < npl; ++tt) { const int64_t d = pl.pt_obs[tt + 1] - pl.pt_obs[tt]; np += d * (d - 1) / 2; }
             const char *env = std::getenv("MI_BA_SUPER");
-            super = !cam_split && (env ? std::atoi(env) != 0 : np >= kSuperMinPairs);
+            const int v = env ? std::atoi(env) : (np >= kSuperMinPairs ? 4 : 0);
+            levels = cam_split ? 0 : v == 0 ? 0 : v == 8 ? 2 : 1;
         }
-        constexpr int GS = kSuperCams;
-        const int ngrp = (m + GS - 1) / GS;
-        // the group pairs with a block in the pattern: sup_row / sup_col (CSR over row groups, column groups ascending, the diagonal group pair left out)
-        std::vector<int> sup_row(ngrp + 1, 0), sup_col;
-        if (super) {
-            std::vector<int> mark(ngrp, -1);
-            for (int G = 0; G < ngrp; ++G) {
+        const bool super = levels > 0;
+        // One level = the groups of GS consecutive cameras and the group pairs (row group < column group) with a block in the pattern, as a CSR over
+        // row groups (column groups ascending); entries of 2 GS records; per-thread counts, then positions, of the two passes
+        struct Level {
+            int GS = 0, ngrp = 0, nsup = 0, round = 1;               // round: entries per round of the kernel (lists padded to whole rounds)
+            std::vector<int> row, col, grp_of;
+            std::vector<std::vector<int>> cnt;
+            std::vector<std::vector<int64_t>> pos;
+            std::vector<int64_t> pairs;
+            std::vector<int> *blk = nullptr; std::vector<int64_t> *q = nullptr; std::vector<int32_t> *ent = nullptr;
+            int find(int G, int H) const {
+                const int *b = col.data() + row[G], *e = col.data() + row[G + 1];
+                const int *it = std::lower_bound(b, e, H);
+                return (it == e || *it != H) ? -1 : (int)(it - col.data());
+            }
+        };
+        Level lv[2];
+        lv[0].GS = kSuperCams; lv[0].round = 4; lv[0].blk = &pl.sb_blk; lv[0].q = &pl.sb_q; lv[0].ent = &pl.sb_ent;
+        lv[1].GS = 2 * kSuperCams; lv[1].round = 1; lv[1].blk = &pl.sb8_blk; lv[1].q = &pl.sb8_q; lv[1].ent = &pl.sb8_ent;
+        for (int L = 0; L < levels; ++L) {
+            Level &v = lv[L];
+            v.ngrp = (m + v.GS - 1) / v.GS;
+            v.row.assign(v.ngrp + 1, 0);
+            std::vector<int> mark(v.ngrp, -1);
+            for (int G = 0; G < v.ngrp; ++G) {
                 std::vector<int> cols;
-                for (int j = G * GS; j < std::min(m, (G + 1) * GS); ++j)
+                for (int j = G * v.GS; j < std::min(m, (G + 1) * v.GS); ++j)
                     for (int q = pl.up_row[j]; q < pl.up_row[j + 1]; ++q) {
-                        const int H = pl.up_col[q] / GS;
+                        const int H = pl.up_col[q] / v.GS;
                         if (H != G && mark[H] != G) { mark[H] = G; cols.push_back(H); }
                     }
                 std::sort(cols.begin(), cols.end());
-                sup_col.insert(sup_col.end(), cols.begin(), cols.end());
-                sup_row[G + 1] = (int)sup_col.size();
+                v.col.insert(v.col.end(), cols.begin(), cols.end());
+                v.row[G + 1] = (int)v.col.size();
             }
+            v.nsup = (int)v.col.size();
+            v.grp_of.resize(v.nsup);
+            for (int G = 0; G < v.ngrp; ++G) for (int q = v.row[G]; q < v.row[G + 1]; ++q) v.grp_of[q] = G;
+            v.cnt.assign(nt, std::vector<int>(nrow ? v.nsup : 0, 0));
+            v.pos.assign(nt, std::vector<int64_t>());
+            v.pairs.assign(nt, 0);
         }
-        const int nsup = (int)sup_col.size();
-        auto sup_of = [&](int G, int H) {
-            const int *b = sup_col.data() + sup_row[G], *e = sup_col.data() + sup_row[G + 1];
-            const int *it = std::lower_bound(b, e, H);
-            return (it == e || *it != H) ? -1 : (int)(it - sup_col.data());
-        };
-        std::vector<std::vector<int>> cnt(nt, std::vector<int>(nrow ? nbu : 0, 0)), scnt(nt, std::vector<int>(nrow ? nsup : 0, 0));
-        std::vector<int64_t> spairs(nt, 0);
-        std::vector<int64_t> sbase;                       // super-block s's entries start at sbase[s] (filled before the second pass)
+        constexpr int GS = kSuperCams;
+        std::vector<std::vector<int>> cnt(nt, std::vector<int>(nrow ? nbu : 0, 0));
         std::atomic<bool> missing(false);
-        auto walk = [&](int k, bool fill_pass, std::vector<int64_t> *pos, std::vector<int64_t> *spos) {
+        auto walk = [&](int k, bool fill_pass, std::vector<int64_t> *pos) {
             const int b0 = t_rows + (int)((int64_t)nrow * k / nt), b1 = t_rows + (int)((int64_t)nrow * (k + 1) / nt);
+            // one entry of level v: the observations [a0, a1) (row group) and [e0, e1) (column group) of the point whose observations start at os
+            auto entry = [&](Level &v, const int *c, int os, int a0, int a1, int e0, int e1) {
+                const int sidx = v.find(c[a0] / v.GS, c[e0] / v.GS);
+                if (sidx < 0) { missing = true; return; }
+                if (!fill_pass) { v.cnt[k][sidx]++; v.pairs[k] += (int64_t)(a1 - a0) * (e1 - e0); }
+                else {
+                    int32_t *ent = v.ent->data() + 2 * v.GS * (size_t)v.pos[k][sidx]++;
+                    for (int x = a0; x < a1; ++x) ent[c[x] % v.GS] = pl.obs_rec[os + x];
+                    for (int x = e0; x < e1; ++x) ent[v.GS + c[x] % v.GS] = pl.obs_rec[os + x];
+                }
+            };
             for (int tt = b0; tt < b1; ++tt) {
                 const int os = pl.pt_obs[tt], d = pl.pt_obs[tt + 1] - os;
                 const int *c = pl.obs_cam.data() + os;
@@ -722,23 +751,31 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
                     }
                 }
                 if (!super) continue;
-                // the point's runs of observations by camera group, and one entry per pair of runs
+                // The point's runs of observations by camera group, one entry per pair of runs.  Two levels: a point that reaches kSuper8MinGroups
+                // groups of eight or more pairs its runs of EIGHT (16 records serve up to 64 pairs) and, inside a run of eight, its two runs of
+                // four; any other point pairs its runs of four (8 records, up to 16 pairs: short tracks would leave most of an 8 x 8 entry idle).
+                bool two = false;
+                if (levels > 1) {
+                    int n8 = 1;
+                    for (int x = 1; x < d; ++x) n8 += c[x] / lv[1].GS != c[x - 1] / lv[1].GS;
+                    two = n8 >= kSuper8MinGroups;
+                }
+                Level &top = lv[two ? 1 : 0];
                 for (int a0 = 0; a0 < d;) {
                     int a1 = a0 + 1;
-                    while (a1 < d && c[a1] / GS == c[a0] / GS) ++a1;
+                    while (a1 < d && c[a1] / top.GS == c[a0] / top.GS) ++a1;
+                    if (two) {                                             // the run of eight's two halves
+                        int mid = a0;
+                        while (mid < a1 && c[mid] / GS == c[a0] / GS) ++mid;
+                        if (mid < a1) entry(lv[0], c, os, a0, mid, mid, a1);
+                    }
                     for (int e0 = a1; e0 < d;) {
                         int e1 = e0 + 1;
-                        while (e1 < d && c[e1] / GS == c[e0] / GS) ++e1;
-                        const int sidx = sup_of(c[a0] / GS, c[e0] / GS);
-                        if (sidx < 0) { missing = true; return; }
-                        if (!fill_pass) { scnt[k][sidx]++; spairs[k] += (int64_t)(a1 - a0) * (e1 - e0); }
-                        else {
-                            int32_t *ent = pl.sb_ent.data() + 2 * GS * (size_t)(*spos)[sidx]++;
-                            for (int x = a0; x < a1; ++x) ent[c[x] % GS] = pl.obs_rec[os + x];
-                            for (int x = e0; x < e1; ++x) ent[GS + c[x] % GS] = pl.obs_rec[os + x];
-                        }
+                        while (e1 < d && c[e1] / top.GS == c[e0] / top.GS) ++e1;
+                        entry(top, c, os, a0, a1, e0, e1);
                         e0 = e1;
                     }
+                    if (missing) return;
                     a0 = a1;
                 }
             }
@@ -749,46 +786,45 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             for (int k = 0; k < nt; ++k) th.emplace_back(fn, k);
             for (auto &x : th) x.join();
         };
-        if (nrow) run_threads([&](int k) { walk(k, false, nullptr, nullptr); });
+        if (nrow) run_threads([&](int k) { walk(k, false, nullptr); });
         if (missing) return "internal: block missing from pattern";
         // block g's pairs: [base[g], base[g + 1]), thread k's share of them after the shares of the threads before it
         std::vector<int64_t> base(nbu + 1, 0);
-        std::vector<std::vector<int64_t>> pos(nt), spos(nt);
+        std::vector<std::vector<int64_t>> pos(nt);
         if (nrow) {
             for (int g = 0; g < nbu; ++g) { int64_t tot = 0; for (int k = 0; k < nt; ++k) tot += cnt[k][g]; base[g + 1] = base[g] + tot; }
             for (int k = 0; k < nt; ++k) pos[k].resize(nbu);
             for (int g = 0; g < nbu; ++g) { int64_t at = base[g]; for (int k = 0; k < nt; ++k) { pos[k][g] = at; at += cnt[k][g]; } }
         }
-        pl.sb_blk.clear(); pl.sb_q.assign(1, 0); pl.sb_ent.clear(); pl.nsuper_pairs = 0;
-        if (nrow && super) {
+        pl.sb_blk.clear(); pl.sb_q.assign(1, 0); pl.sb_ent.clear(); pl.sb8_blk.clear(); pl.sb8_q.assign(1, 0); pl.sb8_ent.clear(); pl.nsuper_pairs = 0;
+        for (int L = 0; nrow && L < levels; ++L) {
+            Level &v = lv[L];
             // work items in the order of falling entry counts (one wavefront each, dealt to the chip in this order: the long ones first)
-            std::vector<int64_t> tot(nsup, 0);
-            for (int s2 = 0; s2 < nsup; ++s2) for (int k = 0; k < nt; ++k) tot[s2] += scnt[k][s2];
+            std::vector<int64_t> tot(v.nsup, 0);
+            for (int s2 = 0; s2 < v.nsup; ++s2) for (int k = 0; k < nt; ++k) tot[s2] += v.cnt[k][s2];
             std::vector<int> order;
-            for (int s2 = 0; s2 < nsup; ++s2) if (tot[s2] > 0) order.push_back(s2);
+            for (int s2 = 0; s2 < v.nsup; ++s2) if (tot[s2] > 0) order.push_back(s2);
             std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return tot[x] > tot[y]; });
-            std::vector<int> grp_of(nsup);
-            for (int G = 0; G < ngrp; ++G) for (int q = sup_row[G]; q < sup_row[G + 1]; ++q) grp_of[q] = G;
-            sbase.assign(nsup, 0);
+            std::vector<int64_t> sbase(v.nsup, 0);
             int64_t at = 0;
             for (int s2 : order) {
                 sbase[s2] = at;
-                at += (tot[s2] + 3) / 4 * 4;
-                pl.sb_q.push_back(at);
-                const int G = grp_of[s2], H = sup_col[s2];
-                for (int ja = 0; ja < GS; ++ja)
-                    for (int kb = 0; kb < GS; ++kb) {
-                        const int j = G * GS + ja, k2 = H * GS + kb;
-                        pl.sb_blk.push_back(j < m && k2 < m ? pl.upper_block(j, k2) : -1);
+                at += (tot[s2] + v.round - 1) / v.round * v.round;
+                v.q->push_back(at);
+                const int G = v.grp_of[s2], H = v.col[s2];
+                for (int ja = 0; ja < v.GS; ++ja)
+                    for (int kb = 0; kb < v.GS; ++kb) {
+                        const int j = G * v.GS + ja, k2 = H * v.GS + kb;
+                        v.blk->push_back(j < m && k2 < m ? pl.upper_block(j, k2) : -1);
                     }
             }
-            pl.sb_ent.assign((size_t)(2 * GS * at), -1);
-            for (int k = 0; k < nt; ++k) spos[k].assign(nsup, 0);
-            for (int s2 = 0; s2 < nsup; ++s2) { int64_t a2 = sbase[s2]; for (int k = 0; k < nt; ++k) { spos[k][s2] = a2; a2 += scnt[k][s2]; } }
-            for (int k = 0; k < nt; ++k) pl.nsuper_pairs += spairs[k];
+            v.ent->assign((size_t)(2 * v.GS * at), -1);
+            for (int k = 0; k < nt; ++k) v.pos[k].assign(v.nsup, 0);
+            for (int s2 = 0; s2 < v.nsup; ++s2) { int64_t a2 = sbase[s2]; for (int k = 0; k < nt; ++k) { v.pos[k][s2] = a2; a2 += v.cnt[k][s2]; } }
+            for (int k = 0; k < nt; ++k) pl.nsuper_pairs += v.pairs[k];
         }
         pl.rpair.assign((size_t)(2 * base[nbu]), 0u);
-        if (nrow) run_threads([&](int k) { walk(k, true, &pos[k], &spos[k]); });
+        if (nrow) run_threads([&](int k) { walk(k, true, &pos[k]); });
         if (missing) return "internal: block missing from pattern";
         pl.wk_blk.clear(); pl.wk_q.assign(1, 0); pl.wk_diag_cam.clear(); pl.wk_diag_blk.clear();
         for (int g = 0; g < nbu; ++g)

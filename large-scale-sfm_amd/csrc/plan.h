@@ -67,6 +67,7 @@ constexpr int kMinRunPts = 12;          // a camera set shared by fewer consecut
                                         // per-point work and no atomics; break-even ~14 points.  MI_BA_MIN_RUN_PTS overrides (probes);
                                         // mi_ba_config.deterministic sends EVERY point down the row path
 constexpr int kSuperCams = 4;             // cameras per side of a super-block (plan.h sb_blk; k_schur_super: lane = (entry of the round, row camera, column camera))
+constexpr int kSuper8MinGroups = 4;        // a point that reaches this many groups of eight cameras pairs its runs of eight (plan.h sb8_*)
 constexpr int64_t kSuperMinPairs = 1 << 20; // row-path pairs from which the super-blocks are worth their tables
 constexpr int kRec = 32;                // doubles per observation record: A (2 x 8) | B (6) | e (2) | G = B V*^-1 (6) | e - B h (2)
 constexpr int kRec9 = 36;               // the same with nine camera parameters: A (2 x 10)
@@ -118,6 +119,11 @@ struct Plan {
     std::vector<int> sb_blk;
     std::vector<int64_t> sb_q;                       // work item w's entries sb_ent[8 sb_q[w] .. 8 sb_q[w + 1]): a multiple of four (padded with all -1)
     std::vector<int32_t> sb_ent;
+    // ... and the same with groups of EIGHT cameras (64 blocks per work item, 16 records per entry, one entry per round: no padding): the points with long
+    // tracks pair their runs of eight here and only the two halves of a run of eight in the lists above (plan.cpp)
+    std::vector<int> sb8_blk;
+    std::vector<int64_t> sb8_q;
+    std::vector<int32_t> sb8_ent;
     int64_t nsuper_pairs = 0;                        // pairs the entries stand for
     std::vector<int> wk_vblk, wk_diag_vblk;          // cam_split: 4 virtual blocks per work item: (2a,2b) (2a,2b+1) (2a+1,2b) (2a+1,2b+1)
     int64_t nrow_pts = 0;                            // points on the row path (long ones included)

@@ -308,7 +308,7 @@ def _check_plan(sc, rank=0, world=1, tmb=0, all_rows=False):
     g = {k: pl.get(k) for k in ("perm", "obs_cam", "obs_pt", "obs_src", "pt_obs", "batch_obs", "batch_pt", "batch_pair", "tile_batch",
                                 "tile_slot", "slot_gblk", "tile_cslot", "cslot_cam", "pair", "obs_cslot", "up_row",
                                 "up_col", "bsr_row", "bsr_col", "bsr_src", "bsr_trans", "tile_mode", "obs_rec", "rec_cam", "wk_blk", "wk_q",
-                                "rpair", "wk_diag_cam", "wk_diag_blk", "long_pts", "sb_blk", "sb_q", "sb_ent")}
+                                "rpair", "wk_diag_cam", "wk_diag_blk", "long_pts", "sb_blk", "sb_q", "sb_ent", "sb8_blk", "sb8_q", "sb8_ent")}
     assert sorted(g["perm"]) == list(range(sc.n))
     # observations: a permutation of this shard's original observations, cameras ascending inside a point
     assert np.array_equal(sc.obs_cam[g["obs_src"]], g["obs_cam"])
@@ -395,33 +395,36 @@ def _check_plan(sc, rank=0, world=1, tmb=0, all_rows=False):
         assert np.all(g["obs_pt"][oa] == g["obs_pt"][ob]) and np.all(np.diff(g["obs_pt"][oa]) > 0)
         assert all(up[(a, b)] == blk for a, b in set(zip(g["obs_cam"][oa], g["obs_cam"][ob])))
         got[blk] = set(g["obs_pt"][oa])
-    # ... or, cameras in different groups of four, in the entry list of its super-block (k_schur_super): per point both groups see ONE entry with
-    # the point's records of the row group's cameras (slot = camera % 4) and of the column group's; lists padded to whole rounds of four
-    nsup = len(g["sb_q"]) - 1
-    assert len(g["sb_blk"]) == 16 * nsup and len(g["sb_ent"]) == 8 * g["sb_q"][-1] and np.all(np.diff(g["sb_q"]) % 4 == 0)
-    assert np.all(np.diff(np.diff(g["sb_q"])) <= 0)                      # the longest lists first (padded lengths)
+    # ... or, cameras in different groups of four (eight), in the entry list of its super-block (k_schur_super): per point both groups see ONE entry
+    # with the point's records of the row group's cameras (slot = camera % GS) and of the column group's; the lists of four padded to whole
+    # rounds of four entries.  A point uses either the groups of four alone, or the groups of eight and, inside one, its two halves of four.
     npairs_super = 0
-    for w in range(nsup):
-        blks = g["sb_blk"][16 * w:16 * w + 16].reshape(4, 4)
-        ent = g["sb_ent"][8 * g["sb_q"][w]:8 * g["sb_q"][w + 1]].reshape(-1, 8)
-        real = ent[(ent >= 0).any(axis=1)]
-        assert len(real) > len(ent) - 4 and np.all(ent[len(real):] == -1)
-        pts_seen = []
-        for e in real:
-            ra, rb = e[:4], e[4:]
-            assert (ra >= 0).any() and (rb >= 0).any()
-            oa, ob = rec_obs[ra[ra >= 0]], rec_obs[rb[rb >= 0]]
-            p = g["obs_pt"][oa[0]]
-            assert np.all(g["obs_pt"][oa] == p) and np.all(g["obs_pt"][ob] == p)
-            pts_seen.append(p)
-            for x in np.flatnonzero(ra >= 0):
-                for y in np.flatnonzero(rb >= 0):
-                    ca, cb = g["obs_cam"][rec_obs[ra[x]]], g["obs_cam"][rec_obs[rb[y]]]
-                    assert ca % 4 == x and cb % 4 == y and ca // 4 < cb // 4 and blks[x, y] == up[(ca, cb)]
-                    assert p not in got.setdefault(blks[x, y], set())
-                    got[blks[x, y]].add(p)
-                    npairs_super += 1
-        assert np.all(np.diff(pts_seen) > 0)                             # point order: the sums have a fixed order
+    for GS, kb, kq, ke in ((4, "sb_blk", "sb_q", "sb_ent"), (8, "sb8_blk", "sb8_q", "sb8_ent")):
+        nsup, rnd = len(g[kq]) - 1, 4 if GS == 4 else 1
+        assert len(g[kb]) == GS * GS * nsup and len(g[ke]) == 2 * GS * g[kq][-1] and np.all(np.diff(g[kq]) % rnd == 0)
+        assert np.all(np.diff(np.diff(g[kq])) <= 0)                      # the longest lists first (padded lengths)
+        for w in range(nsup):
+            blks = g[kb][GS * GS * w:GS * GS * (w + 1)].reshape(GS, GS)
+            ent = g[ke][2 * GS * g[kq][w]:2 * GS * g[kq][w + 1]].reshape(-1, 2 * GS)
+            real = ent[(ent >= 0).any(axis=1)]
+            assert len(real) > len(ent) - rnd and np.all(ent[len(real):] == -1)
+            pts_seen = []
+            for e in real:
+                ra, rb = e[:GS], e[GS:]
+                assert (ra >= 0).any() and (rb >= 0).any()
+                oa, ob = rec_obs[ra[ra >= 0]], rec_obs[rb[rb >= 0]]
+                p = g["obs_pt"][oa[0]]
+                assert np.all(g["obs_pt"][oa] == p) and np.all(g["obs_pt"][ob] == p)
+                pts_seen.append(p)
+                for x in np.flatnonzero(ra >= 0):
+                    for y in np.flatnonzero(rb >= 0):
+                        ca, cb = g["obs_cam"][rec_obs[ra[x]]], g["obs_cam"][rec_obs[rb[y]]]
+                        assert ca % GS == x and cb % GS == y and ca // GS < cb // GS and blks[x, y] == up[(ca, cb)]
+                        assert p not in got.setdefault(blks[x, y], set())
+                        got[blks[x, y]].add(p)
+                        npairs_super += 1
+            assert np.all(np.diff(pts_seen) > 0)                         # point order: the sums have a fixed order
+    nsup = len(g["sb_q"]) - 1 + len(g["sb8_q"]) - 1
     assert st["npair_rows"] == len(g["rpair"]) // 2 + npairs_super
     want = {}
     for p in row_pts:
@@ -636,18 +639,21 @@ def test_large_side_files_read_by_threads_equal_the_serial_path(tmp_path, monkey
 
 
 def test_plan_tables_with_super_blocks(monkeypatch):
-    """MI_BA_SUPER=1 (the default from 2^20 row-path pairs on): the pairs whose cameras lie in different groups of four consecutive cameras sit in
-    super-block entry lists, the others stay in the per-block pair lists; together every pair of every row point exactly once (_check_plan)"""
-    monkeypatch.setenv("MI_BA_SUPER", "1")
+    """MI_BA_SUPER=4 (the default from 2^20 row-path pairs on; 8: groups of eight as well, opt-in): the pairs whose cameras lie in different groups of four
+    (eight) consecutive cameras sit in super-block entry lists, the others stay in the per-block pair lists; together every pair of every row point exactly once (_check_plan)"""
     scene = pkg("scene")
     rng = np.random.default_rng(11)
     L = np.minimum(2 + rng.geometric(0.12, 1500), 40)
     for sc in (scene.make_scene("x", m=83, n=1500, d=40, seed=21, strides=(1, 2), track_len=L),
                scene.make_scene("x", m=40, n=600, d=13, seed=5, strides=(1, 2, 3))):
+        monkeypatch.setenv("MI_BA_SUPER", "8")
         st, g = _check_plan(sc)
-        assert len(g["sb_q"]) > 1
+        assert len(g["sb_q"]) > 1 and len(g["sb8_q"]) > 1                         # (both scenes have tracks that reach four groups of eight)
         _check_plan(sc, rank=1, world=2)
         _check_plan(sc, all_rows=True)
+        monkeypatch.setenv("MI_BA_SUPER", "4")
+        st, g = _check_plan(sc)
+        assert len(g["sb_q"]) > 1 and len(g["sb8_q"]) == 1
     monkeypatch.setenv("MI_BA_SUPER", "0")
     st, g = _check_plan(sc)
-    assert len(g["sb_q"]) == 1 and len(g["sb_ent"]) == 0
+    assert len(g["sb_q"]) == 1 and len(g["sb_ent"]) == 0 and len(g["sb8_ent"]) == 0
