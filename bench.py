@@ -279,7 +279,7 @@ def main():
                                    "overlap": 0.0},
             "setup_s": {"scene": t_gen, "plan_upload": t_plan},
             "roofline": {"bound": "hbm", "kernel": "the build: k_build (fused linearise + Schur complement in register tiles) + the row path "
-                                                    "(k_build row tiles, k_long_reduce, k_schur_blocks) between one pair of HIP events",
+                                                    "(k_build row tiles, k_long_reduce, k_schur_pairs, k_schur_super, k_schur_blocks) between one pair of HIP events",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": os.path.relpath(tpath, ROOT) + " (rocprofv3 FETCH_SIZE / WRITE_SIZE passes)" if traffic
                          else "none: no PMC pass under profiles/ was taken on the present kernels.hip / plan.cpp (tools/profile_round.sh)",
