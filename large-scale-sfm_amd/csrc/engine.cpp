@@ -508,8 +508,10 @@ int Engine::prepare()
         !hipok(d_E_.alloc((size_t)mv_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)mv_ * kCP), "alloc dA") ||
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)mv_ * kCP * 8), "alloc pcg") ||
         !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)mv_), "alloc rz/pq") ||
-        !hipok(d_part_.alloc((size_t)(std::max(pl.ntile(), kBacksubGridMax) + pl.ntile() + pl.long_pts.size() + 1) * kPartW), "alloc partials") ||
-        !hipok(d_stage_.alloc((size_t)kReduceStage * kPartW), "alloc reduce stage") ||
+        // partial rows: the build's (a row per tile, per long track), then -- from bs_row0_() on: both sets are summed together at the trial's end -- the
+        // back-substitution's (k_backsub's grid | the long tracks | the uniform tiles)
+        !hipok(d_part_.alloc((size_t)(2 * (pl.ntile() + pl.long_pts.size()) + kBacksubGridMax + pl.ntile() + 2) * kPartW), "alloc partials") ||
+        !hipok(d_stage_.alloc((size_t)2 * kReduceStage * kPartW), "alloc reduce stage") ||
         !hipok(d_cam_part_.alloc((size_t)((mv_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
         !hipok(d_cam_part2_.alloc((size_t)((m_ + 63) / 64 + 1) * kPartW), "alloc camera partials"))
         return MI_BA_ERROR;
@@ -748,8 +750,12 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
         launch_schur_blocks(st_, cnp, sa);
     }
     if (timed) (void)hipEventRecord(ev_[lin_pair_ + 1], st_);
-    launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST,
-                           cfg.world > 1 ? slots1_() + (size_t)cfg.rank * 8 : scal_() + SC_EB_INF);
+    // the build's partial rows (cost, |X|^2, |e_b|inf, ...): nothing on the device needs their sums before the trial's end on one rank -- k_reduce_final
+    // adds them up with the back-substitution's (two launches less per trial); several ranks exchange them now, the parity hooks read them now
+    build_part_pending_ = cfg.world == 1 && !want_diag;
+    if (!build_part_pending_)
+        launch_reduce_partials(st_, pl.ntile() + (int)pl.long_pts.size(), d_part_.p, d_stage_.p, scal_() + SC_COST,
+                               cfg.world > 1 ? slots1_() + (size_t)cfg.rank * 8 : scal_() + SC_EB_INF);
     if (!allreduce1()) return false;
     // the coarse space is built from the first trial after a solve that needed many iterations, and then for the rest of the run
     if (co_.ng && !co_on_ && (co_force_ == 1 || pcg_pred_ >= kTwoLevelFrom)) co_on_ = true;
@@ -942,17 +948,18 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     b.bld_batch_obs = d_batch_obs_.p; b.bld_batch_pt = d_batch_pt_.p;
     b.pt_obs = d_pt_obs_.p; b.obs_cam = d_obs_cam_.p; b.obs_pt = d_obs_pt_.p;
     b.obs_xy = d_obs_xy_.p; b.cam_fixed = d_fixed_real_.p; b.cam_lin = d_cam_lin_[cur_].p; b.cam_lin_new = d_cam_lin_[cur_ ^ 1].p; b.pts = d_pts_[cur_].p;
-    b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p;
+    b.ptout = d_ptout_.p; b.dA = d_dA_.p; b.pts_new = d_pts_[cur_ ^ 1].p; b.dB = dB_dev; b.part = d_part_.p + bs_row0_() * kPartW;
     b.mu = mu; b.eps5 = cfg.lm_variant >= 1 ? 0.0 : cfg.opts[5];   /* (Bundler's rule; under PBA's controller opts[5] is the auto-switch threshold) */ b.nbatch = (int)pl.bs_batch_obs.size(); b.ngrid = std::min(b.nbatch, backsub_grid()); b.cfg = mc; b.scal = scal_();
     const int nlong = (int)pl.long_pts.size();
     b.uni_ntile = pl.bs_uni ? pl.ntile_lds : 0; b.uni_row0 = b.ngrid + nlong; b.uni_fixed = uni_fixed_; b.uni_other = uni_other_;     // partial rows: k_backsub's | the long tracks' | the uniform tiles'
     if (timing_detail >= 2) (void)hipEventRecord(ev_[4], st_);
     launch_backsub(st_, cnp, b);
-    launch_long_backsub(st_, cnp, long_args(mu, dB_dev, b.ngrid));
+    { LongArgs la = long_args(mu, dB_dev, b.ngrid); la.part = b.part; launch_long_backsub(st_, cnp, la); }
     if (timing_detail >= 2) (void)hipEventRecord(ev_[5], st_);
-    launch_reduce_final(st_, b.ngrid + nlong + b.uni_ntile, d_part_.p, d_stage_.p, scal_() + SC_COST_NEW,
+    launch_reduce_final(st_, b.ngrid + nlong + b.uni_ntile, b.part, d_stage_.p, scal_() + SC_COST_NEW,
                         cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT,
-                        m_, mv_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, peek_args(mu));
+                        m_, mv_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, peek_args(mu),
+                        build_part_pending_ ? pl.ntile() + nlong : 0, d_part_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }

@@ -68,6 +68,8 @@ public:
     int comm_info(int out[4]);
     bool pcg_f32_() const;
     bool pcg_cm_() const;
+    bool build_part_pending_ = false;             // the build's partial rows of the present linearisation are summed by the trial's k_reduce_final (engine.cpp linear_phase)
+    size_t bs_row0_() const { return (size_t)plan_.ntile() + plan_.long_pts.size(); }   // first partial row of the back-substitution
     bool pcg_push_ok_ = false;                    // the reduced solve's push halo (opt-in MI_BA_PCG_PUSH=1: mailboxes allocated, symmetric pattern)
     int pcg_f32_force_ = -1; size_t pcg_f32_from_ = (size_t)64 << 20;   // read from the environment by prepare()
     int debug_blocks(double *U, double *W);

@@ -2249,6 +2249,21 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(int nrows, const doubl
     }
 }
 
+// first stage of TWO row sets in one launch (the build's partial rows and the back-substitution's): workgroups [0, G / 2) take set A, the rest set B
+__global__ __launch_bounds__(1024) void k_reduce_partials2(int nA, const double *__restrict__ partA, double *__restrict__ stageA,
+                                                         int nB, const double *__restrict__ partB, double *__restrict__ stageB)
+{
+    __shared__ double sh[16][kPartW];
+    const int half = (int)gridDim.x >> 1, second = (int)blockIdx.x >= half, wg = (int)blockIdx.x - (second ? half : 0);
+    const int nrows = second ? nB : nA;
+    const double *part = second ? partB : partA;
+    double *stage = second ? stageB : stageA;
+    const int chunk = (nrows + half - 1) / half;
+    const int r0 = wg * chunk, r1 = min(nrows, r0 + chunk);
+    const double v = reduce_rows(part, r0, r1, sh);
+    if (threadIdx.x < kPartW) stage[(size_t)wg * kPartW + threadIdx.x] = v;
+}
+
 // The end of a trial in one launch: the last stage of the back-substitution's sums, the camera-side sums k_finalize_vec and
 // k_cam_update left as partial rows (nothing on the device needs them earlier), and -- on one rank, where no exchange
 // comes in between -- the controller's accept test and damping update (k_lm_peek below).
@@ -2256,6 +2271,7 @@ struct FinalReduceArgs {
     const double *bs_part; int bs_rows; double *bs_sum, *bs_max;       // back-substitution (or its first stage's output)
     const double *fv_part; int fv_rows;                                 // k_finalize_vec  -> scal[16, 24)
     const double *cu_part; int cu_rows;                                 // k_cam_update    -> scal[24, 28)
+    const double *bp_part; int bp_rows; double *bp_sum, *bp_max;       // the build's partial rows of this trial's linearisation (one rank; 0 rows: summed after the build already)
     double *scal;
     double *spec; PeekArgs pk;                                          // spec != nullptr: peek
 };
@@ -2266,19 +2282,19 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const FinalReduceArgs a)
 {
     // three sets of rows; each thread's first row of every set is requested before anything is added up, so the three sets
     // cost one round of memory latency (they come from other XCDs' kernels: L2 misses), not three
-    __shared__ double sh[3][16][kPartW];
+    __shared__ double sh[4][16][kPartW];
     const int w = threadIdx.x >> 6, tid = threadIdx.x;
-    const double *part[3] = { a.fv_part, a.cu_part, a.bs_part };
-    const int rows[3] = { a.fv_rows, a.cu_rows, a.bs_rows };
-    double acc[3][kPartW];
+    const double *part[4] = { a.fv_part, a.cu_part, a.bs_part, a.bp_rows > 0 ? a.bp_part : a.bs_part };
+    const int rows[4] = { a.fv_rows, a.cu_rows, a.bs_rows, a.bp_rows };
+    double acc[4][kPartW];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const double *pr = part[k] + (size_t)(tid < rows[k] ? tid : 0) * kPartW;
 #pragma unroll
         for (int c = 0; c < kPartW; ++c) acc[k][c] = pr[c];
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         if (tid >= rows[k]) {
 #pragma unroll
             for (int c = 0; c < kPartW; ++c) acc[k][c] = 0.0;
@@ -2299,13 +2315,14 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const FinalReduceArgs a)
             for (int c = 0; c < kPartW; ++c) sh[k][w][c] = acc[k][c];
     }
     __syncthreads();
-    if (threadIdx.x < 3 * kPartW) {
+    if (threadIdx.x < 4 * kPartW) {
         const int k = threadIdx.x / kPartW, c = threadIdx.x % kPartW, nw = blockDim.x >> 6;
         double v = 0.0;
         for (int i = 0; i < nw; ++i) v = (c < 4) ? v + sh[k][i][c] : fmax(v, sh[k][i][c]);
         if (k == 0) { if (c < 4) a.scal[SC_PL2_CAMS + c] = v; else a.scal[SC_EA_INF + c - 4] = v; }
         else if (k == 1) { if (c < 4) a.scal[SC_DL_CAMS + c] = v; }
-        else { if (c < 4) a.bs_sum[c] = v; else a.bs_max[c - 4] = v; }
+        else if (k == 2) { if (c < 4) a.bs_sum[c] = v; else a.bs_max[c - 4] = v; }
+        else if (a.bp_rows > 0) { if (c < 4) a.bp_sum[c] = v; else a.bp_max[c - 4] = v; }
     }
     if (a.spec) {
         __threadfence_block();
@@ -4235,13 +4252,25 @@ void launch_cam_rebase(hipStream_t st, int m, int row_stride, double *cam_a, dou
 
 // last stage of the back-substitution's reduction (its first stage first when there are many rows) + the camera-side sums + peek
 void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
-                         int m, int mv, const double *fv_part, const double *cu_part, double *scal, double *spec, const PeekArgs &pk)
+                         int m, int mv, const double *fv_part, const double *cu_part, double *scal, double *spec, const PeekArgs &pk,
+                         int bp_rows, const double *bp_part, double *bp_sum, double *bp_max)
 {
     FinalReduceArgs a;
     a.bs_part = bs_part; a.bs_rows = bs_rows;
-    if (bs_rows > 4096) {
-        hipLaunchKernelGGL(k_reduce_partials, dim3(kReduceStage), dim3(1024), 0, st, bs_rows, bs_part, stage, bs_sum, bs_max);
-        a.bs_part = stage; a.bs_rows = kReduceStage;
+    a.bp_part = bp_part; a.bp_rows = bp_rows; a.bp_sum = bp_sum; a.bp_max = bp_max;
+    double *stage2 = stage + (size_t)kReduceStage * kPartW;      // (the stage buffer holds two sets of kReduceStage rows)
+    if (bs_rows > 4096 && bp_rows > 4096) {
+        hipLaunchKernelGGL(k_reduce_partials2, dim3(2 * kReduceStage), dim3(1024), 0, st, bs_rows, bs_part, stage, bp_rows, bp_part, stage2);
+        a.bs_part = stage; a.bs_rows = kReduceStage; a.bp_part = stage2; a.bp_rows = kReduceStage;
+    } else {
+        if (bs_rows > 4096) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3(kReduceStage), dim3(1024), 0, st, bs_rows, bs_part, stage, bs_sum, bs_max);
+            a.bs_part = stage; a.bs_rows = kReduceStage;
+        }
+        if (bp_rows > 4096) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3(kReduceStage), dim3(1024), 0, st, bp_rows, bp_part, stage2, bp_sum, bp_max);
+            a.bp_part = stage2; a.bp_rows = kReduceStage;
+        }
     }
     a.bs_sum = bs_sum; a.bs_max = bs_max;
     a.fv_part = fv_part; a.fv_rows = (mv * kCP + 63) / 64;     // k_finalize_vec: a row per wavefront of (virtual camera, parameter) threads
