@@ -674,7 +674,7 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
             const int v = env ? std::atoi(env) : (np >= kSuperMinPairs ? 4 : 0);
             levels = cam_split ? 0 : v == 0 ? 0 : v == 8 ? 2 : 1;
         }
-        const bool super = levels > 0;
+        bool super = levels > 0;
         // One level = the groups of GS consecutive cameras and the group pairs (row group < column group) with a block in the pattern, as a CSR over
         // row groups (column groups ascending); entries of 2 GS records; per-thread counts, then positions, of the two passes
         struct Level {
@@ -788,6 +788,19 @@ std::string build_plan(Plan &pl, int n, int m, int64_t nobs, const int *pt_idx, 
         };
         if (nrow) run_threads([&](int k) { walk(k, false, nullptr); });
         if (missing) return "internal: block missing from pattern";
+        if (super && nrow && !std::getenv("MI_BA_SUPER")) {
+            // an entry pays when it stands for several pairs: cameras that see the same points have to be neighbours in the numbering (a camera
+            // path, clusters numbered one after the other).  Where they are not -- fewer than kSuperMinFill pairs per entry of the first level --
+            // an entry is little more than a pair with a whole round's overhead: the pair lists then
+            int64_t ents = 0, prs = 0;
+            for (int k = 0; k < nt; ++k) { for (int c2 : lv[0].cnt[k]) ents += c2; prs += lv[0].pairs[k]; }
+            if (ents > 0 && (double)prs < kSuperMinFill * (double)ents) {
+                super = false; levels = 0;
+                for (auto &c2 : cnt) std::fill(c2.begin(), c2.end(), 0);
+                run_threads([&](int k) { walk(k, false, nullptr); });
+                if (missing) return "internal: block missing from pattern";
+            }
+        }
         // block g's pairs: [base[g], base[g + 1]), thread k's share of them after the shares of the threads before it
         std::vector<int64_t> base(nbu + 1, 0);
         std::vector<std::vector<int64_t>> pos(nt);

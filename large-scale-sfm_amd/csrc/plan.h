@@ -68,6 +68,7 @@ constexpr int kMinRunPts = 12;          // a camera set shared by fewer consecut
                                         // mi_ba_config.deterministic sends EVERY point down the row path
 constexpr int kSuperCams = 4;             // cameras per side of a super-block (plan.h sb_blk; k_schur_super: lane = (entry of the round, row camera, column camera))
 constexpr int kSuper8MinGroups = 4;        // a point that reaches this many groups of eight cameras pairs its runs of eight (plan.h sb8_*)
+constexpr double kSuperMinFill = 5.0;       // pairs per entry of the groups of four below which the planner keeps the per-block pair lists (16 at most; C4: 13.3)
 constexpr int64_t kSuperMinPairs = 1 << 20; // row-path pairs from which the super-blocks are worth their tables
 constexpr int kRec = 32;                // doubles per observation record: A (2 x 8) | B (6) | e (2) | G = B V*^-1 (6) | e - B h (2)
 constexpr int kRec9 = 36;               // the same with nine camera parameters: A (2 x 10)

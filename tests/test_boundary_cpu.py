@@ -657,3 +657,17 @@ def test_plan_tables_with_super_blocks(monkeypatch):
     monkeypatch.setenv("MI_BA_SUPER", "0")
     st, g = _check_plan(sc)
     assert len(g["sb_q"]) == 1 and len(g["sb_ent"]) == 0 and len(g["sb8_ent"]) == 0
+
+
+def test_super_blocks_only_where_entries_hold_several_pairs(monkeypatch):
+    """by default (no MI_BA_SUPER) a scene with 2^20 row-path pairs or more gets super-blocks when the cameras that see a point are neighbours in the
+    numbering (13 consecutive cameras: ~10 pairs per entry) and keeps the per-block pair lists when they are not (every 31st camera: one pair per entry)"""
+    monkeypatch.delenv("MI_BA_SUPER", raising=False)
+    scene, capi = pkg("scene"), pkg("capi")
+    for stride, want in ((1, True), (31, False)):
+        sc = scene.make_scene("x", m=410, n=14000, d=13, seed=3, strides=(stride,))
+        pl = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam)
+        st = pl.stats()
+        assert st["npair_rows"] == sc.n * 78 >= 1 << 20
+        assert (len(pl.get("sb_q")) > 1) == want and (len(pl.get("rpair")) // 2 < st["npair_rows"]) == want
+

@@ -1074,3 +1074,30 @@ def test_reduced_solve_with_pushed_vectors(monkeypatch):
         assert np.allclose(res["push"][2][:, 3], res["gather"][2][:, 3], rtol=1e-12)                                     # trial costs
         assert np.allclose(res["push"][3], res["gather"][3], rtol=0, atol=1e-10 * np.abs(res["gather"][3]).max())
 
+
+@pytest.mark.parametrize("levels", ["4", "8"])
+def test_super_blocks_against_the_oracle(oracle, monkeypatch, levels):
+    """k_schur_super (the default from 2^20 row-path pairs on; forced here on scenes the oracle solves): the pairs of cameras in different groups of
+    four (MI_BA_SUPER=8: of eight as well, for the points that reach four such groups) summed from per-point entries of records instead of
+    per-block pair lists -- the same S and E as the oracle's dense blocks and the same solve, tracks of 13 views on three strides and ragged
+    tracks of up to 40 views"""
+    monkeypatch.setenv("MI_BA_SUPER", levels)
+    scene, capi = pkg("scene"), pkg("capi")
+    rng = np.random.default_rng(11)
+    L = np.minimum(2 + rng.geometric(0.12, 500), 40)
+    for sc in (scene.make_scene("x", m=40, n=600, d=13, seed=5, strides=(1, 2, 3)),
+               scene.make_scene("x", m=83, n=500, d=40, seed=21, strides=(1, 2), track_len=L)):
+        pl = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam)
+        assert len(pl.get("sb_q")) > 1 and (len(pl.get("sb8_q")) > 1) == (levels == "8")
+        eng = make_engine(sc, pcg_tol=1e-12, pcg_maxit=400)
+        lin = oracle.linearize(sc, fd_jacobian=0)
+        mu = 1e-3 * max(lin["U"].max(), lin["V"].max())
+        g = eng.debug_linearize(mu)
+        S, E, _ = reduced_system(lin, sc, mu)
+        assert np.abs(g["S"] - S).max() < 1e-10 * np.abs(lin["U"]).max()
+        assert rel(g["E"].reshape(-1), E) < 1e-9
+        ret, info = eng.run()
+        o = oracle.run(sc, itmax=150, fd_jacobian=0)
+        assert ret == o["ret"] and abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
+        eng.close()
+

@@ -1,5 +1,6 @@
 """One damping trial as the GPU saw it, from a rocprofv3 rocpd database: every dispatch between two k_build launches with its
-start offset, duration and the idle gap before it:   python tools/trial_timeline.py <results.db> [trial index, default 6]"""
+start offset, duration and the idle gap before it:   python tools/trial_timeline.py <results.db> [trial index, default 6] [marker kernel, default k_build;
+k_zero for scenes whose build is several launches]"""
 import sqlite3
 import sys
 
@@ -8,7 +9,8 @@ cur = db.cursor()
 names = dict(cur.execute("select id, kernel_name from rocpd_info_kernel_symbol").fetchall())
 rows = sorted(cur.execute("select start, end, kernel_id from rocpd_kernel_dispatch").fetchall())
 short = lambda n: n.split("(")[0].replace("miba::", "")[:60]
-starts = [i for i, (s, e, k) in enumerate(rows) if "k_build" in names.get(k, "")]
+marker = sys.argv[3] if len(sys.argv) > 3 else "k_build"
+starts = [i for i, (s, e, k) in enumerate(rows) if marker in names.get(k, "")]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 a, b = starts[which], starts[which + 1]
 t0 = rows[a][0]
