@@ -1058,6 +1058,8 @@ def test_reduced_solve_with_pushed_vectors(monkeypatch):
     (kernels.hip push_row) and the product reads them by block position instead of gathering by column index -- the same sums in the same
     order, so the same iterates as the default to rounding, on a workgroup-per-row scene (C1) and a wavefront-per-row one (1 000 cameras)"""
     scenes = [scene_from_golden("C1")[0], pkg("scene").make_scene("x", m=1000, n=20000, d=6, seed=4, strides=(1, 3))]
+    monkeypatch.delenv("MI_BA_PCG_F32_FROM_MB", raising=False)     # (the mailboxes go with the f64 matrix)
+    monkeypatch.delenv("MI_BA_PCG_F32", raising=False)
     for sc in scenes:
         res = {}
         for mode in ("gather", "push"):
