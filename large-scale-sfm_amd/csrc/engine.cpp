@@ -19,6 +19,7 @@ namespace {
 constexpr double kEpsilonSq = 1E-12 * 1E-12; // SBA_EPSILON_SQ, sba_levmar.c:37-38
 constexpr double kOneThird = 0.3333333334;   // SBA_ONE_THIRD, sba_levmar.c:40
 constexpr int kBuildTimedEvery = 4;          // mi_ba_set_timing_detail(1): every fourth build is bracketed by HIP events (both buffers of the double-buffered pair in turn)
+constexpr double kPcgEllMaxFill = 1.25;        // the CG's matrix at a fixed row pitch while padding every block row to the longest costs at most this factor
 constexpr size_t kPcgF32FromBytes = 64u << 20;   // the scaled matrix goes single precision above this size (pcg_f32_)
 constexpr int kPcgChunk = 8;                 // PCG iterations launched between two host checks
 constexpr int kPcgRowPerWorkgroupMax = 512; // up to this many cameras a block row of S~ gets a whole workgroup (4 wavefronts), above: a wavefront
@@ -363,6 +364,23 @@ int Engine::prepare()
             }
         // (opt-in, MI_BA_PCG_PUSH=1: measured SLOWER than the gather by column index -- C3 0.38 against 0.26 ms per solve, C2 0.208 / 0.202, C1 0.066 / 0.056:
         //  the mailboxes are 37 x the vectors' bytes, written and read across the XCDs every iteration)
+        {   // fixed-pitch copy of the pattern for the CG (PcgArgs.ell_w): every block row padded to the longest one, the pads zero blocks in the own column
+            int W = 0;
+            for (int j = 0; j < mv_; ++j) W = std::max(W, pl.bsr_row[j + 1] - pl.bsr_row[j]);
+            const char *env = std::getenv("MI_BA_PCG_ELL");
+            pcg_ell_w_ = (env ? std::atoi(env) != 0 : true) && W > 0 && (double)mv_ * W <= kPcgEllMaxFill * pl.nb_full() ? W : 0;
+            if (pcg_ell_w_) {
+                std::vector<int> ecol((size_t)mv_ * W), epos(pl.nb_full());
+                for (int j = 0; j < mv_; ++j)
+                    for (int t = 0; t < W; ++t) {
+                        const int q = pl.bsr_row[j] + t;
+                        const bool real = q < pl.bsr_row[j + 1];
+                        ecol[(size_t)j * W + t] = real ? pl.bsr_col[q] : j;
+                        if (real) epos[q] = j * W + t;
+                    }
+                UP(d_ell_col_, ecol); UP(d_ell_pos_, epos);
+            }
+        }
         pcg_push_ok_ = sym && (size_t)pl.nb_full() * 64 * sizeof(double) <= kPcgF32FromBytes && std::getenv("MI_BA_PCG_PUSH") && std::atoi(std::getenv("MI_BA_PCG_PUSH")) != 0;
         if (pcg_push_ok_) UP(d_bsr_tq_, tq);
     }
@@ -504,7 +522,7 @@ int Engine::prepare()
     }
     const size_t acc_n = 2 * nslot_() + (size_t)pl.nb_up() * 64 + (size_t)3 * mv_ * kCP + kScalCount;
     if (!hipok(d_ptout_.alloc(npl * kPtOut), "alloc ptout") || !hipok(d_acc_.alloc(acc_n), "alloc acc") ||
-        !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Linv_.alloc((size_t)mv_ * 64), "alloc Linv") || !hipok(d_S_pcg_.alloc((size_t)pl.nb_full() * 64), "alloc S~") ||
+        !hipok(d_S_full_.alloc((size_t)pl.nb_full() * 64), "alloc S") || !hipok(d_Linv_.alloc((size_t)mv_ * 64), "alloc Linv") || !hipok(d_S_pcg_.alloc(std::max((size_t)pl.nb_full(), (size_t)mv_ * pcg_ell_w_) * 64), "alloc S~") ||
         !hipok(d_E_.alloc((size_t)mv_ * kCP), "alloc E") || !hipok(d_dA_.alloc((size_t)mv_ * kCP), "alloc dA") ||
         !hipok(d_dB_.alloc(npl * 3), "alloc dB") || !hipok(d_pcg_.alloc((size_t)mv_ * kCP * 8), "alloc pcg") ||
         !hipok(d_rzpq_.alloc(2 * (size_t)(cfg.pcg_maxit + 4) + 4 * (size_t)mv_), "alloc rz/pq") ||
@@ -518,6 +536,7 @@ int Engine::prepare()
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (!hipok(hipMemset(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double)), "memset rz/pq")) return MI_BA_ERROR;
     if (pcg_push_ok_ && (!hipok(d_mb_.alloc(2 * (size_t)pl.nb_full() * 24), "alloc CG mailboxes") || !hipok(hipMemset(d_mb_.p, 0, d_mb_.n * sizeof(double)), "memset CG mailboxes"))) return MI_BA_ERROR;
+    if (pcg_ell_w_ && !hipok(hipMemset(d_S_pcg_.p, 0, d_S_pcg_.n * sizeof(double)), "memset S~")) return MI_BA_ERROR;   // (the pads stay zero: only blocks of the pattern are ever written)
     if (!hipok(d_spec_.alloc(2), "alloc spec") || !hipok(hipMemset(d_spec_.p, 0, 2 * sizeof(double)), "memset spec")) return MI_BA_ERROR;
     if (cfg.pcg_maxit + 4 > 500) { err = "pcg_maxit too large (max 496)"; return MI_BA_ERROR; }
     if (std::getenv("MI_BA_PCG_STAMPS")) {
@@ -760,6 +779,11 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
     // the coarse space is built from the first trial after a solve that needed many iterations, and then for the rest of the run
     if (co_.ng && !co_on_ && (co_force_ == 1 || pcg_pred_ >= kTwoLevelFrom)) co_on_ = true;
     co_active_ = co_.ng && co_on_;
+    if (pcg_ell_w_) {   // the fixed-pitch matrix relies on its pads being zero: a trial that wrote the buffer in another layout (block b at b) has soiled them
+        const bool ell_now = pcg_args().ell_w != 0;
+        if (ell_now && ell_pads_dirty_ && !hipok(hipMemsetAsync(d_S_pcg_.p, 0, d_S_pcg_.n * sizeof(double), st_), "memset S~")) return false;
+        ell_pads_dirty_ = !ell_now;
+    }
     launch_finalize(st_, cnp_cam_(), mv_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
                     d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag /* a linear phase on its own (begin, parity hooks) */, pcg_start(),
@@ -802,7 +826,7 @@ PcgStart Engine::pcg_start()
     const PcgArgs p = pcg_args();
     timing.pcg_matrix_f32 = pcg_f32_() ? 1.0 : 0.0;
     timing.pcg_push = p.mb0 ? 1.0 : 0.0;
-    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr, pcg_f32_() ? 1 : pcg_cm_() ? 2 : 0 };
+    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr, p.ell_w ? d_ell_pos_.p : nullptr, pcg_f32_() ? 1 : pcg_cm_() ? 2 : 0 };
 }
 
 PcgArgs Engine::pcg_args()
@@ -812,6 +836,7 @@ PcgArgs Engine::pcg_args()
     p.bsr_row = d_bsr_row_.p; p.bsr_col = d_bsr_col_.p; p.S = d_S_pcg_.p; p.Linv = d_Linv_.p; p.E = d_E_.p;
     p.S32 = pcg_f32_() ? reinterpret_cast<const float *>(d_S_pcg_.p) : nullptr;
     p.cm = pcg_cm_() ? 1 : 0;
+    if (p.cm && pcg_ell_w_ && !pcg_push_ok_) { p.ell_w = pcg_ell_w_; p.bsr_col = d_ell_col_.p; }
     if (p.cm && pcg_push_ok_) { p.mb0 = d_mb_.p; p.mb1 = d_mb_.p + (size_t)plan_.nb_full() * 24; p.bsr_tq = d_bsr_tq_.p; }
     double *v = d_pcg_.p;
     p.da = d_dA_.p; p.x = v; p.p = v + vec; p.r0 = v + 2 * vec; p.r1 = v + 3 * vec; p.w0 = v + 4 * vec; p.w1 = v + 5 * vec;

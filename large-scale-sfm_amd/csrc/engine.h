@@ -68,6 +68,8 @@ public:
     int comm_info(int out[4]);
     bool pcg_f32_() const;
     bool pcg_cm_() const;
+    int pcg_ell_w_ = 0;                           // row pitch of the CG's fixed-pitch matrix (0: rows by bsr_row): prepare()
+    bool ell_pads_dirty_ = false;                 // ... its pads have been written over by a trial in another layout
     bool build_part_pending_ = false;             // the build's partial rows of the present linearisation are summed by the trial's k_reduce_final (engine.cpp linear_phase)
     size_t bs_row0_() const { return (size_t)plan_.ntile() + plan_.long_pts.size(); }   // first partial row of the back-substitution
     bool pcg_push_ok_ = false;                    // the reduced solve's push halo (opt-in MI_BA_PCG_PUSH=1: mailboxes allocated, symmetric pattern)
@@ -147,7 +149,7 @@ private:
 
     // device: plan
     DevBuf<int> d_tile_batch_, d_tile_slot_, d_tile_cslot_, d_slot_gblk_, d_cslot_cam_, d_batch_obs_, d_batch_pt_, d_pt_obs_,
-        d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_, d_bsr_tq_;
+        d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_, d_bsr_tq_, d_ell_col_, d_ell_pos_;
     DevBuf<long long> d_batch_pair_;
     DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_, d_pfix_;   // per ROW of the camera-side arrays: held camera; bit r = parameter r held constant
     DevBuf<unsigned char> d_fixed_real_;                                    // per real camera (the point-side kernels)

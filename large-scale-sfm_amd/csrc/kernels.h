@@ -147,7 +147,7 @@ struct SchurArgs {
 };
 
 // where the CG starts: written by k_block_inv, which holds L^-1 of every camera's diagonal block anyway
-struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; int layout /* of the scaled matrix in S_pcg: 0 f64 blocks row-major, 1 single precision (PcgArgs.S32), 2 f64 in the product's column form (PcgArgs.cm) */; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
+struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; const int *ellpos /* with PcgArgs.ell_w: where block b of the pattern goes in the padded matrix; nullptr: at b */; int layout /* of the scaled matrix in S_pcg: 0 f64 blocks row-major, 1 single precision (PcgArgs.S32), 2 f64 in the product's column form (PcgArgs.cm) */; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
 // grid-barrier words of the persistent reduced solve (u64, 64-byte apart): root counter, generation, abort, one counter per group
 constexpr int kBarRoot = 0, kBarGen = 8, kBarAbort = 16, kBarGroup0 = 32, kBarMaxGroups = 32, kBarWords = kBarGroup0 + 8 * kBarMaxGroups;
 
@@ -172,6 +172,8 @@ struct PcgArgs {
     int cm;                                            // S (f64) holds each block in the product's column form (k_scale_blocks layout 2) instead of row-major
     double *mb0, *mb1;                                 // push halo (with cm): per block q of the pattern the r | w | s (3 x 8) of block row bsr_col[q], by iteration parity; nullptr: gathered by column index
     const int *bsr_tq;                                 // ... and where block q's transpose sits: bsr_col[bsr_tq[q]] = row of q
+    int ell_w;                                         // > 0: S and bsr_col hold every block row at the fixed pitch ell_w (padded with zero blocks in the own column): row j = [j ell_w, (j + 1) ell_w)
+                                                       // -- no row pointer between the kernel's arguments and the first matrix loads (engine.cpp pcg_ell_)
     double *x, *da, *p, *r0, *r1, *w0, *w1, *s0, *s1;  // r, w, s alternate by iteration parity (read by the neighbours' rows)
     double *gp, *dp, *rz_hist, *alpha_hist, *scal;     // gp, dp [2][nwg]: partials of r.r and w.r per workgroup; histories [maxit+2]
     double tol;

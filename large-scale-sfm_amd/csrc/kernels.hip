@@ -2488,18 +2488,18 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
 // chain of two memory round trips and three LDS exchanges per block, 4.5 (C3) to 50 (C4) of them one after the other per wavefront slot
 // (C3 19.5 us, C4 184 us for 26 / 260 MB).  Diagonal blocks are the identity by construction: nothing is fetched for them.
 // layout 1: the scaled matrix is stored in single precision instead (PcgArgs.S32: the CG then streams half the bytes; engine.cpp pcg_f32_)
-__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg, int layout)
+__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg, int layout, const int *__restrict__ ellpos)
 {
     __shared__ double sh[4][4][64];   // per wavefront: S, T = Linv_j S, Linv_j, Linv_k
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
     const int nw = (int)gridDim.x * 4;
     int b = (int)blockIdx.x * 4 + wv;                 // (left a per-lane value on purpose: made wave-uniform, every index load is followed by a wait for its v_readfirstlane)
     if (b >= nb) return;
-    struct Idx { int j, k, src, trans; };
+    struct Idx { int j, k, src, trans, pos; };        // pos: where the block goes (the fixed-pitch matrix of the CG: PcgArgs.ell_w)
     struct Dat { double s, lj, lk; int fx, pj, pk; };
     auto ldidx = [&](int bb) {                        // (past the end: the last block again, never used)
         const int q = bb < nb ? bb : nb - 1;
-        return Idx{ f.rowidx[q], f.col[q], f.src[q], (int)f.trans[q] };
+        return Idx{ f.rowidx[q], f.col[q], f.src[q], (int)f.trans[q], ellpos ? ellpos[q] : q };
     };
     auto lddat = [&](const Idx &x) {                  // every load unconditional and independent of the others
         Dat d;
@@ -2536,7 +2536,7 @@ __global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs
         // the vector for them.  f64 (layout 2): element (r, c) at ((r >> 1) * 8 + c) * 2 + (r & 1) -- rows 2h, 2h + 1 of column c in one 16-byte load.
         // Single precision (layout 1): at ((r >> 2) * 8 + c) * 4 + (r & 3) -- rows 4h .. 4h + 3 of column c in one 16-byte load.
         if (layout == 1) reinterpret_cast<float *>(S_pcg)[(size_t)b * 64 + (((r >> 2) * 8 + c) * 4 + (r & 3))] = (float)val;
-        else if (layout == 2) S_pcg[(size_t)b * 64 + (((r >> 1) * 8 + c) * 2 + (r & 1))] = val;
+        else if (layout == 2) S_pcg[(size_t)i0.pos * 64 + (((r >> 1) * 8 + c) * 2 + (r & 1))] = val;
         else S_pcg[(size_t)b * 64 + lane] = val;
         i0 = i1; i1 = i2; d0 = d1;
     }
@@ -2885,7 +2885,7 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_start(const PcgArgs a)
     const int lane = threadIdx.x & 63, j = ROWS == 4 ? blockIdx.x * 4 + (threadIdx.x >> 6) / WPR : blockIdx.x, r = lane >> 3, c = lane & 7;
     const bool live = j < a.m;
     const int jj = live ? j : 0;
-    const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
+    const int q0 = a.ell_w ? jj * a.ell_w : a.bsr_row[jj], q1 = !live ? q0 : a.ell_w ? q0 + a.ell_w : a.bsr_row[jj + 1];
     const double *const vec[1] = { a.r0 };
     double w[1];
     constexpr int SH = ROWS == 4 ? WPR : 4;
@@ -3337,7 +3337,7 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
     else if (kOwn || threadIdx.x < 64)
         for (int i = lane; i < a.nwg; i += 64) { gs += a.gp[(size_t)par * a.nwg + i]; ds += a.dp[(size_t)par * a.nwg + i]; }
     const double g_prev = a.rz_hist[prev], g_zero = a.rz_hist[0], a_prev = a.alpha_hist[prev];
-    const int q0 = a.bsr_row[jj], q1 = live ? a.bsr_row[jj + 1] : q0;
+    const int q0 = a.ell_w ? jj * a.ell_w : a.bsr_row[jj], q1 = !live ? q0 : a.ell_w ? q0 + a.ell_w : a.bsr_row[jj + 1];   // (fixed pitch: nothing to wait for)
     const double r_own = rc[idx], w_own = wc[idx], s_own = so[idx], p_own = a.p[idx], x_own = a.x[idx];
     constexpr int SH = ROWS == 4 ? WPR : 4;
     const int part = (threadIdx.x >> 6) % SH;
@@ -4107,7 +4107,7 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
     hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
-    hipLaunchKernelGGL(k_scale_blocks, dim3(std::min((nb + 3) / 4, kScaleBlocksGrid)), dim3(256), 0, st, nb, f, Linv, S_pcg, ps.layout);
+    hipLaunchKernelGGL(k_scale_blocks, dim3(std::min((nb + 3) / 4, kScaleBlocksGrid)), dim3(256), 0, st, nb, f, Linv, S_pcg, ps.layout, ps.layout == 2 ? ps.ellpos : nullptr);
     if (co.ng) {   // the coarse space of this trial's system: Z'SZ, its inverse, S~Z~
         static_assert(kBcSlots == 4, "k_coarse_bc: one wavefront per slot");
         hipLaunchKernelGGL(k_coarse_bc, dim3(m), dim3(256), 0, st, m, bsr_row, bsr_col, (const double *)S_pcg, co);
