@@ -2560,7 +2560,12 @@ __global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs
 __device__ __forceinline__ double wave_total(const double *__restrict__ v, int n, int lane)
 {
     double s = 0.0;
-    for (int i = lane; i < n; i += 64) s += v[i];
+    for (int i0 = lane; i0 < n; i0 += 256) {          // (four loads in flight: a load and an add per trip is a chain of round trips)
+        double t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + 64 * k; t[k] = v[i < n ? i : n - 1]; if (i >= n) t[k] = 0.0; }
+        s += (t[0] + t[1]) + (t[2] + t[3]);
+    }
     return wave_sum(s);
 }
 
@@ -3326,6 +3331,9 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
     const bool live = j < a.m;
     const int jj = live ? j : 0, idx = jj * 8 + r;
     const double *__restrict__ rc = par ? a.r1 : a.r0, *__restrict__ wc = par ? a.w1 : a.w0, *__restrict__ so = par ? a.s1 : a.s0;
+    constexpr int SH = ROWS == 4 ? WPR : 4;
+    const int part = (threadIdx.x >> 6) % SH;
+    const double *const vec[3] = { rc, wc, so };
     // round 1
     const double st = a.scal[SC_PCG_STATUS], dn = a.scal[SC_PCG_DONE];
     // the two dot products of the last launch, one partial per workgroup: with a wavefront per block row every wavefront adds
@@ -3335,17 +3343,24 @@ __global__ __launch_bounds__(256 * WPR) void k_pcg_iter(const PcgArgs a)
     double gs = 0.0, ds = 0.0;
     if (a.tot) { if (lane == 0) { gs = a.tot[par * 2]; ds = a.tot[par * 2 + 1]; } }      // (the wave sums below add zeros to it)
     else if (kOwn || threadIdx.x < 64)
-        for (int i = lane; i < a.nwg; i += 64) { gs += a.gp[(size_t)par * a.nwg + i]; ds += a.dp[(size_t)par * a.nwg + i]; }
+        // (four partials per lane requested at once: a loop of one load and one add per trip was a chain of nwg / 64 round trips to another XCD's data)
+        for (int i0 = lane; i0 < a.nwg; i0 += 256) {
+            double gv[4], dv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int i = i0 + 64 * t, ic = i < a.nwg ? i : a.nwg - 1;
+                gv[t] = a.gp[(size_t)par * a.nwg + ic]; dv[t] = a.dp[(size_t)par * a.nwg + ic];
+                if (i >= a.nwg) { gv[t] = 0.0; dv[t] = 0.0; }
+            }
+            gs += (gv[0] + gv[1]) + (gv[2] + gv[3]); ds += (dv[0] + dv[1]) + (dv[2] + dv[3]);
+        }
     const double g_prev = a.rz_hist[prev], g_zero = a.rz_hist[0], a_prev = a.alpha_hist[prev];
     const int q0 = a.ell_w ? jj * a.ell_w : a.bsr_row[jj], q1 = !live ? q0 : a.ell_w ? q0 + a.ell_w : a.bsr_row[jj + 1];   // (fixed pitch: nothing to wait for)
     const double r_own = rc[idx], w_own = wc[idx], s_own = so[idx], p_own = a.p[idx], x_own = a.x[idx];
-    constexpr int SH = ROWS == 4 ? WPR : 4;
-    const int part = (threadIdx.x >> 6) % SH;
     const int tq_first = a.mb0 ? push_first(a, q0, q1, part, lane) : 0;
     if (st != 0.0 || dn != 0.0) return;
     PSTAMP(1);
     // rounds 2 and 3
-    const double *const vec[3] = { rc, wc, so };
     double S3[3];
     if (!kOwn && threadIdx.x < 64) {                 // (the barrier inside workgroup_row_products orders this against the reads below)
         const double gsum = wave_sum(gs), dsum = wave_sum(ds);
