@@ -531,7 +531,7 @@ int Engine::prepare()
         !hipok(d_part_.alloc((size_t)(2 * (pl.ntile() + pl.long_pts.size()) + kBacksubGridMax + pl.ntile() + 2) * kPartW), "alloc partials") ||
         !hipok(d_stage_.alloc((size_t)2 * kReduceStage * kPartW), "alloc reduce stage") ||
         !hipok(d_cam_part_.alloc((size_t)((mv_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
-        !hipok(d_cam_part2_.alloc((size_t)((m_ + 63) / 64 + 1) * kPartW), "alloc camera partials"))
+        !hipok(d_cam_part2_.alloc((size_t)((m_ + 7) / 8 + 1) * kPartW), "alloc camera partials"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
     if (!hipok(hipMemset(d_rzpq_.p, 0, d_rzpq_.n * sizeof(double)), "memset rz/pq")) return MI_BA_ERROR;

@@ -3691,6 +3691,64 @@ __global__ void k_cam_update(int m, int cnp, ModelCfg cfg, const unsigned char *
     }
 }
 
+// The same with EIGHT lanes per camera, lane = (camera, parameter) -- every camera model but the nine-parameter one (cfg.split).  A thread per camera
+// was 16 wavefronts on a 1 000-camera scene, each lane walking its own 512-byte block of L^-1 (64 loads of 64 different lines per instruction) and
+// then the rotation's exponential: 12.6 us between the reduced solve and the back-substitution.  Here a camera's eight lanes read its block of
+// L^-1 as one contiguous piece, the new parameters meet in the camera's first lane through LDS for the record.  A partial row per wavefront = 8 cameras.
+__global__ __launch_bounds__(64) void k_cam_update8(int m, int cnp, ModelCfg cfg, const unsigned char *__restrict__ fixed, double mu, const double *__restrict__ cam_a,
+                                                 const PcgArgs pa, double *__restrict__ dA, const double *__restrict__ camvec,
+                                                 const double *__restrict__ R0, const double *__restrict__ f_fixed, const CamLinks lk,
+                                                 double *__restrict__ cam_a_new, double *__restrict__ cam_lin_new, double *__restrict__ part, double *__restrict__ R0_new)
+{
+    __shared__ double sA[64];
+    if (pa.tail && blockIdx.x == 0) pcg_tail(pa);
+    const int lane = threadIdx.x, r = lane & 7, j = blockIdx.x * 8 + (lane >> 3);
+    double dl = 0.0, dp2 = 0.0, lc = 0.0;
+    const bool on = j < m;
+    const int jj = on ? j : 0;
+    const double dj = scaled_back(pa, jj, r);
+    const bool live = on && r < cnp && !fixed[jj];
+    const double d = live ? dj : 0.0;
+    double a_new = cam_a[jj * kCP + r] + d;
+    // PBA's UpdateCamera keeps the focal length positive: f = max(f + d, 1e-10) (SparseBundleCPU.cpp:1082), in its own units
+    if (cfg.pba_update && cfg.est_focal && r == 6 && live) a_new = fmax(a_new, 1e-10 * cfg.f_scale);
+    const double D = cfg.damp_diag ? camvec[(2 * (size_t)m + jj) * kCP + r] : 1.0;   // PBA: dL = d'(mu D d + g), |d|^2 in D's metric
+    if (on) {
+        dA[j * kCP + r] = dj;
+        cam_a_new[j * kCP + r] = a_new;
+        dl = d * (mu * D * d + camvec[j * kCP + r]);
+        dp2 = D * d * d;
+    }
+    sA[lane] = a_new;
+    wave_lds_sync();
+    if (on && r == 0) {
+        double an[9];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) an[i] = sA[lane + i];
+        an[8] = 0.0;
+        cam_record(cfg, cnp, an, R0 + (size_t)j * 9, f_fixed ? f_fixed[j] : 1.0, cam_lin_new + (size_t)j * kCamLin);
+        if (cfg.pba_update && R0_new) {   // PBA's update of the rotation (k_cam_update above)
+            double *cl = cam_lin_new + (size_t)j * kCamLin;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { R0_new[(size_t)j * 9 + i] = cl[i]; cl[9 + i] = (i % 4 == 0) ? 1.0 : 0.0; }
+            cam_a_new[j * kCP + 3] = 0.0; cam_a_new[j * kCP + 4] = 0.0; cam_a_new[j * kCP + 5] = 0.0;
+        }
+        if (lk.row)                                            // link penalty at the trial point
+            for (int q = lk.row[j]; q < lk.row[j + 1]; ++q) {
+                const int k = lk.other[q];
+                for (int rr = 0; rr < (cnp < kCP ? cnp : kCP); ++rr) {
+                    const double ak = cam_a[k * kCP + rr] + (fixed[k] ? 0.0 : scaled_back(pa, k, rr)), dq = ak - an[rr];
+                    lc = fma(0.5 * lk.w[(size_t)q * kCP + rr], dq * dq, lc);
+                }
+            }
+    }
+    dl = wave_sum(dl); dp2 = wave_sum(dp2); lc = wave_sum(lc);
+    if (lane == 0) {
+        double *pr = part + (size_t)blockIdx.x * kPartW;
+        pr[0] = dl; pr[1] = dp2; pr[2] = lc; pr[3] = 0.0; pr[4] = 0.0; pr[5] = 0.0; pr[6] = 0.0; pr[7] = 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_backsub: db_i = V*^-1 (eb_i - sum_j W_ij^T da_j) = h_i - V*^-1 sum_j B^T (A da_j)
 // (sba_levmar.c:1393-1433), trial point, cost at p + dp (:1468-1476), dL and ||dp||^2 point parts,
@@ -4256,8 +4314,10 @@ void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, cons
                        double *dA, const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,
                        double *cam_lin_new, double *cam_part, double *R0_new)
 {
-    hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, pa, dA, camvec, R0, f_fixed,
-                       links, cam_a_new, cam_lin_new, cam_part, R0_new);
+    if (!cfg.split) hipLaunchKernelGGL(k_cam_update8, dim3((m + 7) / 8), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, pa, dA, camvec, R0, f_fixed,
+                                       links, cam_a_new, cam_lin_new, cam_part, R0_new);
+    else hipLaunchKernelGGL(k_cam_update, dim3((m + 63) / 64), dim3(64), 0, st, m, cnp, cfg, fixed, mu, cam_a, pa, dA, camvec, R0, f_fixed,
+                            links, cam_a_new, cam_lin_new, cam_part, R0_new);
 }
 
 void launch_cam_rebase(hipStream_t st, int m, int row_stride, double *cam_a, double *cam_lin, double *R0)
@@ -4289,7 +4349,7 @@ void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, dou
     }
     a.bs_sum = bs_sum; a.bs_max = bs_max;
     a.fv_part = fv_part; a.fv_rows = (mv * kCP + 63) / 64;     // k_finalize_vec: a row per wavefront of (virtual camera, parameter) threads
-    a.cu_part = cu_part; a.cu_rows = (m + 63) / 64;            // k_cam_update: a thread per real camera
+    a.cu_part = cu_part; a.cu_rows = mv == m ? (m + 7) / 8 : (m + 63) / 64;   // k_cam_update8: eight cameras per wavefront (k_cam_update, nine parameters: 64)
     a.scal = scal; a.spec = spec; a.pk = pk;
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, st, a);
 }
