@@ -285,7 +285,7 @@ def main():
                          else "none: no PMC pass under profiles/ was taken on the present kernels.hip / plan.cpp (tools/profile_round.sh)",
                          "algorithmic_bytes_per_launch": tm["build_bytes"],
                          "algorithmic_bytes_formula": "24 k + 96 n + 192 m + 512 nb_up (SURVEY 8d Pass A in f64; the engine's own tables are not in it)",
-                         "engine_table_bytes_per_launch": tm["build_index_bytes"], "avg_launch_ms": build_ms,
+                         "engine_table_bytes_per_launch": tm["build_index_bytes"], "block_handovers_per_launch": tm.get("build_block_handovers"), "avg_launch_ms": build_ms,
                          # the kernel is not HBM-bound: its arithmetic against the f64 vector peak
                          "valu_f64": {"achieved": tm["build_flops"] / (build_ms * 1e-3) / 1e12 if build_ms > 0 else 0.0,
                                       "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -195,7 +195,9 @@ typedef struct {
     double pcg_matrix_f32;                 /* 1: the reduced solve streams its scaled matrix in single precision (systems whose matrix exceeds 64 MB at the
                                             * default tolerance; vectors, dot products and recurrences f64) -- engine.cpp pcg_f32_ */
     double pcg_push;                       /* 1: the reduced solve reads its neighbours' vectors from per-block mailboxes (opt-in MI_BA_PCG_PUSH=1) */
-    double reserved[8];                    /* the struct stays 32 doubles from here on: new figures come out of this tail */
+    double build_block_handovers;          /* blocks of S the tiles of one build launch hand over with f64 atomics (or as per-tile copies): the plan's slots summed
+                                            * over the tiles -- exact for the tiles of one camera set (one hand-over per block and tile), a lower bound for the others */
+    double reserved[7];                    /* the struct stays 32 doubles from here on: new figures come out of this tail */
 } mi_ba_timing;
 /* ABI note: the struct grew twice before it got its tail (17 doubles in round 1, 21 in round 2, 32 now).  mi_ba_get_timing is the
  * symbol every one of those headers declares, so it only ever writes the 17 doubles they all share (build_ms .. build_index_bytes);

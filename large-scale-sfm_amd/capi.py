@@ -35,7 +35,7 @@ class Config(C.Structure):
 class Timing(C.Structure):
     _fields_ = [(k, C.c_double) for k in
                 ("build_ms", "build_launches", "pcg_ms", "pcg_solves", "pcg_iters", "backsub_ms", "backsub_launches",
-                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes", "pcg_resumes", "build_flops", "pcg_timed", "spec_adopted", "build_index_bytes", "exchange_ms", "exchanges_timed", "replicated_ms", "replicated_timed", "pcg_persistent", "pcg_matrix_f32", "pcg_push")] + [("reserved", C.c_double * 8)]
+                 "step_ms", "steps", "allreduce_ms", "allreduces", "build_bytes", "pcg_resumes", "build_flops", "pcg_timed", "spec_adopted", "build_index_bytes", "exchange_ms", "exchanges_timed", "replicated_ms", "replicated_timed", "pcg_persistent", "pcg_matrix_f32", "pcg_push", "build_block_handovers")] + [("reserved", C.c_double * 7)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

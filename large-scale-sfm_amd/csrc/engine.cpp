@@ -559,6 +559,7 @@ int Engine::prepare()
     // camera its 192-B record, every upper block of S once (512 B).  The engine's own index tables (pair entries, batch and
     // tile descriptors) and the row path's observation records are NOT problem data: they are reported beside it.
     timing.build_bytes = 24.0 * (double)pl.nobs_local() + 96.0 * (double)npl + 192.0 * m_ + 512.0 * pl.nb_up();
+    timing.build_block_handovers = (double)pl.slot_gblk.size();
     timing.build_index_bytes = 1.0 * (double)pl.nobs_local() + 4.0 * (double)pl.pair.size() + 8.0 * (double)(pl.rpair.size() / 2) + 4.0 * (double)(pl.sb_ent.size() + pl.sb8_ent.size()) +
                                2.0 * 8.0 * kRec * (double)pl.rec_cam[m_];
     {   // arithmetic of the same launch (for the f64 vector roofline beside the HBM one)
