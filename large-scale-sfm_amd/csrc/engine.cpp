@@ -362,6 +362,7 @@ int Engine::prepare()
                 if (f == e) { sym = false; break; }
                 tq[q] = (int)(f - pl.bsr_col.data());
             }
+        if (!sym) { err = "internal: the pattern of S is not symmetric"; return MI_BA_ERROR; }
         // (opt-in, MI_BA_PCG_PUSH=1: measured SLOWER than the gather by column index -- C3 0.38 against 0.26 ms per solve, C2 0.208 / 0.202, C1 0.066 / 0.056:
         //  the mailboxes are 37 x the vectors' bytes, written and read across the XCDs every iteration)
         {   // fixed-pitch copy of the pattern for the CG (PcgArgs.ell_w): every block row padded to the longest one, the pads zero blocks in the own column
@@ -370,16 +371,28 @@ int Engine::prepare()
             const char *env = std::getenv("MI_BA_PCG_ELL");
             pcg_ell_w_ = (env ? std::atoi(env) != 0 : true) && W > 0 && (double)mv_ * W <= kPcgEllMaxFill * pl.nb_full() ? W : 0;
             if (pcg_ell_w_) {
-                std::vector<int> ecol((size_t)mv_ * W), epos(pl.nb_full());
+                std::vector<int> ecol((size_t)mv_ * W);
                 for (int j = 0; j < mv_; ++j)
                     for (int t = 0; t < W; ++t) {
                         const int q = pl.bsr_row[j] + t;
                         const bool real = q < pl.bsr_row[j + 1];
                         ecol[(size_t)j * W + t] = real ? pl.bsr_col[q] : j;
-                        if (real) epos[q] = j * W + t;
                     }
-                UP(d_ell_col_, ecol); UP(d_ell_pos_, epos);
+                UP(d_ell_col_, ecol);
             }
+            // k_scale_blocks' work list: the blocks on and above the diagonal with everything the kernel needs to know about them and their mirror blocks
+            std::vector<int> sl;
+            sl.reserve((size_t)pl.nb_up() * 8);
+            for (int j = 0; j < mv_; ++j)
+                for (int q = pl.bsr_row[j]; q < pl.bsr_row[j + 1]; ++q) {
+                    const int k = pl.bsr_col[q];
+                    if (k < j) continue;
+                    const int bm = k == j ? -1 : tq[q];
+                    const int pe = pcg_ell_w_ ? j * W + (q - pl.bsr_row[j]) : q, pme = bm < 0 ? -1 : pcg_ell_w_ ? k * W + (bm - pl.bsr_row[k]) : bm;
+                    const int e[8] = { j, k, pl.bsr_src[q], q, bm, pe, pme, 0 };
+                    sl.insert(sl.end(), e, e + 8);
+                }
+            UP(d_scale_list_, sl);
         }
         pcg_push_ok_ = sym && (size_t)pl.nb_full() * 64 * sizeof(double) <= kPcgF32FromBytes && std::getenv("MI_BA_PCG_PUSH") && std::atoi(std::getenv("MI_BA_PCG_PUSH")) != 0;
         if (pcg_push_ok_) UP(d_bsr_tq_, tq);
@@ -827,7 +840,7 @@ PcgStart Engine::pcg_start()
     const PcgArgs p = pcg_args();
     timing.pcg_matrix_f32 = pcg_f32_() ? 1.0 : 0.0;
     timing.pcg_push = p.mb0 ? 1.0 : 0.0;
-    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr, p.ell_w ? d_ell_pos_.p : nullptr, pcg_f32_() ? 1 : pcg_cm_() ? 2 : 0 };
+    return PcgStart{ p.E, p.x, p.r0, p.p, p.s0, p.s1, persist_ok_ ? d_bar_.p : nullptr, d_scale_list_.p, (int)(d_scale_list_.n / 8), p.ell_w ? 1 : 0, pcg_f32_() ? 1 : pcg_cm_() ? 2 : 0 };
 }
 
 PcgArgs Engine::pcg_args()

@@ -149,7 +149,7 @@ private:
 
     // device: plan
     DevBuf<int> d_tile_batch_, d_tile_slot_, d_tile_cslot_, d_slot_gblk_, d_cslot_cam_, d_batch_obs_, d_batch_pt_, d_pt_obs_,
-        d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_, d_bsr_tq_, d_ell_col_, d_ell_pos_;
+        d_obs_cam_, d_obs_pt_, d_bsr_row_, d_bsr_rowidx_, d_bsr_col_, d_bsr_src_, d_bsr_diag_, d_bsr_tq_, d_ell_col_, d_scale_list_;
     DevBuf<long long> d_batch_pair_;
     DevBuf<unsigned char> d_obs_cslot_, d_bsr_trans_, d_fixed_, d_pfix_;   // per ROW of the camera-side arrays: held camera; bit r = parameter r held constant
     DevBuf<unsigned char> d_fixed_real_;                                    // per real camera (the point-side kernels)

@@ -147,7 +147,7 @@ struct SchurArgs {
 };
 
 // where the CG starts: written by k_block_inv, which holds L^-1 of every camera's diagonal block anyway
-struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; const int *ellpos /* with PcgArgs.ell_w: where block b of the pattern goes in the padded matrix; nullptr: at b */; int layout /* of the scaled matrix in S_pcg: 0 f64 blocks row-major, 1 single precision (PcgArgs.S32), 2 f64 in the product's column form (PcgArgs.cm) */; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
+struct PcgStart { const double *E; double *x, *r0, *p, *s0, *s1; unsigned long long *bar; const int *list /* k_scale_blocks' work list: 8 ints per block on or above the diagonal (kernels.hip) */; int nlist; int ell /* with PcgArgs.ell_w: the blocks go to their fixed-pitch positions */; int layout /* of the scaled matrix in S_pcg: 0 f64 blocks row-major, 1 single precision (PcgArgs.S32), 2 f64 in the product's column form (PcgArgs.cm) */; /* k_pcg_persist's barrier words, zeroed here; or nullptr */ };
 // grid-barrier words of the persistent reduced solve (u64, 64-byte apart): root counter, generation, abort, one counter per group
 constexpr int kBarRoot = 0, kBarGen = 8, kBarAbort = 16, kBarGroup0 = 32, kBarMaxGroups = 32, kBarWords = kBarGroup0 + 8 * kBarMaxGroups;
 

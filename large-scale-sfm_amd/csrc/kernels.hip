@@ -2488,36 +2488,41 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
 // chain of two memory round trips and three LDS exchanges per block, 4.5 (C3) to 50 (C4) of them one after the other per wavefront slot
 // (C3 19.5 us, C4 184 us for 26 / 260 MB).  Diagonal blocks are the identity by construction: nothing is fetched for them.
 // layout 1: the scaled matrix is stored in single precision instead (PcgArgs.S32: the CG then streams half the bytes; engine.cpp pcg_f32_)
-__global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg, int layout, const int *__restrict__ ellpos)
+// Round 4, second step: only the blocks on and above the diagonal are multiplied -- S~_kj is S~_jk transposed, to the last bit, so the lane that holds
+// element (r, c) of block (j, k) also stores it as element (c, r) of block (k, j): half the products and half the LDS traffic (the kernel is LDS-bound:
+// 16 KB of operand reads per block).  `list`: per block with k >= j eight ints { j, k, upper block, b, b of the mirror block or -1, fixed-pitch position
+// of b, of the mirror, - } (engine.cpp prepare): everything a block needs to know arrives in ONE round, two blocks ahead.
+__global__ __launch_bounds__(256) void k_scale_blocks(int nl, const int4 *__restrict__ list, const FinalizeArgs f, const double *__restrict__ Linv, double *__restrict__ S_pcg, int layout, int ell)
 {
     __shared__ double sh[4][4][64];   // per wavefront: S, T = Linv_j S, Linv_j, Linv_k
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane >> 3, c = lane & 7;
     const int nw = (int)gridDim.x * 4;
-    int b = (int)blockIdx.x * 4 + wv;                 // (left a per-lane value on purpose: made wave-uniform, every index load is followed by a wait for its v_readfirstlane)
-    if (b >= nb) return;
-    struct Idx { int j, k, src, trans, pos; };        // pos: where the block goes (the fixed-pitch matrix of the CG: PcgArgs.ell_w)
+    int i = (int)blockIdx.x * 4 + wv;                 // (left a per-lane value on purpose: made wave-uniform, every index load is followed by a wait for its v_readfirstlane)
+    if (i >= nl) return;
+    struct Idx { int j, k, src, b, bm, pe, pme; };
     struct Dat { double s, lj, lk; int fx, pj, pk; };
-    auto ldidx = [&](int bb) {                        // (past the end: the last block again, never used)
-        const int q = bb < nb ? bb : nb - 1;
-        return Idx{ f.rowidx[q], f.col[q], f.src[q], (int)f.trans[q], ellpos ? ellpos[q] : q };
+    auto ldidx = [&](int ii) {                        // (past the end: the last entry again, never used)
+        const int q = ii < nl ? ii : nl - 1;
+        const int4 u = list[2 * (size_t)q], w2 = list[2 * (size_t)q + 1];
+        return Idx{ u.x, u.y, u.z, u.w, w2.x, w2.y, w2.z };
     };
     auto lddat = [&](const Idx &x) {                  // every load unconditional and independent of the others
         Dat d;
-        d.s = f.S_up[(size_t)x.src * 64 + (x.trans ? c * 8 + r : r * 8 + c)];
+        d.s = f.S_up[(size_t)x.src * 64 + r * 8 + c];
         d.lj = Linv[(size_t)x.j * 64 + lane]; d.lk = Linv[(size_t)x.k * 64 + lane];
         d.fx = (int)f.fixed[x.j] | (int)f.fixed[x.k]; d.pj = f.pfix[x.j]; d.pk = f.pfix[x.k];
         return d;
     };
-    Idx i0 = ldidx(b), i1 = ldidx(b + nw);
+    Idx i0 = ldidx(i), i1 = ldidx(i + nw);
     Dat d0 = lddat(i0);
-    for (; b < nb; b += nw) {
-        const Idx i2 = ldidx(b + 2 * nw);
+    for (; i < nl; i += nw) {
+        const Idx i2 = ldidx(i + 2 * nw);
         const Dat d1 = lddat(i1);
         const int j = i0.j, k = i0.k;
         double o = 0.0;
         if (j != k) {                                     // (the same for all lanes)
             double v = d0.s;
-            if (r == c && f.lk.row) { const int pq = f.lk.blk_pair[b]; if (pq >= 0) v -= f.lk.pair_w[(size_t)pq * kCP + r]; }   // shared-intrinsics links: U_jk = -w
+            if (r == c && f.lk.row) { const int pq = f.lk.blk_pair[i0.b]; if (pq >= 0) v -= f.lk.pair_w[(size_t)pq * kCP + r]; }   // shared-intrinsics links: U_jk = -w
             // fixed cameras, padding rows / columns, constant parameters (finalized_element)
             if (d0.fx | (r >= f.cnp) | (c >= f.cnp) | ((d0.pj >> r) & 1) | ((d0.pk >> c) & 1)) v = 0.0;
             sh[wv][0][lane] = v; sh[wv][2][lane] = d0.lj; sh[wv][3][lane] = d0.lk;
@@ -2535,9 +2540,19 @@ __global__ __launch_bounds__(256) void k_scale_blocks(int nb, const FinalizeArgs
         // The product's column forms (row_products): a lane of the product holds ONE column's elements of a few rows and needs one 8-byte element of
         // the vector for them.  f64 (layout 2): element (r, c) at ((r >> 1) * 8 + c) * 2 + (r & 1) -- rows 2h, 2h + 1 of column c in one 16-byte load.
         // Single precision (layout 1): at ((r >> 2) * 8 + c) * 4 + (r & 3) -- rows 4h .. 4h + 3 of column c in one 16-byte load.
-        if (layout == 1) reinterpret_cast<float *>(S_pcg)[(size_t)b * 64 + (((r >> 2) * 8 + c) * 4 + (r & 3))] = (float)val;
-        else if (layout == 2) S_pcg[(size_t)i0.pos * 64 + (((r >> 1) * 8 + c) * 2 + (r & 1))] = val;
-        else S_pcg[(size_t)b * 64 + lane] = val;
+        // The mirror block gets the same value as its element (c, r).
+        const bool mir = i0.bm >= 0;
+        if (layout == 1) {
+            float *Sf = reinterpret_cast<float *>(S_pcg);
+            Sf[(size_t)i0.b * 64 + (((r >> 2) * 8 + c) * 4 + (r & 3))] = (float)val;
+            if (mir) Sf[(size_t)i0.bm * 64 + (((c >> 2) * 8 + r) * 4 + (c & 3))] = (float)val;
+        } else if (layout == 2) {
+            S_pcg[(size_t)(ell ? i0.pe : i0.b) * 64 + (((r >> 1) * 8 + c) * 2 + (r & 1))] = val;
+            if (mir) S_pcg[(size_t)(ell ? i0.pme : i0.bm) * 64 + (((c >> 1) * 8 + r) * 2 + (c & 1))] = val;
+        } else {
+            S_pcg[(size_t)i0.b * 64 + lane] = val;
+            if (mir) S_pcg[(size_t)i0.bm * 64 + c * 8 + r] = val;
+        }
         i0 = i1; i1 = i2; d0 = d1;
     }
 }
@@ -4180,7 +4195,7 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
     hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
-    hipLaunchKernelGGL(k_scale_blocks, dim3(std::min((nb + 3) / 4, kScaleBlocksGrid)), dim3(256), 0, st, nb, f, Linv, S_pcg, ps.layout, ps.layout == 2 ? ps.ellpos : nullptr);
+    hipLaunchKernelGGL(k_scale_blocks, dim3(std::min((ps.nlist + 3) / 4, kScaleBlocksGrid)), dim3(256), 0, st, ps.nlist, reinterpret_cast<const int4 *>(ps.list), f, Linv, S_pcg, ps.layout, ps.layout == 2 && ps.ell ? 1 : 0);
     if (co.ng) {   // the coarse space of this trial's system: Z'SZ, its inverse, S~Z~
         static_assert(kBcSlots == 4, "k_coarse_bc: one wavefront per slot");
         hipLaunchKernelGGL(k_coarse_bc, dim3(m), dim3(256), 0, st, m, bsr_row, bsr_col, (const double *)S_pcg, co);

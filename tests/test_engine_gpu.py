@@ -329,7 +329,9 @@ def test_persistent_reduced_solve_equals_the_launched_one(oracle, monkeypatch, s
     # (the two runs' CG iterates differ at rounding level -- the partial sums are grouped by different workgroups --, and a whole
     #  Levenberg-Marquardt run amplifies that to ~1e-8 of the cost)
     assert ret1 == ret0 and info1[6] == info0[6] and abs(info1[1] - info0[1]) < 1e-6 * info0[1] and np.abs(p1 - p0).max() < 1e-4
-    assert len(tr1) == len(tr0) and np.abs(tr1[:, 5] - tr0[:, 5]).max() <= 2          # CG iterations trial by trial
+    # CG iterations trial by trial: equal to within two while the solves are short; the long solves at the end of a run (residual 1e-10 of the first: the
+    # recurrence's rounding decides when the test is met) to within 15 %
+    assert len(tr1) == len(tr0) and np.all(np.abs(tr1[:, 5] - tr0[:, 5]) <= np.maximum(2, 0.15 * tr0[:, 5]))
 
 
 @pytest.mark.parametrize("two_level", ["1", "-1"])
