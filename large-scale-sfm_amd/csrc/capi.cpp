@@ -97,9 +97,9 @@ int mi_ba_set_timing_detail(mi_ba_engine *h, int level) { if (!h) return MI_BA_E
 int mi_ba_reset_timing(mi_ba_engine *h)
 {
     if (!h) return MI_BA_ERROR;
-    const double bytes = h->e->timing.build_bytes, flops = h->e->timing.build_flops, index = h->e->timing.build_index_bytes;
-    h->e->timing = mi_ba_timing{};
-    h->e->timing.build_bytes = bytes; h->e->timing.build_flops = flops; h->e->timing.build_index_bytes = index;
+    const double bytes = h->e->timing.build_bytes, flops = h->e->timing.build_flops, index = h->e->timing.build_index_bytes, hand = h->e->timing.build_block_handovers;
+    h->e->timing = mi_ba_timing{};   // (the figures of the plan stay)
+    h->e->timing.build_bytes = bytes; h->e->timing.build_flops = flops; h->e->timing.build_index_bytes = index; h->e->timing.build_block_handovers = hand;
     return 0;
 }
 
