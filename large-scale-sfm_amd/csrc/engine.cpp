@@ -543,7 +543,7 @@ int Engine::prepare()
         // back-substitution's (k_backsub's grid | the long tracks | the uniform tiles)
         !hipok(d_part_.alloc((size_t)(2 * (pl.ntile() + pl.long_pts.size()) + kBacksubGridMax + pl.ntile() + 2) * kPartW), "alloc partials") ||
         !hipok(d_stage_.alloc((size_t)2 * kReduceStage * kPartW), "alloc reduce stage") ||
-        !hipok(d_cam_part_.alloc((size_t)((mv_ * kCP + 63) / 64 + 1) * kPartW), "alloc camera partials") ||
+        !hipok(d_cam_part_.alloc((size_t)(mv_ + 1) * kPartW), "alloc camera partials") ||
         !hipok(d_cam_part2_.alloc((size_t)((m_ + 7) / 8 + 1) * kPartW), "alloc camera partials"))
         return MI_BA_ERROR;
     if (cfg.world > 1 && !hipok(d_full_pts_.alloc((size_t)n_ * 3), "alloc full pts")) return MI_BA_ERROR;
@@ -798,6 +798,7 @@ bool Engine::linear_phase(double mu, bool want_diag, const double *spec)
         if (ell_now && ell_pads_dirty_ && !hipok(hipMemsetAsync(d_S_pcg_.p, 0, d_S_pcg_.n * sizeof(double), st_), "memset S~")) return false;
         ell_pads_dirty_ = !ell_now;
     }
+    fv_rows_ = want_diag ? (mv_ * kCP + 63) / 64 : mv_;   // (launch_finalize: the camera-side vectors inside k_block_inv unless the hooks want the full matrix / the sums now)
     launch_finalize(st_, cnp_cam_(), mv_, pl.nb_full(), d_fixed_.p, d_pfix_.p, mu, spec, d_bsr_rowidx_.p, d_bsr_col_.p, d_bsr_src_.p, d_bsr_trans_.p, d_bsr_diag_.p,
                     S_up_(), want_diag ? d_S_full_.p : nullptr, camvec_(), d_cam_a_[cur_].p, d_cam_cw_.p, d_cam_cv_.p, links_, d_E_.p,
                     d_cam_part_.p, d_stage_.p, scal_(), d_Linv_.p, d_S_pcg_.p, want_diag /* a linear phase on its own (begin, parity hooks) */, pcg_start(),
@@ -998,7 +999,7 @@ bool Engine::update_phase(double mu, double *dB_dev, bool peek)
     launch_reduce_final(st_, b.ngrid + nlong + b.uni_ntile, b.part, d_stage_.p, scal_() + SC_COST_NEW,
                         cfg.world > 1 ? slots2_() + (size_t)cfg.rank * 8 : scal_() + SC_MAX_PCT,
                         m_, mv_, d_cam_part_.p, d_cam_part2_.p, scal_(), peek ? d_spec_.p : nullptr, peek_args(mu),
-                        build_part_pending_ ? pl.ntile() + nlong : 0, d_part_.p, scal_() + SC_COST, scal_() + SC_EB_INF);
+                        build_part_pending_ ? pl.ntile() + nlong : 0, d_part_.p, scal_() + SC_COST, scal_() + SC_EB_INF, fv_rows_);
     if (!allreduce2()) return false;
     return hipok(hipGetLastError(), "launch (solve phase)");
 }

@@ -70,6 +70,7 @@ public:
     bool pcg_cm_() const;
     int pcg_ell_w_ = 0;                           // row pitch of the CG's fixed-pitch matrix (0: rows by bsr_row): prepare()
     bool ell_pads_dirty_ = false;                 // ... its pads have been written over by a trial in another layout
+    int fv_rows_ = 0;                             // partial rows the camera-side vectors of the present linearisation left (engine.cpp linear_phase)
     bool build_part_pending_ = false;             // the build's partial rows of the present linearisation are summed by the trial's k_reduce_final (engine.cpp linear_phase)
     size_t bs_row0_() const { return (size_t)plan_.ntile() + plan_.long_pts.size(); }   // first partial row of the back-substitution
     bool pcg_push_ok_ = false;                    // the reduced solve's push halo (opt-in MI_BA_PCG_PUSH=1: mailboxes allocated, symmetric pattern)

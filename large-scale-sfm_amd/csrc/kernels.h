@@ -233,7 +233,8 @@ void launch_lm_peek(hipStream_t st, double *scal, const PeekArgs &pk, double *sp
 void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
                          int m /* real cameras */, int mv /* rows of the camera-side arrays */, const double *fv_part, const double *cu_part,
                          double *scal, double *spec /* or nullptr */, const PeekArgs &pk,
-                         int bp_rows /* the build's partial rows, still to be summed (0: done after the build) */, const double *bp_part, double *bp_sum, double *bp_max);
+                         int bp_rows /* the build's partial rows, still to be summed (0: done after the build) */, const double *bp_part, double *bp_sum, double *bp_max,
+                         int fv_rows /* partial rows of the camera-side vectors: mv (inside k_block_inv) or ceil(8 mv / 64) (k_finalize_vec) */);
  // out8[c] = max over the ranks' slots, which are zeroed
 void launch_cam_update(hipStream_t st, int m, int cnp, const ModelCfg &cfg, const unsigned char *fixed, double mu, const double *cam_a, const PcgArgs &pa,
                        double *dA, const double *camvec, const double *R0, const double *f_fixed, const CamLinks &links, double *cam_a_new,

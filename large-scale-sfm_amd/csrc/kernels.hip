@@ -2348,7 +2348,7 @@ struct FinalizeArgs {
     CamLinks lk;
 };
 
-__device__ __forceinline__ double finalized_element(const FinalizeArgs &f, int blk, int el)
+__device__ __forceinline__ double finalized_element(const FinalizeArgs &f, int blk, int el, const double *du_now = nullptr /* diag U of this camera as just updated (k_block_inv with k_finalize_vec's work inside) */)
 {
     const int r = el >> 3, c = el & 7, j = f.rowidx[blk], k = f.col[blk];
     const double *sb = f.S_up + (size_t)f.src[blk] * 64;
@@ -2357,7 +2357,7 @@ __device__ __forceinline__ double finalized_element(const FinalizeArgs &f, int b
         v = 0.5 * (sb[r * 8 + c] + sb[c * 8 + r]);
         if (r == c && r < f.cnp && f.lk.row)                           // shared-intrinsics links: U_jj += sum w
             for (int q = f.lk.row[j]; q < f.lk.row[j + 1]; ++q) v += f.lk.w[(size_t)q * kCP + r];
-        if (r == c) v = (r < f.cnp) ? v + (f.spec ? f.spec[1] : f.mu) * (f.diagU ? f.diagU[j * 8 + r] : 1.0) + f.cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
+        if (r == c) v = (r < f.cnp) ? v + (f.spec ? f.spec[1] : f.mu) * (f.diagU ? (du_now ? du_now[r] : f.diagU[j * 8 + r]) : 1.0) + f.cam_cw[j * 8 + r] : 1.0;   // damping + soft camera constraint (sba_levmar.c:959)
         if (f.fixed[j]) v = (r == c) ? 1.0 : 0.0;
     } else {
         v = f.trans[blk] ? sb[c * 8 + r] : sb[r * 8 + c];
@@ -2429,15 +2429,54 @@ __global__ __launch_bounds__(256) void k_finalize_vec(int m, int cnp, const unsi
 // ------------------------------------------------------------------------------------------
 // one wavefront per camera: the 64 lanes fetch the diagonal block's 64 finalised elements at once (one round of memory
 // latency instead of 36 dependent ones), lane 0 factors it from LDS and writes L^-1
+// k_finalize_vec's arguments, for its work done inside k_block_inv (fv.on; the trial's common case: one launch less): a camera's parameter r on lane (r, 0)
+// of the camera's wavefront, one partial row per camera
+struct FvArgs { int on; double *camvec; const double *cam_a, *cam_cw, *cam_cv; double *E, *part; };
 __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict__ bsr_diag, const FinalizeArgs f,
-                                                  double *__restrict__ Linv, double *__restrict__ scal, const PcgStart ps, double *__restrict__ Lfac)
+                                                  double *__restrict__ Linv, double *__restrict__ scal, const PcgStart ps, double *__restrict__ Lfac, const FvArgs fv)
 {
-    __shared__ double sb[4][64], so[4][64];
+    __shared__ double sb[4][64], so[4][64], sE[4][8], sDu[4][8];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, j = blockIdx.x * 4 + wv;
     const bool live = j < m;
     if (ps.bar && blockIdx.x == 0)        // the persistent solve's barrier words start every trial from zero (k_pcg_persist)
         for (int i = threadIdx.x; i < kBarWords; i += blockDim.x) ps.bar[i] = 0ull;
-    sb[wv][lane] = live ? finalized_element(f, bsr_diag[j], lane) : (lane % 9 == 0 ? 1.0 : 0.0);
+    if (fv.on) {   // (uniform) the right-hand side E_j, |e_a|inf, max diag U, |a|^2 and the camera-side penalties of camera j: k_finalize_vec, line by line
+        double eainf = 0.0, maxdu = 0.0, pl2 = 0.0, cc = 0.0, lc = 0.0;
+        const int pr_ = lane >> 3;
+        if (live && (lane & 7) == 0) {
+            const int gid = j * kCP + pr_;
+            const bool plive = (pr_ < f.cnp) && !f.fixed[j] && !((f.pfix[j] >> pr_) & 1);
+            double ea = fv.camvec[gid], Ev = fv.camvec[(size_t)m * kCP + gid], du = fv.camvec[2 * (size_t)m * kCP + gid];
+            if (pr_ < f.cnp) {
+                const double a = fv.cam_a[gid], w = fv.cam_cw[gid], d = fv.cam_cv[gid] - a;
+                pl2 = a * a;
+                cc = w * d * d;
+                double add = 0.0, dadd = 0.0;
+                if (w != 0.0) { add = w * d; dadd = w; }
+                if (f.lk.row)
+                    for (int q = f.lk.row[j]; q < f.lk.row[j + 1]; ++q) {
+                        const double wq = f.lk.w[(size_t)q * kCP + pr_], dq = fv.cam_a[(size_t)f.lk.other[q] * kCP + pr_] - a;
+                        add = fma(wq, dq, add); dadd += wq;
+                        lc = fma(0.5 * wq, dq * dq, lc);
+                    }
+                if (plive && (add != 0.0 || dadd != 0.0)) {
+                    ea += add; Ev += add; du += dadd;
+                    fv.camvec[gid] = ea;
+                    fv.camvec[2 * (size_t)m * kCP + gid] = du;
+                }
+            }
+            const double Eo = plive ? Ev : 0.0;
+            fv.E[gid] = Eo; sE[wv][pr_] = Eo; sDu[wv][pr_] = du;
+            if (plive) { eainf = fabs(ea); maxdu = du; }
+        }
+        eainf = wave_max(eainf); maxdu = wave_max(maxdu); pl2 = wave_sum(pl2); cc = wave_sum(cc); lc = wave_sum(lc);
+        if (live && lane == 0) {
+            double *pr = fv.part + (size_t)j * kPartW;
+            pr[0] = pl2; pr[1] = cc; pr[2] = lc; pr[3] = 0.0; pr[4] = eainf; pr[5] = maxdu; pr[6] = 0.0; pr[7] = 0.0;
+        }
+        wave_lds_sync();
+    }
+    sb[wv][lane] = live ? finalized_element(f, bsr_diag[j], lane, fv.on ? sDu[wv] : nullptr) : (lane % 9 == 0 ? 1.0 : 0.0);
     wave_lds_sync();
     // right-looking Cholesky in LDS, lane (r, c): eight steps of (pivot, column, trailing update), the lower triangle of sb
     // becomes L; then lane c solves L x = e_c for column c of L^-1.  (One lane doing all of it serially took 7 us.)
@@ -2472,7 +2511,7 @@ __global__ __launch_bounds__(256) void k_block_inv(int m, const int *__restrict_
         Linv[(size_t)j * 64 + lane] = so[wv][lane];
         if (Lfac) Lfac[(size_t)j * 64 + lane] = c <= r ? sb[wv][lane] : 0.0;   // the factor itself, for the coarse space (k_pcg2_*)
         if (lane < 8) { // the start of the CG on the scaled system: r_0 = E~ = L^-1 E, x~_0 = 0 (this camera's rows)
-            const double *Ej = ps.E + (size_t)j * 8;
+            const double *Ej = fv.on ? sE[wv] : ps.E + (size_t)j * 8;
             double rr = 0.0;
 #pragma unroll
             for (int c = 0; c < 8; ++c) rr += so[wv][lane * 8 + c] * Ej[c];
@@ -4190,11 +4229,15 @@ void launch_finalize(hipStream_t st, int cnp, int m, int nb, const unsigned char
     f.S_up = S_up; f.cam_cw = cam_cw; f.lk = links;
     f.diagU = damp_diag ? camvec + 2 * (size_t)m * kCP : nullptr;
     const long long total = (long long)nb * 64;
-    hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, pfix, camvec, cam_a, cam_cw, cam_cv,
-                       links, E, cam_part);
+    // the camera-side vectors (E, the norms, the penalties): inside k_block_inv -- unless the full matrix (parity hooks) or the sums are wanted right away
+    const bool fused = !S_full && !reduce_now;
+    if (!fused)
+        hipLaunchKernelGGL(k_finalize_vec, dim3((m * kCP + 255) / 256), dim3(256), 0, st, m, cnp, fixed, pfix, camvec, cam_a, cam_cw, cam_cv,
+                           links, E, cam_part);
     if (S_full) hipLaunchKernelGGL(k_finalize, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nb, f, S_full);
     if (reduce_now) launch_reduce_partials(st, (m * kCP + 63) / 64, cam_part, stage, scal + SC_PL2_CAMS, scal + SC_EA_INF);   // else: k_reduce_final
-    hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr);
+    const FvArgs fv{ fused ? 1 : 0, camvec, cam_a, cam_cw, cam_cv, E, cam_part };
+    hipLaunchKernelGGL(k_block_inv, dim3((m + 3) / 4), dim3(256), 0, st, m, bsr_diag, f, Linv, scal, ps, co.ng ? co.Lfac : nullptr, fv);
     hipLaunchKernelGGL(k_scale_blocks, dim3(std::min((ps.nlist + 3) / 4, kScaleBlocksGrid)), dim3(256), 0, st, ps.nlist, reinterpret_cast<const int4 *>(ps.list), f, Linv, S_pcg, ps.layout, ps.layout == 2 && ps.ell ? 1 : 0);
     if (co.ng) {   // the coarse space of this trial's system: Z'SZ, its inverse, S~Z~
         static_assert(kBcSlots == 4, "k_coarse_bc: one wavefront per slot");
@@ -4343,7 +4386,7 @@ void launch_cam_rebase(hipStream_t st, int m, int row_stride, double *cam_a, dou
 // last stage of the back-substitution's reduction (its first stage first when there are many rows) + the camera-side sums + peek
 void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, double *stage, double *bs_sum, double *bs_max,
                          int m, int mv, const double *fv_part, const double *cu_part, double *scal, double *spec, const PeekArgs &pk,
-                         int bp_rows, const double *bp_part, double *bp_sum, double *bp_max)
+                         int bp_rows, const double *bp_part, double *bp_sum, double *bp_max, int fv_rows)
 {
     FinalReduceArgs a;
     a.bs_part = bs_part; a.bs_rows = bs_rows;
@@ -4363,7 +4406,7 @@ void launch_reduce_final(hipStream_t st, int bs_rows, const double *bs_part, dou
         }
     }
     a.bs_sum = bs_sum; a.bs_max = bs_max;
-    a.fv_part = fv_part; a.fv_rows = (mv * kCP + 63) / 64;     // k_finalize_vec: a row per wavefront of (virtual camera, parameter) threads
+    a.fv_part = fv_part; a.fv_rows = fv_rows;                  // k_finalize_vec: a row per wavefront of (virtual camera, parameter) threads; inside k_block_inv: a row per camera
     a.cu_part = cu_part; a.cu_rows = mv == m ? (m + 7) / 8 : (m + 63) / 64;   // k_cam_update8: eight cameras per wavefront (k_cam_update, nine parameters: 64)
     a.scal = scal; a.spec = spec; a.pk = pk;
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(1024), 0, st, a);
