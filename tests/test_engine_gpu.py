@@ -1105,3 +1105,27 @@ def test_super_blocks_against_the_oracle(oracle, monkeypatch, levels):
         assert ret == o["ret"] and abs(info[1] - o["info"][1]) < 1e-8 * o["info"][1]
         eng.close()
 
+
+def test_super_blocks_equal_the_pair_lists_on_a_ladybug_like_scene(monkeypatch):
+    """A scene of BASELINE config C4's shape, large enough that the planner chooses the super-blocks by itself (>= 2^20 row-path pairs, cameras along a
+    path): the reduced system they build is the one the per-block pair lists build (MI_BA_SUPER=0) -- the same pairs summed in another order: S to
+    1e-12 of |U|, E to 1e-11 -- and the two solves take the same iterations to the same cost."""
+    scene, capi = pkg("scene"), pkg("capi")
+    sc = scene.ladybug_like_scene(m=300, n=24000, dmax=60, seed=7)
+    res = {}
+    for mode in ("default", "0"):
+        if mode == "0":
+            monkeypatch.setenv("MI_BA_SUPER", "0")
+        else:
+            monkeypatch.delenv("MI_BA_SUPER", raising=False)
+        pl = capi.Plan(sc.n, sc.m, sc.obs_pt(), sc.obs_cam)
+        assert (len(pl.get("sb_q")) > 1) == (mode == "default") and pl.stats()["npair_rows"] >= 1 << 20
+        eng = make_engine(sc, pcg_tol=1e-10, pcg_maxit=400)
+        g = eng.debug_linearize(1e-3)
+        ret, info = eng.run()
+        res[mode] = (g["S"].copy(), g["E"].copy(), g["diagU"].max(), ret, np.array(info))
+        eng.close()
+    (S1, E1, u1, r1, i1), (S0, E0, u0, r0, i0) = res["default"], res["0"]
+    assert np.abs(S1 - S0).max() < 1e-12 * u0 * 10 and rel(E1.reshape(-1), E0.reshape(-1)) < 1e-11
+    assert r1 == r0 and i1[6] == i0[6] and abs(i1[1] - i0[1]) < 1e-9 * i0[1]
+
