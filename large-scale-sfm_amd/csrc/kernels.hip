@@ -2306,10 +2306,15 @@ __global__ __launch_bounds__(1024) void k_reduce_final(const FinalReduceArgs a)
 #pragma unroll
             for (int c = 4; c < kPartW; ++c) acc[k][c] = fmax(acc[k][c], pr[c]);
         }
+        // A wave-wide f64 sum is ~20 instructions; 16 wavefronts x 32 of them were most of this kernel's 11 us.  Only the wavefronts that hold rows of
+        // a set reduce it, and only the columns its producer fills (k_finalize_vec: 0-2, 4, 5; k_cam_update: 0-2) -- the others are zero by construction.
+        constexpr unsigned kUsed[4] = { 0x37u, 0x07u, 0xFFu, 0xFFu };
+        const bool has = w * 64 < rows[k];                     // (wave-uniform)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[k][c] = wave_sum(acc[k][c]);
-#pragma unroll
-        for (int c = 4; c < kPartW; ++c) acc[k][c] = wave_max(acc[k][c]);
+        for (int c = 0; c < kPartW; ++c) {
+            if (!has || !((kUsed[k] >> c) & 1u)) acc[k][c] = 0.0;
+            else acc[k][c] = c < 4 ? wave_sum(acc[k][c]) : wave_max(acc[k][c]);
+        }
         if ((tid & 63) == 0)
 #pragma unroll
             for (int c = 0; c < kPartW; ++c) sh[k][w][c] = acc[k][c];
